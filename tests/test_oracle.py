@@ -1,0 +1,115 @@
+"""Pin the CPU oracle (oracle/sayuri_oracle.c) against golden vectors produced by the
+reference's own DNNLoader + BlasForwardPipe (tests/golden/make_golden.py).
+
+Tolerance: fp32, abs <= 2e-5 on raw outputs whose magnitude is O(1) (the reference build
+uses -ffast-math, so bit equality with any restatement is not defined); SURVEY.md 8c sets
+the fp32 parity gate at 1e-4."""
+import numpy as np
+import pytest
+
+from _golden import Golden
+from _oracle import PortNet, RefNet, ref_available
+from golden_specs import FIXTURES
+
+SMALL = [fx["name"] for fx in FIXTURES if fx["name"].startswith("tiny")]
+BIG = ["net_6b96", "net_20b256"]
+ATOL = 2e-5
+
+
+@pytest.mark.parametrize("name", SMALL + ["net_6b96"])
+def test_port_matches_reference_golden(name, tmp_weights_dir):
+    g = Golden(name, tmp_weights_dir)
+    nets = {}
+    for case in g.cases:
+        w = case["winograd"]
+        if w not in nets:
+            nets[w] = PortNet(g.weights_path, bool(w))
+        net = nets[w]
+        assert net.info == list(g.data["info"])
+        got = net.forward(g.planes(case), case["board_size"], offset=case["offset"])
+        exp = g.expected(case)
+        assert np.isfinite(got).all()
+        assert np.abs(got - exp).max() <= ATOL, (name, case, float(np.abs(got - exp).max()))
+    net = next(iter(nets.values()))
+    for i, b in enumerate(g.data["blocks"]):
+        assert net.block_info(i) == list(b)
+    for tn, exp in g.tensors().items():
+        got = net.tensor(tn)
+        assert got is not None and got.shape == exp.shape, tn
+        np.testing.assert_allclose(got, exp, rtol=2e-6, atol=1e-7, err_msg=tn)
+
+
+def test_port_matches_reference_golden_20b256(tmp_weights_dir):
+    # BASELINE.json configs[1] network; ~1 s per evaluation on one core
+    g = Golden("net_20b256", tmp_weights_dir)
+    net = PortNet(g.weights_path, True)
+    for case in g.cases[:2]:
+        got = net.forward(g.planes(case), case["board_size"], offset=case["offset"])
+        exp = g.expected(case)
+        assert np.abs(got - exp).max() <= 5e-5, float(np.abs(got - exp).max())
+
+
+def test_winograd_and_im2col_agree(tmp_weights_dir):
+    g = Golden("tiny_res", tmp_weights_dir)
+    a, b = PortNet(g.weights_path, True), PortNet(g.weights_path, False)
+    case = g.cases[2]
+    x = a.forward(g.planes(case), case["board_size"])
+    y = b.forward(g.planes(case), case["board_size"])
+    assert np.abs(x - y).max() < 2e-5
+
+
+def test_raw_heads_consistent_with_filloutputs(tmp_weights_dir):
+    # blas_forward_pipe.cc:565-619: v3+ nets pick plane `offset`, pass[offset], misc 0..3/8/13/14
+    g = Golden("tiny_res", tmp_weights_dir)
+    net = PortNet(g.weights_path, True)
+    case = g.cases[3]
+    bs, off = case["board_size"], case["offset"]
+    prob, pas, misc, own = net.forward_raw(g.planes(case), bs)
+    out = net.forward(g.planes(case), bs, offset=off)
+    s = bs * bs
+    np.testing.assert_array_equal(out[:s], prob[off])
+    np.testing.assert_array_equal(out[s:2 * s], own)
+    np.testing.assert_array_equal(out[2 * s:2 * s + 8],
+                                  [pas[off], misc[0], misc[1], misc[2], misc[3], misc[8], misc[13], misc[14]])
+
+
+def test_postprocess_properties(tmp_weights_dir):
+    g = Golden("tiny_res", tmp_weights_dir)
+    net = PortNet(g.weights_path, True)
+    case = g.cases[0]
+    bs = case["board_size"]
+    raw = net.forward(g.planes(case), bs)
+    post = PortNet.postprocess(raw, bs, 1.0)
+    s = bs * bs
+    assert abs(post[:s + 1].sum() - 1.0) < 1e-5
+    assert (np.abs(post[s + 1:2 * s + 1]) <= 1.0).all()
+    t = post[2 * s + 1:]
+    assert abs(t[:3].sum() - 1.0) < 1e-6 and 0 <= t[3] <= 1 and 0 <= t[4] <= 1
+    assert abs(t[5] - 20 * raw[2 * s + 5]) < 1e-6
+
+
+def test_loader_rejects_bad_files(tmp_path):
+    p = tmp_path / "bad.txt"
+    p.write_text("hello\n")
+    with pytest.raises(RuntimeError):
+        PortNet(str(p))
+    with pytest.raises(RuntimeError):
+        PortNet(str(tmp_path / "missing.bin"))
+    # truncated parameter stream
+    g = Golden("tiny_res", str(tmp_path))
+    blob = open(g.weights_path, "rb").read()
+    q = tmp_path / "trunc.bin"
+    q.write_bytes(blob[: len(blob) // 2])
+    with pytest.raises(RuntimeError):
+        PortNet(str(q))
+
+
+@pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (only in the dev container)")
+def test_live_reference_agrees_with_golden(tmp_weights_dir):
+    g = Golden("tiny_all", tmp_weights_dir)
+    net = RefNet(g.weights_path, True)
+    for case in g.cases:
+        if case["winograd"] != 1:
+            continue
+        got = net.forward(g.planes(case), case["board_size"], offset=case["offset"])
+        np.testing.assert_allclose(got, g.expected(case), rtol=0, atol=1e-6)
