@@ -1,0 +1,161 @@
+/* include/sayuri_hip.h -- C-ABI of the MI355X (gfx950) forward-pipe engine.
+ *
+ * This is the drop-in boundary for Sayuri's NN hot path.  In the reference the path sits
+ * behind `class NetworkForwardPipe` (reference src/neural/network_basic.h:132-161) and, for
+ * GPU backends, `BatchForwardPipe::BatchForward(int gpu, const std::vector<InputData>&)`
+ * (reference src/neural/batch_forward_pipe.h:27-28), implemented for CUDA by
+ * `CudaForwardPipe::NNGraph` (reference src/neural/cuda/cuda_forward_pipe.cc:133-1090).
+ * A `HipForwardPipe` (sayuri_amd/csrc/host/hip_forward_pipe.h, or the stub shown in
+ * INTEGRATION.md inside the reference tree) owns one `sayuri_hip_ctx` per GPU and calls the
+ * entry points below; no HIP or torch type crosses this header.
+ *
+ * Conventions: plain C, pointers + sizes, return 0 on success / -1 on failure with the
+ * message in sayuri_hip_last_error() (thread-local); no exception crosses the ABI
+ * (the C++ pipe turns -1 into std::runtime_error like reference cuda_common.cc:46-62).
+ * One ctx per GPU; a ctx is driven by ONE caller thread at a time (the pump thread).
+ */
+#ifndef SAYURI_HIP_H
+#define SAYURI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sayuri_hip_ctx sayuri_hip_ctx;
+
+/* reference src/neural/activation.h:8-17 (enum class Activation) */
+enum {
+    SAYURI_ACT_IDENTITY = 0, SAYURI_ACT_RELU = 1, SAYURI_ACT_ELU = 2, SAYURI_ACT_SELU = 3,
+    SAYURI_ACT_GELU = 4, SAYURI_ACT_MISH = 5, SAYURI_ACT_SWISH = 6, SAYURI_ACT_HARDSWISH = 7
+};
+
+/* reference src/neural/description.h:92-93 (BlockBasic::Type) */
+enum {
+    SAYURI_BLOCK_RESIDUAL = 1, SAYURI_BLOCK_BOTTLENECK = 2, SAYURI_BLOCK_NESTED_BOTTLENECK = 3,
+    SAYURI_BLOCK_MIXER = 4
+};
+
+/* One tower block: mirrors the shape fields of reference description.h:90-137 (BlockBasic). */
+typedef struct {
+    int32_t type;                 /* SAYURI_BLOCK_* */
+    int32_t apply_se;             /* BlockBasic::apply_se */
+    int32_t se_size;              /* BlockBasic::se_size */
+    int32_t bottleneck_channels;  /* BlockBasic::bottleneck_channels (0 if n/a) */
+    int32_t feedforward_channels; /* BlockBasic::feedforward_channels (0 if n/a) */
+    int32_t dw_filter;            /* dw_conv.GetFilter() for mixer blocks (0 if n/a) */
+} sayuri_hip_blockdesc;
+
+/* The architecture part of reference description.h:164-215 (DNNWeights). */
+typedef struct {
+    int32_t version;                  /* DNNWeights::version (1..5) */
+    int32_t input_channels;           /* 43 (v3+) or 38 */
+    int32_t residual_channels;
+    int32_t residual_blocks;
+    int32_t policy_head_channels;
+    int32_t value_head_channels;
+    int32_t probabilities_channels;   /* 5 (v3+) or 1 */
+    int32_t pass_probability_outputs; /* 5 (v3+) or 1 */
+    int32_t ownership_channels;       /* 1 */
+    int32_t value_misc_outputs;       /* 15 (v3+) or 5 */
+    int32_t default_act;              /* SAYURI_ACT_* */
+    int32_t policy_head_type;         /* 0 = kNormal, 1 = kRepLK */
+    int32_t policy_dw_filter;         /* p_dw_conv.GetFilter() when RepLK, else 0 */
+    const sayuri_hip_blockdesc* blocks; /* [residual_blocks] */
+} sayuri_hip_netdesc;
+
+/* Layer ids for sayuri_hip_load_tensor: the named members of DNNWeights / BlockBasic. */
+enum {
+    SAYURI_L_INPUT_CONV = 0, SAYURI_L_P_HD_CONV = 1, SAYURI_L_P_DW_CONV = 2, SAYURI_L_P_PT_CONV = 3,
+    SAYURI_L_P_INTER_FC = 4, SAYURI_L_PROB_CONV = 5, SAYURI_L_PASS_FC = 6, SAYURI_L_V_HD_CONV = 7,
+    SAYURI_L_V_INTER_FC = 8, SAYURI_L_V_OWNERSHIP = 9, SAYURI_L_V_MISC = 10,
+    SAYURI_L_BLOCK_BASE = 16 /* block b, slot s -> 16 + 16*b + s */
+};
+enum { /* slots inside a block */
+    SAYURI_S_CONV1 = 0, SAYURI_S_CONV2 = 1, SAYURI_S_CONV3 = 2, SAYURI_S_CONV4 = 3,
+    SAYURI_S_PRE_BTL = 4, SAYURI_S_POST_BTL = 5, SAYURI_S_DW_CONV = 6, SAYURI_S_SQUEEZE = 7,
+    SAYURI_S_EXCITE = 8
+};
+#define SAYURI_L_BLOCK(b, slot) (SAYURI_L_BLOCK_BASE + 16 * (b) + (slot))
+enum { SAYURI_T_WEIGHTS = 0, SAYURI_T_BIASES = 1 };
+
+/* Number of visible gfx950 devices (replaces reference src/utils/probe_gpu.h:10-27 GetGpuCount). */
+int sayuri_hip_device_count(void);
+
+/* Build the per-GPU graph: replaces NNGraph::ConstructGraph (cuda_forward_pipe.cc:133-613).
+ * `board` is the NN board size (ForwardPipeOption::board_size), `max_batch` the largest batch
+ * BatchForward will be handed, `use_fp16` mirrors option "fp16" (1: fp16 storage + MFMA with
+ * fp32 accumulation; 0: fp32 storage + fp32 MFMA, the strict-parity mode). NULL on failure. */
+sayuri_hip_ctx* sayuri_hip_create(int device, const sayuri_hip_netdesc* desc, int max_batch,
+                                  int board, int use_fp16);
+
+/* Hand one host tensor of DNNWeights to the device (replaces the LoadWeights calls of
+ * cuda_layers.cc:621-716).  Tensors are the BN-folded fp32 arrays the reference loader
+ * produces: conv weights [K][C][k][k] (depthwise [C][1][k][k]), fc weights [out][in],
+ * biases [K].  `n` must equal the element count implied by the netdesc. */
+int sayuri_hip_load_tensor(sayuri_hip_ctx* ctx, int layer_id, int kind, const float* host, size_t n);
+
+/* One batch through the net: replaces NNGraph::BatchForward (cuda_forward_pipe.cc:684-1018)
+ * up to, not including, FillOutputs.
+ *   planes      [n][input_channels][board*board]  each sample already re-padded top-left into
+ *               the NN grid as BatchForwardPipe::SendQueryAndWait does (batch_forward_pipe.cc:15-33)
+ *   board_sizes [n]  the sample's own board size (InputData::board_size), NULL = all `board`
+ *   prob [n][probabilities_channels][board*board], pass [n][pass_probability_outputs],
+ *   misc [n][value_misc_outputs], own [n][board*board]   raw (pre-softmax/tanh) outputs in the
+ *               NN grid; off-board entries of smaller samples are 0.
+ * Blocking; host pointers. */
+int sayuri_hip_forward(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes,
+                       float* prob, float* pass, float* misc, float* own);
+
+/* The three phases of sayuri_hip_forward, for callers that keep inputs resident in HBM
+ * (bench.py times `run` only) or overlap copies with compute. upload/download block. */
+int sayuri_hip_upload(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes);
+int sayuri_hip_run(sayuri_hip_ctx* ctx);   /* asynchronous on the ctx stream */
+int sayuri_hip_sync(sayuri_hip_ctx* ctx);
+int sayuri_hip_download(sayuri_hip_ctx* ctx, float* prob, float* pass, float* misc, float* own);
+
+/* Time `iters` back-to-back runs of the uploaded batch with HIP events on the ctx stream
+ * (torch.cuda.Event cannot see this stream). total_ms = wall of all iters on the device. */
+int sayuri_hip_time_runs(sayuri_hip_ctx* ctx, int iters, float* total_ms);
+
+/* Per-kernel-class device time of ONE run of the uploaded batch (events around every launch).
+ * Fills up to `cap` rows; returns the row count, -1 on error. */
+typedef struct {
+    char name[48];
+    int32_t launches;
+    float total_ms;
+    double flops;  /* algorithmic FLOPs (2*MAC of the direct convolution) of those launches */
+    double bytes;  /* algorithmic HBM bytes (inputs + outputs + weights once) of those launches */
+} sayuri_hip_kernel_stat;
+int sayuri_hip_profile_run(sayuri_hip_ctx* ctx, sayuri_hip_kernel_stat* rows, int cap);
+
+/* Page-locked host memory for the staging buffers handed to upload/download/forward
+ * (replaces the cudaHostAlloc staging of reference cuda_common.cc:312-403); the host side
+ * never includes a HIP header. */
+void* sayuri_hip_host_alloc(size_t bytes);
+void sayuri_hip_host_free(void* p);
+
+/* Bytes of device memory held by the ctx. */
+size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* ctx);
+
+/* Release everything (replaces NNGraph::DestroyGraph, cuda_forward_pipe.cc:1092-1130). */
+void sayuri_hip_destroy(sayuri_hip_ctx* ctx);
+
+const char* sayuri_hip_last_error(void);
+
+/* ---- layer-level taps for the parity tests (not used by the pipe) ---------------------- */
+/* One convolution layer on host NCHW fp32 tensors, through the same device kernels:
+ * x [n][cin][bs*bs] with per-sample board sizes (compact, stride bs*bs per channel),
+ * w [cout][cin][k][k], bias [cout] or NULL, res like the output or NULL,
+ * y [n][cout][bs*bs].  k = 1 or 3 (MFMA implicit GEMM) or depthwise (cin == 1 in w). */
+int sayuri_hip_test_conv(int device, int use_fp16, int n, const int* board_sizes, int max_board,
+                         int cin, int cout, int k, int depthwise, int act, int post_residual,
+                         const float* x, const float* w, const float* bias, const float* res,
+                         float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,82 @@
+"""Build the native libraries in-tree (they travel to the GPU box with the snapshot).
+
+    sayuri_amd/lib/libsayuri_hip.so   hipcc --offload-arch=gfx950 (kernels + C-ABI)
+    sayuri_amd/lib/libsayuri_host.so  g++ (weights loader, HipForwardPipe, ctypes wrapper)
+    oracle/libsayuri_oracle.so        gcc (CPU checker, test infrastructure)
+    oracle/_ref/libsayuri_ref.so      g++ on the reference's own sources, only where
+                                      /root/reference exists (dev container)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "sayuri_amd")
+LIB = os.path.join(PKG, "lib")
+HIP_SRC = os.path.join(PKG, "csrc", "hip")
+HOST_SRC = os.path.join(PKG, "csrc", "host")
+HIP_SO = os.path.join(LIB, "libsayuri_hip.so")
+HOST_SO = os.path.join(LIB, "libsayuri_host.so")
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _files(d: str, exts):
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIB, exist_ok=True)
+    srcs = _files(HIP_SRC, (".hip", ".h")) + [os.path.join(ROOT, "include", "sayuri_hip.h")]
+    if force or _newer(HIP_SO, srcs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               os.path.join(HIP_SRC, "engine.hip"), "-o", HIP_SO]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HIP_SO
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    build_hip(force=False, verbose=verbose)
+    srcs = _files(HOST_SRC, (".cc", ".h")) + [os.path.join(ROOT, "include", "sayuri_hip.h")]
+    if force or _newer(HOST_SO, srcs + [HIP_SO]):
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra"] + _files(HOST_SRC, (".cc",)) + \
+              ["-o", HOST_SO, "-L" + LIB, "-lsayuri_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_SO
+
+
+def build_oracle(verbose: bool = False) -> None:
+    odir = os.path.join(ROOT, "oracle")
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", odir, "port"], stdout=out)
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", odir, "-j8", "ref"], stdout=out, stderr=out)
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip(force, verbose)
+    build_host(force, verbose)
+    build_oracle(verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,86 @@
+"""ctypes bindings of the native libraries.  Loading fails LOUDLY: there is no CPU fallback
+for the product path (the CPU oracle lives under oracle/ and is test infrastructure)."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import _build
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+class KernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_int32), ("total_ms", ctypes.c_float),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
+# every symbol include/sayuri_hip.h declares
+HIP_SYMBOLS = [
+    "sayuri_hip_device_count", "sayuri_hip_create", "sayuri_hip_load_tensor", "sayuri_hip_forward",
+    "sayuri_hip_upload", "sayuri_hip_run", "sayuri_hip_sync", "sayuri_hip_download", "sayuri_hip_time_runs",
+    "sayuri_hip_profile_run", "sayuri_hip_host_alloc", "sayuri_hip_host_free", "sayuri_hip_device_bytes",
+    "sayuri_hip_destroy", "sayuri_hip_last_error", "sayuri_hip_test_conv",
+]
+
+_hip = None
+_host = None
+
+
+def _require(path: str) -> str:
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"native library {path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the MI355X forward pipe)")
+    return path
+
+
+def hip() -> ctypes.CDLL:
+    global _hip
+    if _hip is None:
+        lib = ctypes.CDLL(_require(_build.HIP_SO), mode=ctypes.RTLD_GLOBAL)
+        lib.sayuri_hip_last_error.restype = ctypes.c_char_p
+        lib.sayuri_hip_device_count.restype = ctypes.c_int
+        lib.sayuri_hip_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, c_float_p, c_int_p]
+        lib.sayuri_hip_run.argtypes = [ctypes.c_void_p]
+        lib.sayuri_hip_sync.argtypes = [ctypes.c_void_p]
+        lib.sayuri_hip_download.argtypes = [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p]
+        lib.sayuri_hip_forward.argtypes = [ctypes.c_void_p, ctypes.c_int, c_float_p, c_int_p, c_float_p,
+                                           c_float_p, c_float_p, c_float_p]
+        lib.sayuri_hip_time_runs.argtypes = [ctypes.c_void_p, ctypes.c_int, c_float_p]
+        lib.sayuri_hip_profile_run.argtypes = [ctypes.c_void_p, ctypes.POINTER(KernelStat), ctypes.c_int]
+        lib.sayuri_hip_device_bytes.restype = ctypes.c_size_t
+        lib.sayuri_hip_device_bytes.argtypes = [ctypes.c_void_p]
+        lib.sayuri_hip_test_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
+        _hip = lib
+    return _hip
+
+
+def host() -> ctypes.CDLL:
+    global _host
+    if _host is None:
+        hip()
+        lib = ctypes.CDLL(_require(_build.HOST_SO))
+        lib.sayuri_host_last_error.restype = ctypes.c_char_p
+        lib.sayuri_weights_load.restype = ctypes.c_void_p
+        lib.sayuri_weights_load.argtypes = [ctypes.c_char_p]
+        lib.sayuri_weights_free.argtypes = [ctypes.c_void_p]
+        lib.sayuri_weights_info.argtypes = [ctypes.c_void_p, c_int_p]
+        lib.sayuri_weights_block_info.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p]
+        lib.sayuri_weights_tensor.restype = ctypes.c_long
+        lib.sayuri_weights_tensor.argtypes = [ctypes.c_void_p, ctypes.c_char_p, c_float_p, ctypes.c_long]
+        lib.sayuri_pipe_create.restype = ctypes.c_void_p
+        lib.sayuri_pipe_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int]
+        lib.sayuri_pipe_destroy.argtypes = [ctypes.c_void_p]
+        lib.sayuri_pipe_num_workers.argtypes = [ctypes.c_void_p]
+        lib.sayuri_pipe_ctx.restype = ctypes.c_void_p
+        lib.sayuri_pipe_ctx.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.sayuri_pipe_reconstruct.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        lib.sayuri_pipe_eval.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
+                                         c_int_p, c_float_p, c_int_p, c_float_p]
+        _host = lib
+    return _host

@@ -1,0 +1,946 @@
+// engine.hip -- the per-GPU forward graph behind include/sayuri_hip.h.
+//
+// Structural counterpart of the reference's CudaForwardPipe::NNGraph
+// (src/neural/cuda/cuda_forward_pipe.cc:133-1090) and its layer objects
+// (src/neural/cuda/cuda_layers.cc), re-designed for MI355X:
+//   * activations live in compact NHWC (see common.h), fp16 or fp32;
+//   * every convolution is ONE implicit-GEMM MFMA kernel with the bias/residual/activation
+//     epilogue fused (conv_mfma.h) instead of transform/GEMM/transform + add_spatial;
+//   * an SE unit is two launches (gate, scale), the whole head tail is one launch;
+//   * samples of different board sizes share a batch without any masked work.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/sayuri_hip.h"
+#include "common.h"
+#include "conv_mfma.h"
+#include "small_ops.h"
+
+namespace sayuri {
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+
+#define HIP_OK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return -1;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+constexpr size_t kMaxLds = 160 * 1024;
+constexpr int kNumCU = 256;
+
+// ------------------------------------------------------------------ conv kernel registry
+template <typename T> struct ConvKernelTable {
+    typedef void (*Fn)(const ConvParams);
+    struct Entry { int wmt, wnt; Fn fn; size_t (*lds)(int); int npos_cap; };
+    static std::vector<Entry>& entries() {
+        static std::vector<Entry> e;
+        return e;
+    }
+};
+
+template <typename T, int WMT, int WNT> static void register_conv() {
+    typedef ConvCfg<T, WMT, WNT> Cfg;
+    auto fn = &conv_mfma_kernel<T, WMT, WNT>;
+    ConvKernelTable<T>::entries().push_back({WMT, WNT, fn, &Cfg::lds_bytes, Cfg::NPOS_CAP});
+}
+
+template <typename T> static void register_all_convs();
+template <> void register_all_convs<f16>() {
+    if (!ConvKernelTable<f16>::entries().empty()) return;
+    register_conv<f16, 1, 4>(); register_conv<f16, 2, 4>(); register_conv<f16, 3, 4>();
+    register_conv<f16, 4, 4>(); register_conv<f16, 6, 4>(); register_conv<f16, 8, 4>();
+    register_conv<f16, 1, 2>(); register_conv<f16, 2, 2>(); register_conv<f16, 3, 2>();
+    register_conv<f16, 4, 2>(); register_conv<f16, 6, 2>(); register_conv<f16, 8, 2>();
+    register_conv<f16, 6, 3>(); register_conv<f16, 8, 3>();
+}
+template <> void register_all_convs<float>() {
+    if (!ConvKernelTable<float>::entries().empty()) return;
+    register_conv<float, 1, 4>(); register_conv<float, 2, 4>(); register_conv<float, 3, 4>();
+    register_conv<float, 4, 4>();
+    register_conv<float, 1, 2>(); register_conv<float, 2, 2>(); register_conv<float, 3, 2>();
+    register_conv<float, 4, 2>();
+}
+
+// allow > 64 KiB of dynamic LDS on the current device
+template <typename T> static void enable_big_lds() {
+    register_all_convs<T>();
+    for (const auto& e : ConvKernelTable<T>::entries())
+        (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+}
+
+// candidate output-channel tiles, largest first
+static int pick_wmt(int cout_s, bool fp16) {
+    // KO_T = 32*WMT.  Smallest tile that covers cout_s, else the tile with least padding.
+    const int opts16[] = {1, 2, 3, 4, 6, 8};
+    const int opts32[] = {1, 2, 3, 4};
+    const int* opts = fp16 ? opts16 : opts32;
+    const int nopts = fp16 ? 6 : 4;
+    for (int i = 0; i < nopts; ++i)
+        if (opts[i] * 32 >= cout_s) return opts[i];
+    int best = opts[nopts - 1], best_pad = 1 << 30;
+    for (int i = nopts - 1; i >= 0; --i) {
+        const int kot = opts[i] * 32, pad = round_up(cout_s, kot) - cout_s;
+        if (pad < best_pad) { best_pad = pad; best = opts[i]; }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------ host-side geometry
+struct HostGeom {
+    std::vector<int> bsz, off;  // off has n+1 entries
+    int n = 0, total = 0;
+    // worst-case LDS halo positions / subregions of any PT-pixel tile
+    void tile_bounds(int PT, int* npos_out, int* nsub_out) const {
+        int max_pos = 0, max_sub = 0;
+        int s = 0;
+        for (int g0 = 0; g0 < total; g0 += PT) {
+            const int g1 = std::min(g0 + PT, total);
+            while (s + 1 < n && off[s + 1] <= g0) ++s;
+            int pos = 0, sub = 0;
+            for (int m = s; m < n && off[m] < g1; ++m) {
+                const int bs = bsz[m];
+                const int a = std::max(g0, off[m]) - off[m], b = std::min(g1, off[m + 1]) - off[m];
+                const int rows = (b - 1) / bs - a / bs + 3;
+                pos += rows * (bs + 2);
+                ++sub;
+            }
+            max_pos = std::max(max_pos, pos);
+            max_sub = std::max(max_sub, sub);
+        }
+        *npos_out = round_up(std::max(max_pos, 16), 16);
+        *nsub_out = max_sub;
+    }
+};
+
+struct Stat {
+    int launches = 0;
+    float ms = 0.f;
+    double flops = 0, bytes = 0;
+};
+
+// ------------------------------------------------------------------ layers
+struct ConvLayerDev {
+    int cin = 0, cout = 0, k = 0;
+    bool depthwise = false, with_bn_fold = false;
+    std::vector<float> hw, hb;  // host tensors as handed over the ABI
+    int cin_s = 0, cout_s = 0, wmt = 0, ko_pad = 0;
+    void* w = nullptr;      // MFMA image, or [k*k][cs] fp32 for depthwise
+    float* bias = nullptr;  // [ko_pad] / [cs]
+    float* w32 = nullptr;   // plain fp32 copy [cout][cin] for the tiny head convs
+};
+struct FcLayerDev {
+    int in = 0, out = 0;
+    std::vector<float> hw, hb;
+    float* wt = nullptr;  // [in][out]
+    float* b = nullptr;
+    FcDev dev() const { return FcDev{wt, b, in, out}; }
+};
+
+class EngineBase {
+public:
+    virtual ~EngineBase() {}
+    virtual int load_tensor(int layer, int kind, const float* host, size_t n) = 0;
+    virtual int upload(int n, const float* planes, const int* board_sizes) = 0;
+    virtual int run() = 0;
+    virtual int sync() = 0;
+    virtual int download(float* prob, float* pass, float* misc, float* own) = 0;
+    virtual int time_runs(int iters, float* ms) = 0;
+    virtual int profile_run(sayuri_hip_kernel_stat* rows, int cap) = 0;
+    virtual size_t device_bytes() const = 0;
+};
+
+template <typename T> class Engine : public EngineBase {
+public:
+    Engine(int device, const sayuri_hip_netdesc& d, int max_batch, int board)
+        : device_(device), desc_(d), max_batch_(max_batch), board_(board) {
+        blocks_.assign(d.blocks, d.blocks + d.residual_blocks);
+        desc_.blocks = blocks_.data();
+    }
+    ~Engine() override { release(); }
+
+    int init() {
+        HIP_OK(hipSetDevice(device_));
+        HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        HIP_OK(hipEventCreate(&ev0_));
+        HIP_OK(hipEventCreate(&ev1_));
+        enable_big_lds<T>();
+        return describe_layers();
+    }
+
+    // -------------------------------------------------------------- weights
+    int load_tensor(int layer, int kind, const float* host, size_t n) override {
+        if (finalized_) return fail("load_tensor after the first forward");
+        auto ci = convs_.find(layer);
+        if (ci != convs_.end()) {
+            ConvLayerDev& L = ci->second;
+            const size_t expect = kind == SAYURI_T_WEIGHTS
+                                      ? (size_t)(L.depthwise ? 1 : L.cin) * L.cout * L.k * L.k
+                                      : (size_t)L.cout;
+            if (n != expect) return fail("conv tensor size mismatch for layer " + std::to_string(layer));
+            (kind == SAYURI_T_WEIGHTS ? L.hw : L.hb).assign(host, host + n);
+            return 0;
+        }
+        auto fi = fcs_.find(layer);
+        if (fi != fcs_.end()) {
+            FcLayerDev& L = fi->second;
+            const size_t expect = kind == SAYURI_T_WEIGHTS ? (size_t)L.in * L.out : (size_t)L.out;
+            if (n != expect) return fail("fc tensor size mismatch for layer " + std::to_string(layer));
+            (kind == SAYURI_T_WEIGHTS ? L.hw : L.hb).assign(host, host + n);
+            return 0;
+        }
+        return fail("unknown layer id " + std::to_string(layer));
+    }
+
+    // -------------------------------------------------------------- batch i/o
+    int upload(int n, const float* planes, const int* board_sizes) override {
+        HIP_OK(hipSetDevice(device_));
+        if (n <= 0 || n > max_batch_) return fail("batch size out of range");
+        if (finalize()) return -1;
+        geom_.n = n;
+        geom_.bsz.resize(n);
+        geom_.off.resize(n + 1);
+        geom_.off[0] = 0;
+        for (int i = 0; i < n; ++i) {
+            const int bs = board_sizes ? board_sizes[i] : board_;
+            if (bs < 2 || bs > board_) return fail("sample board size out of range");
+            geom_.bsz[i] = bs;
+            geom_.off[i + 1] = geom_.off[i] + bs * bs;
+        }
+        geom_.total = geom_.off[n];
+        tile_cache_.clear();
+        HIP_OK(hipMemcpyAsync(d_off_, geom_.off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, stream_));
+        HIP_OK(hipMemcpyAsync(d_bsz_, geom_.bsz.data(), sizeof(int) * n, hipMemcpyHostToDevice, stream_));
+        HIP_OK(hipMemcpyAsync(d_planes_, planes, sizeof(float) * (size_t)n * desc_.input_channels * board_ * board_,
+                              hipMemcpyHostToDevice, stream_));
+        HIP_OK(hipStreamSynchronize(stream_));
+        have_batch_ = true;
+        return 0;
+    }
+
+    int run() override {
+        if (!have_batch_) return fail("run before upload");
+        HIP_OK(hipSetDevice(device_));
+        return forward();
+    }
+
+    int sync() override {
+        HIP_OK(hipSetDevice(device_));
+        HIP_OK(hipStreamSynchronize(stream_));
+        return 0;
+    }
+
+    int download(float* prob, float* pass, float* misc, float* own) override {
+        HIP_OK(hipSetDevice(device_));
+        const size_t n = geom_.n, B2 = (size_t)board_ * board_;
+        if (prob) HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, stream_));
+        if (pass) HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, stream_));
+        if (misc) HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, stream_));
+        if (own) HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipStreamSynchronize(stream_));
+        return 0;
+    }
+
+    int time_runs(int iters, float* ms) override {
+        if (!have_batch_) return fail("time_runs before upload");
+        HIP_OK(hipSetDevice(device_));
+        HIP_OK(hipEventRecord(ev0_, stream_));
+        for (int i = 0; i < iters; ++i)
+            if (forward()) return -1;
+        HIP_OK(hipEventRecord(ev1_, stream_));
+        HIP_OK(hipEventSynchronize(ev1_));
+        HIP_OK(hipEventElapsedTime(ms, ev0_, ev1_));
+        return 0;
+    }
+
+    int profile_run(sayuri_hip_kernel_stat* rows, int cap) override {
+        if (!have_batch_) return fail("profile_run before upload");
+        HIP_OK(hipSetDevice(device_));
+        stats_.clear();
+        profiling_ = true;
+        const int rc = forward();
+        profiling_ = false;
+        if (rc) return -1;
+        int i = 0;
+        for (auto& kv : stats_) {
+            if (i >= cap) break;
+            std::memset(&rows[i], 0, sizeof(rows[i]));
+            std::snprintf(rows[i].name, sizeof(rows[i].name), "%s", kv.first.c_str());
+            rows[i].launches = kv.second.launches;
+            rows[i].total_ms = kv.second.ms;
+            rows[i].flops = kv.second.flops;
+            rows[i].bytes = kv.second.bytes;
+            ++i;
+        }
+        return i;
+    }
+
+    size_t device_bytes() const override { return dev_bytes_; }
+
+private:
+    // -------------------------------------------------------------- construction helpers
+    void add_conv(int id, int cin, int cout, int k, bool depthwise = false) {
+        ConvLayerDev L;
+        L.cin = cin; L.cout = cout; L.k = k; L.depthwise = depthwise;
+        convs_[id] = L;
+    }
+    void add_fc(int id, int in, int out) {
+        FcLayerDev L;
+        L.in = in; L.out = out;
+        fcs_[id] = L;
+    }
+
+    int describe_layers() {
+        const auto& d = desc_;
+        const int C = d.residual_channels;
+        if (C <= 0 || d.input_channels <= 0) return fail("bad net description");
+        add_conv(SAYURI_L_INPUT_CONV, d.input_channels, C, 3);
+        cs_max_ = std::max(round_up(C, 32), round_up(d.input_channels, 32));
+        for (int b = 0; b < d.residual_blocks; ++b) {
+            const auto& bd = blocks_[b];
+            const int I = bd.bottleneck_channels, F = bd.feedforward_channels;
+            switch (bd.type) {
+            case SAYURI_BLOCK_RESIDUAL:
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1), C, C, 3);
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2), C, C, 3);
+                break;
+            case SAYURI_BLOCK_BOTTLENECK:
+            case SAYURI_BLOCK_NESTED_BOTTLENECK:
+                if (I <= 0) return fail("bottleneck block without bottleneck_channels");
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_PRE_BTL), C, I, 1);
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1), I, I, 3);
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2), I, I, 3);
+                if (bd.type == SAYURI_BLOCK_NESTED_BOTTLENECK) {
+                    add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV3), I, I, 3);
+                    add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV4), I, I, 3);
+                }
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_POST_BTL), I, C, 1);
+                cs_max_ = std::max(cs_max_, round_up(I, 32));
+                break;
+            case SAYURI_BLOCK_MIXER:
+                if (F <= 0 || bd.dw_filter <= 0) return fail("mixer block without ffn channels / dw filter");
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_DW_CONV), C, C, bd.dw_filter, true);
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1), C, F, 1);
+                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2), F, C, 1);
+                cs_max_ = std::max(cs_max_, round_up(F, 32));
+                break;
+            default:
+                return fail("unknown block type");
+            }
+            if (bd.apply_se) {
+                if (bd.se_size <= 0) return fail("SE block without se_size");
+                add_fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE), 3 * C, bd.se_size);
+                add_fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE), bd.se_size, 2 * C);
+            }
+        }
+        const int Cp = d.policy_head_channels, Cv = d.value_head_channels;
+        if (Cp <= 0 || Cv <= 0) return fail("bad head channels");
+        if (d.ownership_channels != 1) return fail("ownership_channels must be 1");
+        if (d.probabilities_channels > 8) return fail("too many policy planes");
+        add_conv(SAYURI_L_P_HD_CONV, C, Cp, 1);
+        if (d.policy_head_type == 1) {
+            if (d.policy_dw_filter <= 0) return fail("RepLK head without dw filter");
+            add_conv(SAYURI_L_P_DW_CONV, Cp, Cp, d.policy_dw_filter, true);
+            add_conv(SAYURI_L_P_PT_CONV, Cp, Cp, 1);
+        }
+        add_fc(SAYURI_L_P_INTER_FC, 3 * Cp, Cp);
+        add_conv(SAYURI_L_PROB_CONV, Cp, d.probabilities_channels, 1);
+        add_fc(SAYURI_L_PASS_FC, Cp, d.pass_probability_outputs);
+        add_conv(SAYURI_L_V_HD_CONV, C, Cv, 1);
+        add_fc(SAYURI_L_V_INTER_FC, 3 * Cv, 3 * Cv);
+        add_conv(SAYURI_L_V_OWNERSHIP, Cv, 1, 1);
+        add_fc(SAYURI_L_V_MISC, 3 * Cv, d.value_misc_outputs);
+        cs_max_ = std::max(cs_max_, std::max(round_up(Cp, 32), round_up(Cv, 32)));
+        return 0;
+    }
+
+    template <typename U> int dev_alloc(U** p, size_t count) {
+        void* q = nullptr;
+        const size_t bytes = std::max<size_t>(count * sizeof(U), 256);
+        HIP_OK(hipMalloc(&q, bytes));
+        HIP_OK(hipMemset(q, 0, bytes));
+        allocs_.push_back(q);
+        dev_bytes_ += bytes;
+        *p = (U*)q;
+        return 0;
+    }
+    template <typename U> int dev_upload(U** p, const std::vector<U>& h) {
+        if (dev_alloc(p, h.size())) return -1;
+        HIP_OK(hipMemcpy(*p, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice));
+        return 0;
+    }
+
+    static bool is_tiny_head_conv(int id) { return id == SAYURI_L_PROB_CONV || id == SAYURI_L_V_OWNERSHIP; }
+
+    int finalize() {
+        if (finalized_) return 0;
+        for (auto& kv : convs_) {
+            ConvLayerDev& L = kv.second;
+            if (L.hw.empty() || L.hb.empty()) return fail("missing tensors for conv layer " + std::to_string(kv.first));
+            L.cin_s = round_up(L.cin, 32);
+            L.cout_s = round_up(L.cout, 32);
+            if (is_tiny_head_conv(kv.first)) {  // consumed by head_tail_kernel in fp32
+                if (dev_upload(&L.w32, L.hw) || dev_upload(&L.bias, L.hb)) return -1;
+            } else if (L.depthwise) {
+                const int kk = L.k * L.k;
+                std::vector<float> wt((size_t)kk * L.cout_s, 0.f), b(L.cout_s, 0.f);
+                for (int c = 0; c < L.cout; ++c) {
+                    for (int t = 0; t < kk; ++t) wt[(size_t)t * L.cout_s + c] = L.hw[(size_t)c * kk + t];
+                    b[c] = L.hb[c];
+                }
+                float* w = nullptr;
+                if (dev_upload(&w, wt) || dev_upload(&L.bias, b)) return -1;
+                L.w = w;
+            } else {
+                L.wmt = pick_wmt(L.cout_s, sizeof(T) == 2);
+                const int kot = L.wmt * 32;
+                L.ko_pad = round_up(L.cout_s, kot);
+                const int taps = L.k * L.k, nch = L.cin_s / 32;
+                std::vector<T> img((size_t)taps * nch * 4 * L.ko_pad * 8, from_float_host(0.f));
+                for (int t = 0; t < taps; ++t)
+                    for (int ch = 0; ch < nch; ++ch)
+                        for (int kg = 0; kg < 4; ++kg)
+                            for (int ko = 0; ko < L.cout; ++ko)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int c = ch * 32 + kg * 8 + e;
+                                    if (c >= L.cin) continue;
+                                    const float v = L.hw[((size_t)ko * L.cin + c) * taps + t];
+                                    img[((((size_t)t * nch + ch) * 4 + kg) * L.ko_pad + ko) * 8 + e] = from_float_host(v);
+                                }
+                std::vector<float> b(L.ko_pad, 0.f);
+                std::copy(L.hb.begin(), L.hb.end(), b.begin());
+                T* w = nullptr;
+                if (dev_upload(&w, img) || dev_upload(&L.bias, b)) return -1;
+                L.w = w;
+            }
+            std::vector<float>().swap(L.hw);
+            std::vector<float>().swap(L.hb);
+        }
+        for (auto& kv : fcs_) {
+            FcLayerDev& L = kv.second;
+            if (L.hw.empty() || L.hb.empty()) return fail("missing tensors for fc layer " + std::to_string(kv.first));
+            std::vector<float> wt((size_t)L.in * L.out);
+            for (int o = 0; o < L.out; ++o)
+                for (int i = 0; i < L.in; ++i) wt[(size_t)i * L.out + o] = L.hw[(size_t)o * L.in + i];
+            if (dev_upload(&L.wt, wt) || dev_upload(&L.b, L.hb)) return -1;
+            std::vector<float>().swap(L.hw);
+            std::vector<float>().swap(L.hb);
+        }
+        // workspaces
+        slot_pix_ = board_ * board_;
+        const size_t act_elems = (size_t)max_batch_ * slot_pix_ * cs_max_;
+        for (int i = 0; i < kNumBufs; ++i)
+            if (dev_alloc(&bufs_[i], act_elems)) return -1;
+        const size_t B2 = (size_t)board_ * board_;
+        if (dev_alloc(&d_planes_, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
+        if (dev_alloc(&d_off_, max_batch_ + 1) || dev_alloc(&d_bsz_, max_batch_)) return -1;
+        if (dev_alloc(&d_gate_, (size_t)max_batch_ * 2 * desc_.residual_channels)) return -1;
+        if (dev_alloc(&d_prob_, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
+        if (dev_alloc(&d_pass_, (size_t)max_batch_ * desc_.pass_probability_outputs)) return -1;
+        if (dev_alloc(&d_misc_, (size_t)max_batch_ * desc_.value_misc_outputs)) return -1;
+        if (dev_alloc(&d_own_, (size_t)max_batch_ * B2)) return -1;
+        finalized_ = true;
+        return 0;
+    }
+
+    static T from_float_host(float v) { return (T)v; }
+
+    void release() {
+        (void)hipSetDevice(device_);
+        for (void* p : allocs_) (void)hipFree(p);
+        allocs_.clear();
+        if (ev0_) (void)hipEventDestroy(ev0_);
+        if (ev1_) (void)hipEventDestroy(ev1_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+        ev0_ = ev1_ = nullptr;
+        stream_ = nullptr;
+    }
+
+    // -------------------------------------------------------------- launch plumbing
+    BatchGeom dgeom() const { return BatchGeom{d_off_, d_bsz_, geom_.n, geom_.total, slot_pix_}; }
+
+    template <typename F> int timed(const char* name, double flops, double bytes, F&& launch) {
+        if (!profiling_) {
+            launch();
+            HIP_OK(hipGetLastError());
+            return 0;
+        }
+        HIP_OK(hipEventRecord(ev0_, stream_));
+        launch();
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(ev1_, stream_));
+        HIP_OK(hipEventSynchronize(ev1_));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, ev0_, ev1_));
+        Stat& s = stats_[name];
+        s.launches += 1;
+        s.ms += ms;
+        s.flops += flops;
+        s.bytes += bytes;
+        return 0;
+    }
+
+    struct TileChoice { int wnt, npos, ntiles; const typename ConvKernelTable<T>::Entry* e; };
+
+    int choose_tile(int wmt, int kot_tiles, TileChoice* out) {
+        auto it = tile_cache_.find(wmt * 1024 + kot_tiles);
+        if (it != tile_cache_.end()) { *out = it->second; return 0; }
+        double best_cost = 1e30;
+        TileChoice best{};
+        bool found = false;
+        for (const auto& e : ConvKernelTable<T>::entries()) {
+            if (e.wmt != wmt) continue;
+            const int PT = 64 * e.wnt;
+            int npos, nsub;
+            geom_.tile_bounds(PT, &npos, &nsub);
+            if (npos > e.npos_cap || nsub > kMaxSub || e.lds(npos) > kMaxLds) continue;
+            const int ntiles = (geom_.total + PT - 1) / PT;
+            const double waves = std::ceil((double)ntiles * kot_tiles / kNumCU);
+            const double cost = waves * (PT + 24);
+            if (cost < best_cost) { best_cost = cost; best = TileChoice{e.wnt, npos, ntiles, &e}; found = true; }
+        }
+        if (!found) return fail("no conv tile configuration fits this batch geometry");
+        tile_cache_[wmt * 1024 + kot_tiles] = best;
+        *out = best;
+        return 0;
+    }
+
+    int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
+        const int kot = L.wmt * 32, kot_tiles = L.ko_pad / kot;
+        TileChoice tc;
+        if (choose_tile(L.wmt, kot_tiles, &tc)) return -1;
+        ConvParams p;
+        p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
+        p.g = dgeom();
+        p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
+        p.taps = L.k * L.k; p.act = act; p.npos = tc.npos; p.num_pix_tiles = tc.ntiles;
+        const double px = geom_.total;
+        const double flops = 2.0 * px * L.cin * L.cout * p.taps;
+        const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * p.taps);
+        const auto fn = tc.e->fn;
+        const size_t lds = tc.e->lds(tc.npos);
+        const int grid = tc.ntiles * kot_tiles;
+        return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, p); });
+    }
+
+    int depthwise(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
+        const int EPP = ElemTraits<T>::kPieceElems;
+        const size_t total = (size_t)geom_.total * (L.cout_s / EPP);
+        const int grid = (int)((total + 255) / 256);
+        const double px = geom_.total;
+        const BatchGeom g = dgeom();
+        return timed(name, 2.0 * px * L.cout * L.k * L.k, sizeof(T) * px * L.cout * (res ? 3 : 2), [&] {
+            hipLaunchKernelGGL(depthwise_kernel<T>, dim3(grid), dim3(256), 0, stream_, in, res, out,
+                               (const float*)L.w, (const float*)L.bias, g, L.cout, L.cout_s, L.k, act);
+        });
+    }
+
+    int se_unit(const FcLayerDev& sq, const FcLayerDev& ex, T* x, const T* res, int C, int cs, int act) {
+        const BatchGeom g = dgeom();
+        const size_t smem = sizeof(float) * (3 * C + sq.out + 512);
+        const double px = geom_.total;
+        if (timed("se_gate", 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out), sizeof(T) * px * C, [&] {
+                hipLaunchKernelGGL(se_gate_kernel<T>, dim3(geom_.n), dim3(256), smem, stream_, (const T*)x, d_gate_, g, C,
+                                   cs, sq.dev(), ex.dev(), act);
+            }))
+            return -1;
+        const int EPP = ElemTraits<T>::kPieceElems;
+        const size_t total = (size_t)geom_.total * (cs / EPP);
+        const int grid = (int)((total + 255) / 256);
+        return timed("se_scale", 3.0 * px * C, sizeof(T) * px * C * 3, [&] {
+            hipLaunchKernelGGL(se_scale_kernel<T>, dim3(grid), dim3(256), 0, stream_, (const T*)x, res, x,
+                               (const float*)d_gate_, g, C, cs, act);
+        });
+    }
+
+    // small pool of activation buffers
+    static constexpr int kNumBufs = 6;
+    int take() {
+        for (int i = 0; i < kNumBufs; ++i)
+            if (!busy_[i]) { busy_[i] = true; return i; }
+        return -1;
+    }
+    void give(int i) { busy_[i] = false; }
+
+    const ConvLayerDev& cv(int id) const { return convs_.at(id); }
+    const FcLayerDev& fc(int id) const { return fcs_.at(id); }
+
+    // -------------------------------------------------------------- the graph
+    int forward() {
+        const auto& d = desc_;
+        const int C = d.residual_channels, csC = round_up(C, 32), act = d.default_act;
+        const BatchGeom g = dgeom();
+        for (int i = 0; i < kNumBufs; ++i) busy_[i] = false;
+
+        int x = take();
+        {
+            const ConvLayerDev& L = cv(SAYURI_L_INPUT_CONV);
+            const int in = take();
+            const int grid = (geom_.total + 255) / 256;
+            const double px = geom_.total;
+            T* dst = bufs_[in];
+            const int cin = d.input_channels, cs = L.cin_s, board = board_;
+            if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
+                    hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(256), 0, stream_,
+                                       (const float*)d_planes_, dst, g, cin, cs, board);
+                }))
+                return -1;
+            if (conv("conv3x3_input", L, bufs_[in], bufs_[x], nullptr, act)) return -1;
+            give(in);
+        }
+
+        for (int b = 0; b < d.residual_blocks; ++b) {
+            const auto& bd = blocks_[b];
+            const bool se = bd.apply_se != 0;
+            const int last_act = se ? (int)kIdentity : act;
+            const int y = take();
+            int skip = x;  // buffer added back at the end of the block
+            if (bd.type == SAYURI_BLOCK_RESIDUAL) {
+                const int t0 = take();
+                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[x], bufs_[t0], nullptr, act)) return -1;
+                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t0], bufs_[y], se ? nullptr : bufs_[x], last_act)) return -1;
+                give(t0);
+            } else if (bd.type == SAYURI_BLOCK_BOTTLENECK) {
+                const int t0 = take(), t1 = take();
+                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_PRE_BTL)), bufs_[x], bufs_[t0], nullptr, act)) return -1;
+                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[t0], bufs_[t1], nullptr, act)) return -1;
+                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t1], bufs_[t0], nullptr, act)) return -1;
+                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_POST_BTL)), bufs_[t0], bufs_[y], se ? nullptr : bufs_[x], last_act)) return -1;
+                give(t0); give(t1);
+            } else if (bd.type == SAYURI_BLOCK_NESTED_BOTTLENECK) {
+                const int r1 = take(), t0 = take(), t1 = take();
+                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_PRE_BTL)), bufs_[x], bufs_[r1], nullptr, act)) return -1;
+                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[r1], bufs_[t0], nullptr, act)) return -1;
+                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t0], bufs_[t1], bufs_[r1], act)) return -1;
+                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV3)), bufs_[t1], bufs_[t0], nullptr, act)) return -1;
+                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV4)), bufs_[t0], bufs_[r1], bufs_[t1], act)) return -1;
+                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_POST_BTL)), bufs_[r1], bufs_[y], se ? nullptr : bufs_[x], last_act)) return -1;
+                give(r1); give(t0); give(t1);
+            } else {  // mixer: x' = act(dw(x)+b) + x is the new skip
+                const int s2 = take(), t1 = take();
+                if (depthwise("depthwise", cv(SAYURI_L_BLOCK(b, SAYURI_S_DW_CONV)), bufs_[x], bufs_[s2], bufs_[x], act)) return -1;
+                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[s2], bufs_[t1], nullptr, act)) return -1;
+                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t1], bufs_[y], se ? nullptr : bufs_[s2], last_act)) return -1;
+                give(t1);
+                give(x);
+                x = s2;
+                skip = s2;
+            }
+            if (se) {
+                if (se_unit(fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)), fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[y],
+                            bufs_[skip], C, csC, act))
+                    return -1;
+            }
+            give(x);
+            x = y;
+        }
+
+        // heads
+        const int Cp = d.policy_head_channels, Cv = d.value_head_channels;
+        int pb = take();
+        const int vb = take();
+        if (conv("conv1x1_head", cv(SAYURI_L_P_HD_CONV), bufs_[x], bufs_[pb], nullptr, act)) return -1;
+        if (d.policy_head_type == 1) {
+            const int p2 = take();
+            if (depthwise("depthwise", cv(SAYURI_L_P_DW_CONV), bufs_[pb], bufs_[p2], nullptr, act)) return -1;
+            if (conv("conv1x1_head", cv(SAYURI_L_P_PT_CONV), bufs_[p2], bufs_[pb], nullptr, act)) return -1;
+            give(p2);
+        }
+        if (conv("conv1x1_head", cv(SAYURI_L_V_HD_CONV), bufs_[x], bufs_[vb], nullptr, act)) return -1;
+        HeadParams h;
+        h.p_inter = fc(SAYURI_L_P_INTER_FC).dev();
+        h.pass_fc = fc(SAYURI_L_PASS_FC).dev();
+        h.v_inter = fc(SAYURI_L_V_INTER_FC).dev();
+        h.v_misc = fc(SAYURI_L_V_MISC).dev();
+        h.prob_w = cv(SAYURI_L_PROB_CONV).w32;
+        h.prob_b = cv(SAYURI_L_PROB_CONV).bias;
+        h.own_w = cv(SAYURI_L_V_OWNERSHIP).w32;
+        h.own_b = cv(SAYURI_L_V_OWNERSHIP).bias;
+        h.Cp = Cp; h.cs_p = round_up(Cp, 32); h.Cv = Cv; h.cs_v = round_up(Cv, 32);
+        h.prob_ch = d.probabilities_channels; h.act = act; h.board = board_;
+        h.prob = d_prob_; h.pass = d_pass_; h.misc = d_misc_; h.own = d_own_;
+        const int maxc = std::max(Cp, Cv);
+        const size_t smem = sizeof(float) * (7 * maxc + 512);
+        const T* pc = bufs_[pb];
+        const T* vc = bufs_[vb];
+        return timed("head_tail", 0, 0, [&] {
+            hipLaunchKernelGGL(head_tail_kernel<T>, dim3(geom_.n), dim3(256), smem, stream_, pc, vc, g, h);
+        });
+    }
+
+    int device_;
+    sayuri_hip_netdesc desc_;
+    std::vector<sayuri_hip_blockdesc> blocks_;
+    int max_batch_, board_;
+    int cs_max_ = 32, slot_pix_ = 0;
+    std::map<int, ConvLayerDev> convs_;
+    std::map<int, FcLayerDev> fcs_;
+    bool finalized_ = false, have_batch_ = false, profiling_ = false;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    std::vector<void*> allocs_;
+    size_t dev_bytes_ = 0;
+    T* bufs_[kNumBufs] = {};
+    bool busy_[kNumBufs] = {};
+    float *d_planes_ = nullptr, *d_gate_ = nullptr, *d_prob_ = nullptr, *d_pass_ = nullptr, *d_misc_ = nullptr,
+          *d_own_ = nullptr;
+    int *d_off_ = nullptr, *d_bsz_ = nullptr;
+    HostGeom geom_;
+    std::map<int, TileChoice> tile_cache_;
+    std::map<std::string, Stat> stats_;
+
+};
+
+}  // namespace sayuri
+
+// ====================================================================== C ABI
+using namespace sayuri;
+
+struct sayuri_hip_ctx {
+    std::unique_ptr<EngineBase> eng;
+};
+
+extern "C" {
+
+const char* sayuri_hip_last_error(void) { return g_err.c_str(); }
+
+int sayuri_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+sayuri_hip_ctx* sayuri_hip_create(int device, const sayuri_hip_netdesc* desc, int max_batch, int board, int use_fp16) {
+    if (!desc || !desc->blocks || max_batch <= 0 || board < 2 || board > 25) {
+        fail("sayuri_hip_create: bad arguments");
+        return nullptr;
+    }
+    int ndev = sayuri_hip_device_count();
+    if (device < 0 || device >= ndev) {
+        fail("sayuri_hip_create: no such HIP device (found " + std::to_string(ndev) + ")");
+        return nullptr;
+    }
+    auto ctx = std::make_unique<sayuri_hip_ctx>();
+    int rc;
+    if (use_fp16) {
+        auto e = std::make_unique<Engine<f16>>(device, *desc, max_batch, board);
+        rc = e->init();
+        ctx->eng = std::move(e);
+    } else {
+        auto e = std::make_unique<Engine<float>>(device, *desc, max_batch, board);
+        rc = e->init();
+        ctx->eng = std::move(e);
+    }
+    if (rc) return nullptr;
+    return ctx.release();
+}
+
+int sayuri_hip_load_tensor(sayuri_hip_ctx* ctx, int layer_id, int kind, const float* host, size_t n) {
+    if (!ctx || !host) return fail("load_tensor: null argument");
+    return ctx->eng->load_tensor(layer_id, kind, host, n);
+}
+
+int sayuri_hip_upload(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes) {
+    if (!ctx || !planes) return fail("upload: null argument");
+    return ctx->eng->upload(n, planes, board_sizes);
+}
+int sayuri_hip_run(sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->run() : fail("run: null ctx"); }
+int sayuri_hip_sync(sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->sync() : fail("sync: null ctx"); }
+int sayuri_hip_download(sayuri_hip_ctx* ctx, float* prob, float* pass, float* misc, float* own) {
+    return ctx ? ctx->eng->download(prob, pass, misc, own) : fail("download: null ctx");
+}
+
+int sayuri_hip_forward(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes, float* prob,
+                       float* pass, float* misc, float* own) {
+    if (!ctx) return fail("forward: null ctx");
+    if (ctx->eng->upload(n, planes, board_sizes)) return -1;
+    if (ctx->eng->run()) return -1;
+    return ctx->eng->download(prob, pass, misc, own);
+}
+
+int sayuri_hip_time_runs(sayuri_hip_ctx* ctx, int iters, float* total_ms) {
+    if (!ctx || !total_ms || iters <= 0) return fail("time_runs: bad argument");
+    return ctx->eng->time_runs(iters, total_ms);
+}
+
+int sayuri_hip_profile_run(sayuri_hip_ctx* ctx, sayuri_hip_kernel_stat* rows, int cap) {
+    if (!ctx || !rows) return fail("profile_run: bad argument");
+    return ctx->eng->profile_run(rows, cap);
+}
+
+void* sayuri_hip_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail("hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+void sayuri_hip_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->device_bytes() : 0; }
+
+void sayuri_hip_destroy(sayuri_hip_ctx* ctx) { delete ctx; }
+
+}
+
+// ---------------------------------------------------------------------- layer-level test tap
+// Drives ONE convolution kernel directly (host-side layout conversion in, out) so the parity
+// tests can localise a defect to a layer kind.
+
+namespace sayuri {
+
+template <typename T>
+static int test_conv_impl(int device, int n, const int* board_sizes, int max_board, int cin, int cout, int k,
+                          int depthwise, int act, int post_residual, const float* x, const float* w, const float* bias,
+                          const float* res, float* y) {
+    HIP_OK(hipSetDevice(device));
+    enable_big_lds<T>();
+    HostGeom hg;
+    hg.n = n;
+    hg.bsz.assign(board_sizes, board_sizes + n);
+    hg.off.resize(n + 1);
+    hg.off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (hg.bsz[i] < 2 || hg.bsz[i] > max_board) return fail("test_conv: bad board size");
+        hg.off[i + 1] = hg.off[i] + hg.bsz[i] * hg.bsz[i];
+    }
+    hg.total = hg.off[n];
+    const int slot = max_board * max_board;
+    const int cin_s = round_up(depthwise ? cout : cin, 32), cout_s = round_up(cout, 32);
+    std::vector<void*> allocs;
+    auto cleanup = [&] { for (void* p : allocs) (void)hipFree(p); };
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, std::max<size_t>(bytes, 256));
+        allocs.push_back(p);
+        return p;
+    };
+    // host NCHW (compact per sample) -> compact NHWC
+    auto to_nhwc = [&](const float* src, int C, int cs) {
+        std::vector<T> h((size_t)n * slot * cs, (T)0.f);
+        size_t so = 0;
+        for (int i = 0; i < n; ++i) {
+            const int S = hg.bsz[i] * hg.bsz[i];
+            for (int c = 0; c < C; ++c)
+                for (int p = 0; p < S; ++p) h[((size_t)i * slot + p) * cs + c] = (T)src[so + (size_t)c * S + p];
+            so += (size_t)C * S;
+        }
+        return h;
+    };
+    const int xin_c = depthwise ? cout : cin;
+    std::vector<T> hx = to_nhwc(x, xin_c, cin_s);
+    T* dx = (T*)dalloc(hx.size() * sizeof(T));
+    T* dy = (T*)dalloc((size_t)n * slot * cout_s * sizeof(T));
+    T* dres = nullptr;
+    if (!dx || !dy) { cleanup(); return fail("test_conv: hipMalloc failed"); }
+    HIP_OK(hipMemcpy(dx, hx.data(), hx.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (res) {
+        std::vector<T> hr = to_nhwc(res, cout, cout_s);
+        dres = (T*)dalloc(hr.size() * sizeof(T));
+        if (!dres) { cleanup(); return fail("test_conv: hipMalloc failed"); }
+        HIP_OK(hipMemcpy(dres, hr.data(), hr.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    int* d_off = (int*)dalloc(sizeof(int) * (n + 1));
+    int* d_bsz = (int*)dalloc(sizeof(int) * n);
+    HIP_OK(hipMemcpy(d_off, hg.off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_bsz, hg.bsz.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    const BatchGeom g{d_off, d_bsz, n, hg.total, slot};
+
+    if (depthwise) {
+        const int kk = k * k;
+        std::vector<float> wt((size_t)kk * cout_s, 0.f), b(cout_s, 0.f);
+        for (int c = 0; c < cout; ++c) {
+            for (int t = 0; t < kk; ++t) wt[(size_t)t * cout_s + c] = w[(size_t)c * kk + t];
+            b[c] = bias ? bias[c] : 0.f;
+        }
+        float* dw = (float*)dalloc(wt.size() * 4);
+        float* db = (float*)dalloc(b.size() * 4);
+        HIP_OK(hipMemcpy(dw, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        const int EPP = ElemTraits<T>::kPieceElems;
+        const size_t total = (size_t)hg.total * (cout_s / EPP);
+        hipLaunchKernelGGL(depthwise_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, (const T*)dx,
+                           post_residual ? (const T*)dres : (const T*)nullptr, dy, (const float*)dw, (const float*)db, g,
+                           cout, cout_s, k, act);
+    } else {
+        const int wmt = pick_wmt(cout_s, sizeof(T) == 2);
+        const int kot = wmt * 32, ko_pad = round_up(cout_s, kot), taps = k * k, nch = cin_s / 32;
+        std::vector<T> img((size_t)taps * nch * 4 * ko_pad * 8, (T)0.f);
+        for (int t = 0; t < taps; ++t)
+            for (int ch = 0; ch < nch; ++ch)
+                for (int kg = 0; kg < 4; ++kg)
+                    for (int ko = 0; ko < cout; ++ko)
+                        for (int e = 0; e < 8; ++e) {
+                            const int c = ch * 32 + kg * 8 + e;
+                            if (c >= cin) continue;
+                            img[((((size_t)t * nch + ch) * 4 + kg) * ko_pad + ko) * 8 + e] =
+                                (T)w[((size_t)ko * cin + c) * taps + t];
+                        }
+        std::vector<float> b(ko_pad, 0.f);
+        if (bias) std::copy(bias, bias + cout, b.begin());
+        T* dw = (T*)dalloc(img.size() * sizeof(T));
+        float* db = (float*)dalloc(b.size() * 4);
+        HIP_OK(hipMemcpy(dw, img.data(), img.size() * sizeof(T), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        const typename ConvKernelTable<T>::Entry* best = nullptr;
+        int best_npos = 0;
+        for (const auto& e : ConvKernelTable<T>::entries()) {
+            if (e.wmt != wmt) continue;
+            int npos, nsub;
+            hg.tile_bounds(64 * e.wnt, &npos, &nsub);
+            if (npos > e.npos_cap || nsub > kMaxSub || e.lds(npos) > kMaxLds) continue;
+            if (!best || e.wnt > best->wnt) { best = &e; best_npos = npos; }
+        }
+        if (!best) { cleanup(); return fail("test_conv: no tile configuration fits"); }
+        ConvParams p;
+        p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
+        p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = taps; p.act = act;
+        p.npos = best_npos;
+        const int PT = 64 * best->wnt;
+        p.num_pix_tiles = (hg.total + PT - 1) / PT;
+        hipLaunchKernelGGL(best->fn, dim3(p.num_pix_tiles * (ko_pad / kot)), dim3(512), best->lds(best_npos), 0, p);
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<T> hy((size_t)n * slot * cout_s);
+    HIP_OK(hipMemcpy(hy.data(), dy, hy.size() * sizeof(T), hipMemcpyDeviceToHost));
+    size_t so = 0;
+    for (int i = 0; i < n; ++i) {
+        const int S = hg.bsz[i] * hg.bsz[i];
+        for (int c = 0; c < cout; ++c)
+            for (int pp = 0; pp < S; ++pp) y[so + (size_t)c * S + pp] = (float)hy[((size_t)i * slot + pp) * cout_s + c];
+        so += (size_t)cout * S;
+    }
+    cleanup();
+    return 0;
+}
+
+}  // namespace sayuri
+
+extern "C" int sayuri_hip_test_conv(int device, int use_fp16, int n, const int* board_sizes, int max_board, int cin,
+                                    int cout, int k, int depthwise, int act, int post_residual, const float* x,
+                                    const float* w, const float* bias, const float* res, float* y) {
+    if (!board_sizes || !x || !w || !y || n <= 0) return fail("test_conv: bad argument");
+    if (use_fp16)
+        return test_conv_impl<f16>(device, n, board_sizes, max_board, cin, cout, k, depthwise, act, post_residual, x, w,
+                                   bias, res, y);
+    return test_conv_impl<float>(device, n, board_sizes, max_board, cin, cout, k, depthwise, act, post_residual, x, w,
+                                 bias, res, y);
+}

@@ -1,0 +1,234 @@
+// capi.cc -- flat C wrapper of the host library for ctypes (tests, bench.py, smoke()).
+// Not part of the drop-in boundary (that is include/sayuri_hip.h + HipForwardPipe).
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "hip_forward_pipe.h"
+
+using namespace sayuri_host;
+
+namespace {
+struct PipeHandle {
+    std::shared_ptr<DNNWeights> weights;
+    std::unique_ptr<HipForwardPipe> pipe;
+};
+thread_local std::string g_err;
+
+std::vector<float>* FindTensor(DNNWeights& w, const std::string& name) {
+    const auto dot = name.rfind('.');
+    if (dot == std::string::npos) return nullptr;
+    const std::string kind = name.substr(dot + 1);
+    std::string path = name.substr(0, dot);
+    ConvLayer* conv = nullptr;
+    LinearLayer* fc = nullptr;
+    if (path.rfind("tower.", 0) == 0) {
+        const auto d2 = path.find('.', 6);
+        if (d2 == std::string::npos) return nullptr;
+        const int idx = std::stoi(path.substr(6, d2 - 6));
+        if (idx < 0 || idx >= w.residual_blocks) return nullptr;
+        BlockBasic& b = *w.tower[idx];
+        const std::string l = path.substr(d2 + 1);
+        if (l == "conv1") conv = &b.conv1;
+        else if (l == "conv2") conv = &b.conv2;
+        else if (l == "conv3") conv = &b.conv3;
+        else if (l == "conv4") conv = &b.conv4;
+        else if (l == "pre_btl_conv") conv = &b.pre_btl_conv;
+        else if (l == "post_btl_conv") conv = &b.post_btl_conv;
+        else if (l == "dw_conv") conv = &b.dw_conv;
+        else if (l == "squeeze") fc = &b.squeeze;
+        else if (l == "excite") fc = &b.excite;
+    } else {
+        if (path == "input_conv") conv = &w.input_conv;
+        else if (path == "p_hd_conv") conv = &w.p_hd_conv;
+        else if (path == "p_dw_conv") conv = &w.p_dw_conv;
+        else if (path == "p_pt_conv") conv = &w.p_pt_conv;
+        else if (path == "prob_conv") conv = &w.prob_conv;
+        else if (path == "v_hd_conv") conv = &w.v_hd_conv;
+        else if (path == "v_ownership") conv = &w.v_ownership;
+        else if (path == "p_inter_fc") fc = &w.p_inter_fc;
+        else if (path == "pass_fc") fc = &w.pass_fc;
+        else if (path == "v_inter_fc") fc = &w.v_inter_fc;
+        else if (path == "v_misc") fc = &w.v_misc;
+    }
+    if (conv) return kind == "w" ? &conv->GetWeights() : kind == "b" ? &conv->GetBiases() : nullptr;
+    if (fc) return kind == "w" ? &fc->GetWeights() : kind == "b" ? &fc->GetBiases() : nullptr;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" {
+
+const char* sayuri_host_last_error() { return g_err.c_str(); }
+
+// ---- weights only (no GPU needed)
+void* sayuri_weights_load(const char* path) {
+    auto w = std::make_unique<DNNWeights>();
+    std::string err;
+    if (!LoadWeightsFile(path, w.get(), &err)) {
+        g_err = err;
+        return nullptr;
+    }
+    return w.release();
+}
+void sayuri_weights_free(void* h) { delete static_cast<DNNWeights*>(h); }
+int sayuri_weights_info(void* h, int* info) {
+    auto* w = static_cast<DNNWeights*>(h);
+    if (!w) return -1;
+    info[0] = w->version; info[1] = w->input_channels; info[2] = w->residual_blocks; info[3] = w->residual_channels;
+    info[4] = w->policy_head_channels; info[5] = w->value_head_channels; info[6] = w->probabilities_channels;
+    info[7] = w->pass_probability_outputs; info[8] = w->ownership_channels; info[9] = w->value_misc_outputs;
+    info[10] = static_cast<int>(w->default_act); info[11] = w->policy_head_type == PolicyHeadType::kRepLK ? 1 : 0;
+    return 0;
+}
+int sayuri_weights_block_info(void* h, int idx, int* binfo) {
+    auto* w = static_cast<DNNWeights*>(h);
+    if (!w || idx < 0 || idx >= w->residual_blocks) return -1;
+    const BlockBasic& b = *w->tower[idx];
+    binfo[0] = static_cast<int>(b.type); binfo[1] = b.apply_se; binfo[2] = b.se_size;
+    binfo[3] = b.bottleneck_channels; binfo[4] = b.feedforward_channels;
+    return 0;
+}
+long sayuri_weights_tensor(void* h, const char* name, float* dst, long cap) {
+    auto* w = static_cast<DNNWeights*>(h);
+    if (!w) return -1;
+    auto* v = FindTensor(*w, name);
+    if (!v) return -1;
+    const long n = static_cast<long>(v->size());
+    if (dst) std::memcpy(dst, v->data(), sizeof(float) * static_cast<size_t>(n < cap ? n : cap));
+    return n;
+}
+
+// ---- the pipe
+void* sayuri_pipe_create(const char* weights_path, int board, int batch, int fp16, int device, int waittime_ms) {
+    try {
+        auto h = std::make_unique<PipeHandle>();
+        h->weights = std::make_shared<DNNWeights>();
+        std::string err;
+        if (!LoadWeightsFile(weights_path, h->weights.get(), &err)) {
+            g_err = err;
+            return nullptr;
+        }
+        HipPipeConfig cfg;
+        cfg.batch_size = batch;
+        cfg.fp16 = fp16 != 0;
+        cfg.default_boardsize = board;
+        cfg.gpu_waittime_ms = waittime_ms;
+        if (device >= 0) cfg.gpus = {device};
+        h->pipe = std::make_unique<HipForwardPipe>(cfg);
+        h->pipe->Initialize(h->weights);
+        return h.release();
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+void sayuri_pipe_destroy(void* hp) {
+    auto* h = static_cast<PipeHandle*>(hp);
+    if (!h) return;
+    try {
+        h->pipe->Destroy();
+    } catch (...) {
+    }
+    delete h;
+}
+
+int sayuri_pipe_num_workers(void* hp) { return static_cast<PipeHandle*>(hp)->pipe->GetNumWorkers(); }
+void* sayuri_pipe_ctx(void* hp, int gpu) { return static_cast<PipeHandle*>(hp)->pipe->ctx(gpu); }
+int sayuri_pipe_reconstruct(void* hp, int board, int batch) {
+    try {
+        static_cast<PipeHandle*>(hp)->pipe->Construct(ForwardPipeOption::Get().SetBoardSize(board).SetBatchSize(batch), nullptr);
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// n evaluations.  planes [n][43*361] in InputData layout (each sample packed with its OWN board
+// stride), out [n][2*361 + 9] = prob[bs*bs], own[bs*bs] (both packed with the sample's stride,
+// zero tail), then at offset 722: pass, wdl[3], stm, score, q_err, score_err, offset.
+// mode 0: HipForwardPipe::BatchForward(gpu) after re-padding the inputs here the way
+//         SendQueryAndWait would, outputs un-padded here; mode 1: n concurrent Forward() calls
+//         through the queue (n threads).
+int sayuri_pipe_eval(void* hp, int mode, int gpu, int n, const float* planes, const int* board_sizes,
+                     const float* komi, const int* offsets, float* out);
+}
+
+#include <thread>
+
+extern "C" int sayuri_pipe_eval(void* hp, int mode, int gpu, int n, const float* planes, const int* board_sizes,
+                                const float* komi, const int* offsets, float* out) {
+    auto* h = static_cast<PipeHandle*>(hp);
+    if (!h || n <= 0) return -1;
+    const int PL = kInputChannels * kNumIntersections, OL = 2 * kNumIntersections + 9;
+    const int C = h->weights->input_channels;
+    try {
+        std::vector<InputData> inputs(n);
+        for (int i = 0; i < n; ++i) {
+            inputs[i].board_size = board_sizes[i];
+            inputs[i].komi = komi ? komi[i] : 7.5f;
+            inputs[i].offset = static_cast<PolicyBufferOffset>(offsets ? offsets[i] : 0);
+            std::memcpy(inputs[i].planes.data(), planes + static_cast<size_t>(i) * PL, sizeof(float) * PL);
+        }
+        std::vector<OutputResult> outs(n);
+        if (mode == 0) {
+            const int B = h->pipe->board_size();
+            std::vector<InputData> padded = inputs;
+            for (int i = 0; i < n; ++i) {
+                const int bs = inputs[i].board_size;
+                if (bs == B) continue;
+                padded[i].planes.fill(0.f);
+                for (int c = 0; c < C; ++c)
+                    for (int y = 0; y < bs; ++y)
+                        for (int x = 0; x < bs; ++x)
+                            padded[i].planes[(c * B + y) * B + x] = inputs[i].planes[(c * bs + y) * bs + x];
+            }
+            outs = h->pipe->BatchForward(gpu, padded);
+            for (int i = 0; i < n; ++i) {
+                const int bs = inputs[i].board_size;
+                if (bs == B) continue;
+                OutputResult r = outs[i];
+                r.probabilities.fill(0.f);
+                r.ownership.fill(0.f);
+                for (int y = 0; y < bs; ++y)
+                    for (int x = 0; x < bs; ++x) {
+                        r.probabilities[y * bs + x] = outs[i].probabilities[y * B + x];
+                        r.ownership[y * bs + x] = outs[i].ownership[y * B + x];
+                    }
+                outs[i] = r;
+            }
+        } else {
+            std::vector<std::thread> th;
+            std::vector<std::string> errs(n);
+            for (int i = 0; i < n; ++i)
+                th.emplace_back([&, i] {
+                    try {
+                        outs[i] = h->pipe->Forward(inputs[i]);
+                    } catch (const std::exception& e) {
+                        errs[i] = e.what();
+                    }
+                });
+            for (auto& t : th) t.join();
+            for (auto& e : errs)
+                if (!e.empty()) throw std::runtime_error(e);
+        }
+        for (int i = 0; i < n; ++i) {
+            float* o = out + static_cast<size_t>(i) * OL;
+            const OutputResult& r = outs[i];
+            std::memcpy(o, r.probabilities.data(), sizeof(float) * kNumIntersections);
+            std::memcpy(o + kNumIntersections, r.ownership.data(), sizeof(float) * kNumIntersections);
+            float* t = o + 2 * kNumIntersections;
+            t[0] = r.pass_probability; t[1] = r.wdl[0]; t[2] = r.wdl[1]; t[3] = r.wdl[2];
+            t[4] = r.stm_winrate; t[5] = r.final_score; t[6] = r.q_error; t[7] = r.score_error;
+            t[8] = static_cast<float>(static_cast<int>(r.offset));
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}

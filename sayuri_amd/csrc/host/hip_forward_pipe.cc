@@ -1,0 +1,370 @@
+// hip_forward_pipe.cc -- see hip_forward_pipe.h.
+#include "hip_forward_pipe.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../../include/sayuri_hip.h"
+
+namespace sayuri_host {
+
+std::string NetworkForwardPipe::GetName() const { return Valid() ? weights_->name : "random"; }
+int NetworkForwardPipe::GetVersion() const { return Valid() ? weights_->version : -1; }
+
+namespace {
+
+[[noreturn]] void ThrowHip(const char* what) {
+    throw std::runtime_error(std::string(what) + ": " + sayuri_hip_last_error());
+}
+
+void LoadConv(sayuri_hip_ctx* ctx, int id, ConvLayer& c) {
+    if (sayuri_hip_load_tensor(ctx, id, SAYURI_T_WEIGHTS, c.GetWeights().data(), c.GetWeights().size()) ||
+        sayuri_hip_load_tensor(ctx, id, SAYURI_T_BIASES, c.GetBiases().data(), c.GetBiases().size()))
+        ThrowHip("sayuri_hip_load_tensor");
+}
+void LoadFc(sayuri_hip_ctx* ctx, int id, LinearLayer& f) {
+    if (sayuri_hip_load_tensor(ctx, id, SAYURI_T_WEIGHTS, f.GetWeights().data(), f.GetWeights().size()) ||
+        sayuri_hip_load_tensor(ctx, id, SAYURI_T_BIASES, f.GetBiases().data(), f.GetBiases().size()))
+        ThrowHip("sayuri_hip_load_tensor");
+}
+
+int BlockTypeCode(const BlockBasic& b) {
+    if (b.IsResidualBlock()) return SAYURI_BLOCK_RESIDUAL;
+    if (b.IsBottleneckBlock()) return SAYURI_BLOCK_BOTTLENECK;
+    if (b.IsNestedBottleneckBlock()) return SAYURI_BLOCK_NESTED_BOTTLENECK;
+    if (b.IsMixerBlock()) return SAYURI_BLOCK_MIXER;
+    throw std::runtime_error("unknown block type in DNNWeights");
+}
+
+// Network description + tensors -> one device graph (NNGraph::ConstructGraph,
+// cuda_forward_pipe.cc:133-613).
+sayuri_hip_ctx* BuildCtx(int device, DNNWeights& w, int max_batch, int board, bool fp16) {
+    std::vector<sayuri_hip_blockdesc> blocks(w.residual_blocks);
+    for (int i = 0; i < w.residual_blocks; ++i) {
+        BlockBasic& b = *w.tower[i];
+        blocks[i].type = BlockTypeCode(b);
+        blocks[i].apply_se = b.apply_se;
+        blocks[i].se_size = b.se_size;
+        blocks[i].bottleneck_channels = b.bottleneck_channels;
+        blocks[i].feedforward_channels = b.feedforward_channels;
+        blocks[i].dw_filter = b.IsMixerBlock() ? b.dw_conv.GetFilter() : 0;
+    }
+    sayuri_hip_netdesc d{};
+    d.version = w.version;
+    d.input_channels = w.input_channels;
+    d.residual_channels = w.residual_channels;
+    d.residual_blocks = w.residual_blocks;
+    d.policy_head_channels = w.policy_head_channels;
+    d.value_head_channels = w.value_head_channels;
+    d.probabilities_channels = w.probabilities_channels;
+    d.pass_probability_outputs = w.pass_probability_outputs;
+    d.ownership_channels = w.ownership_channels;
+    d.value_misc_outputs = w.value_misc_outputs;
+    d.default_act = static_cast<int>(w.default_act);
+    d.policy_head_type = w.policy_head_type == PolicyHeadType::kRepLK ? 1 : 0;
+    d.policy_dw_filter = d.policy_head_type ? w.p_dw_conv.GetFilter() : 0;
+    d.blocks = blocks.data();
+
+    sayuri_hip_ctx* ctx = sayuri_hip_create(device, &d, max_batch, board, fp16 ? 1 : 0);
+    if (!ctx) ThrowHip("sayuri_hip_create");
+    try {
+        LoadConv(ctx, SAYURI_L_INPUT_CONV, w.input_conv);
+        for (int i = 0; i < w.residual_blocks; ++i) {
+            BlockBasic& b = *w.tower[i];
+            if (b.IsResidualBlock()) {
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_CONV1), b.conv1);
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_CONV2), b.conv2);
+            } else if (b.IsBottleneckBlock() || b.IsNestedBottleneckBlock()) {
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_PRE_BTL), b.pre_btl_conv);
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_CONV1), b.conv1);
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_CONV2), b.conv2);
+                if (b.IsNestedBottleneckBlock()) {
+                    LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_CONV3), b.conv3);
+                    LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_CONV4), b.conv4);
+                }
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_POST_BTL), b.post_btl_conv);
+            } else {
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_DW_CONV), b.dw_conv);
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_CONV1), b.conv1);
+                LoadConv(ctx, SAYURI_L_BLOCK(i, SAYURI_S_CONV2), b.conv2);
+            }
+            if (b.apply_se) {
+                LoadFc(ctx, SAYURI_L_BLOCK(i, SAYURI_S_SQUEEZE), b.squeeze);
+                LoadFc(ctx, SAYURI_L_BLOCK(i, SAYURI_S_EXCITE), b.excite);
+            }
+        }
+        LoadConv(ctx, SAYURI_L_P_HD_CONV, w.p_hd_conv);
+        if (d.policy_head_type) {
+            LoadConv(ctx, SAYURI_L_P_DW_CONV, w.p_dw_conv);
+            LoadConv(ctx, SAYURI_L_P_PT_CONV, w.p_pt_conv);
+        }
+        LoadFc(ctx, SAYURI_L_P_INTER_FC, w.p_inter_fc);
+        LoadConv(ctx, SAYURI_L_PROB_CONV, w.prob_conv);
+        LoadFc(ctx, SAYURI_L_PASS_FC, w.pass_fc);
+        LoadConv(ctx, SAYURI_L_V_HD_CONV, w.v_hd_conv);
+        LoadFc(ctx, SAYURI_L_V_INTER_FC, w.v_inter_fc);
+        LoadConv(ctx, SAYURI_L_V_OWNERSHIP, w.v_ownership);
+        LoadFc(ctx, SAYURI_L_V_MISC, w.v_misc);
+    } catch (...) {
+        sayuri_hip_destroy(ctx);
+        throw;
+    }
+    return ctx;
+}
+
+}  // namespace
+
+HipForwardPipe::HipForwardPipe(HipPipeConfig cfg) : cfg_(std::move(cfg)) {}
+
+HipForwardPipe::~HipForwardPipe() {
+    try {
+        Destroy();
+    } catch (...) {
+    }
+}
+
+bool HipForwardPipe::Valid() const { return weights_ != nullptr; }
+
+sayuri_hip_ctx* HipForwardPipe::ctx(int gpu) const {
+    return gpu >= 0 && gpu < static_cast<int>(graphs_.size()) ? graphs_[gpu]->ctx : nullptr;
+}
+
+void HipForwardPipe::Initialize(std::shared_ptr<DNNWeights> weights) {
+    // cuda_forward_pipe.cc:14-25
+    Construct(ForwardPipeOption::Get().SetBoardSize(cfg_.default_boardsize).SetBatchSize(cfg_.batch_size), weights);
+}
+
+void HipForwardPipe::Construct(ForwardPipeOption option, std::shared_ptr<DNNWeights> weights) {
+    // cuda_forward_pipe.cc:44-119: rebuild only when the board changes or the batch grows.
+    if (weights) weights_ = weights;
+    if (weights_ == nullptr) return;  // Network falls back to its dummy backend
+    int board = option.IsValidBoardSize() ? option.board_size : board_size_;
+    int batch = option.IsValidBatchSize() ? option.batch_size : max_batch_;
+    board = std::max(board, cfg_.fixed_nn_boardsize);
+    if (board <= 0 || batch <= 0) return;
+    if (board > kBoardSize) throw std::runtime_error("NN board size exceeds MAX_BOARD_SIZE");
+    cfg_.batch_size = batch;  // forwarding size of the collector (SetForwardingSize)
+    if (board_size_ == board && batch <= max_batch_ && !graphs_.empty() && !weights) return;
+    Release();
+    board_size_ = board;
+    max_batch_ = batch;
+    BuildGraphs();
+}
+
+void HipForwardPipe::BuildGraphs() {
+    const int ndev = sayuri_hip_device_count();
+    std::vector<int> devices;
+    for (int g : cfg_.gpus)
+        if (g >= 0 && g < ndev) devices.push_back(g);
+    if (devices.empty())
+        for (int i = 0; i < ndev; ++i) devices.push_back(i);
+    if (devices.empty()) throw std::runtime_error("No executable GPU device!");
+
+    const size_t B2 = static_cast<size_t>(board_size_) * board_size_;
+    DNNWeights& w = *weights_;
+    for (int dev : devices) {
+        auto g = std::make_unique<Graph>();
+        g->device = dev;
+        g->ctx = BuildCtx(dev, w, max_batch_, board_size_, cfg_.fp16);
+        auto pinned = [&](size_t count) {
+            float* p = static_cast<float*>(sayuri_hip_host_alloc(sizeof(float) * count));
+            if (!p) ThrowHip("sayuri_hip_host_alloc");
+            return p;
+        };
+        g->planes = pinned(static_cast<size_t>(max_batch_) * w.input_channels * B2);
+        g->prob = pinned(static_cast<size_t>(max_batch_) * w.probabilities_channels * B2);
+        g->pass = pinned(static_cast<size_t>(max_batch_) * w.pass_probability_outputs);
+        g->misc = pinned(static_cast<size_t>(max_batch_) * w.value_misc_outputs);
+        g->own = pinned(static_cast<size_t>(max_batch_) * B2);
+        g->bsz.resize(max_batch_);
+        graphs_.push_back(std::move(g));
+    }
+    running_.store(true);
+    for (auto& g : graphs_) g->pump = std::thread([this, gp = g.get()] { PumpLoop(gp); });
+}
+
+void HipForwardPipe::DestroyGraphs() {
+    running_.store(false);
+    for (auto& g : graphs_) {
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+        }
+        g->cv.notify_all();
+    }
+    for (auto& g : graphs_)
+        if (g->pump.joinable()) g->pump.join();
+    for (auto& g : graphs_) {
+        sayuri_hip_host_free(g->planes);
+        sayuri_hip_host_free(g->prob);
+        sayuri_hip_host_free(g->pass);
+        sayuri_hip_host_free(g->misc);
+        sayuri_hip_host_free(g->own);
+        if (g->ctx) sayuri_hip_destroy(g->ctx);
+    }
+    graphs_.clear();
+}
+
+void HipForwardPipe::Release() { DestroyGraphs(); }
+
+void HipForwardPipe::Destroy() { DestroyGraphs(); }
+
+// Copy one request into staging slot `slot`, re-padding a smaller board top-left into the NN
+// grid (what SendQueryAndWait does with a temporary InputData, batch_forward_pipe.cc:15-33).
+void HipForwardPipe::StageInput(Graph* g, int slot, const InputData& in, bool already_padded) {
+    const int B = board_size_, bs = in.board_size, C = weights_->input_channels;
+    if (bs < 2 || bs > B) throw std::runtime_error("InputData board size does not fit the NN board");
+    float* dst = g->planes + static_cast<size_t>(slot) * C * B * B;
+    g->bsz[slot] = bs;
+    if (bs == B || already_padded) {
+        std::memcpy(dst, in.planes.data(), sizeof(float) * C * B * B);
+        return;
+    }
+    std::memset(dst, 0, sizeof(float) * C * B * B);
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < bs; ++y)
+            std::memcpy(dst + (static_cast<size_t>(c) * B + y) * B, in.planes.data() + (static_cast<size_t>(c) * bs + y) * bs,
+                        sizeof(float) * bs);
+}
+
+// FillOutputs of the CPU pipe (blas_forward_pipe.cc:565-619 -- the oracle; the CUDA pipe's
+// pass[0] for every offset, cuda_forward_pipe.cc:1074, is a known discrepancy) fused with the
+// un-padding of SendQueryAndWait (batch_forward_pipe.cc:48-68).
+void HipForwardPipe::FillOutput(const Graph* g, int slot, const InputData& in, bool unpad, OutputResult* out) const {
+    const DNNWeights& w = *weights_;
+    const int B = board_size_, B2 = B * B, bs = in.board_size;
+    const bool v1 = w.version <= 2;  // Encoder::GetEncoderVersion, encoder.h:64-77
+    int offset = v1 ? 0 : static_cast<int>(in.offset);
+    if (offset < 0 || offset >= w.probabilities_channels) offset = 0;
+    const float* prob = g->prob + (static_cast<size_t>(slot) * w.probabilities_channels + offset) * B2;
+    const float* own = g->own + static_cast<size_t>(slot) * B2;
+    const float* misc = g->misc + static_cast<size_t>(slot) * w.value_misc_outputs;
+    const float* pass = g->pass + static_cast<size_t>(slot) * w.pass_probability_outputs;
+    if (unpad && bs != B) {
+        for (int y = 0; y < bs; ++y)
+            for (int x = 0; x < bs; ++x) {
+                out->probabilities[y * bs + x] = prob[y * B + x];
+                out->ownership[y * bs + x] = own[y * B + x];
+            }
+    } else {
+        std::copy(prob, prob + B2, out->probabilities.begin());
+        std::copy(own, own + B2, out->ownership.begin());
+    }
+    out->pass_probability = pass[offset];
+    out->wdl[0] = misc[0];
+    out->wdl[1] = misc[1];
+    out->wdl[2] = misc[2];
+    out->stm_winrate = misc[3];
+    if (v1) {
+        out->final_score = misc[4];
+        out->q_error = 0.f;
+        out->score_error = 0.f;
+        out->offset = PolicyBufferOffset::kNormal;
+    } else {
+        out->final_score = misc[8];
+        out->q_error = misc[13];
+        out->score_error = misc[14];
+        out->offset = in.offset;
+    }
+    out->board_size = bs;
+    out->komi = in.komi;
+    out->fp16 = cfg_.fp16;
+}
+
+void HipForwardPipe::RunBatch(Graph* g, const Request* reqs, int n) {
+    std::lock_guard<std::mutex> dev(g->dev_mu);
+    for (int i = 0; i < n; ++i) StageInput(g, i, *reqs[i].input, false);
+    if (sayuri_hip_forward(g->ctx, n, g->planes, g->bsz.data(), g->prob, g->pass, g->misc, g->own))
+        ThrowHip("sayuri_hip_forward");
+    for (int i = 0; i < n; ++i) {
+        FillOutput(g, i, *reqs[i].input, true, reqs[i].output);
+        reqs[i].done->store(1, std::memory_order_release);
+    }
+    batches_.fetch_add(1, std::memory_order_relaxed);
+    evals_.fetch_add(static_cast<size_t>(n), std::memory_order_relaxed);
+}
+
+// One persistent pump per GPU.  Gathers up to batch_size requests; if fewer are waiting it
+// sleeps at most gpu_waittime_ms for more, and once a wait times out with work pending it
+// stops waiting until the queue runs dry again (the adaptive 0 <-> base wait of
+// batch_forward_pipe.cc:99-193).
+void HipForwardPipe::PumpLoop(Graph* g) {
+    std::vector<Request> batch;
+    bool eager = false;
+    while (true) {
+        batch.clear();
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv.wait(lk, [&] { return !running_.load() || !g->queue.empty(); });
+            if (!running_.load() && g->queue.empty()) return;
+            const int want = std::min(cfg_.batch_size, max_batch_);
+            if (static_cast<int>(g->queue.size()) < want && !eager && cfg_.gpu_waittime_ms > 0) {
+                const bool full = g->cv.wait_for(lk, std::chrono::milliseconds(cfg_.gpu_waittime_ms), [&] {
+                    return !running_.load() || static_cast<int>(g->queue.size()) >= want;
+                });
+                if (!full) eager = true;
+            }
+            const int take = std::min<int>(static_cast<int>(g->queue.size()), want);
+            for (int i = 0; i < take; ++i) {
+                batch.push_back(g->queue.front());
+                g->queue.pop_front();
+            }
+            if (g->queue.empty()) eager = false;
+        }
+        if (batch.empty()) continue;
+        try {
+            RunBatch(g, batch.data(), static_cast<int>(batch.size()));
+        } catch (const std::exception&) {
+            // surface the failure to every waiter: done = -1 (Forward rethrows)
+            for (auto& r : batch) r.done->store(-1, std::memory_order_release);
+        }
+    }
+}
+
+void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atomic<int>* done) {
+    if (graphs_.empty()) throw std::runtime_error("HipForwardPipe is not constructed");
+    done->store(0, std::memory_order_relaxed);
+    Graph* g = graphs_[next_graph_.fetch_add(1, std::memory_order_relaxed) % graphs_.size()].get();
+    bool wake;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->queue.push_back(Request{&input, out, done});
+        wake = static_cast<int>(g->queue.size()) >= std::min(cfg_.batch_size, max_batch_) || g->queue.size() == 1;
+    }
+    if (wake) g->cv.notify_one();
+}
+
+OutputResult HipForwardPipe::Forward(const InputData& input) {
+    OutputResult out;
+    std::atomic<int> done{0};
+    Submit(input, &out, &done);
+    // short spin, then yield: a batch takes O(100 us .. ms)
+    int spins = 0;
+    int st;
+    while ((st = done.load(std::memory_order_acquire)) == 0) {
+        if (++spins < 64) continue;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    if (st < 0) throw std::runtime_error("HIP forward pipe failed while evaluating a batch");
+    return out;
+}
+
+std::vector<OutputResult> HipForwardPipe::BatchForward(int gpu, const std::vector<InputData>& inputs) {
+    if (gpu < 0 || gpu >= static_cast<int>(graphs_.size())) throw std::runtime_error("BatchForward: bad gpu index");
+    const int n = static_cast<int>(inputs.size());
+    if (n > max_batch_) throw std::runtime_error("BatchForward: batch exceeds the constructed maximum");
+    std::vector<OutputResult> outs(inputs.size());
+    if (n == 0) return outs;
+    Graph* g = graphs_[gpu].get();
+    std::lock_guard<std::mutex> dev(g->dev_mu);  // keep the pump out while we own the staging buffers
+    for (int i = 0; i < n; ++i) StageInput(g, i, inputs[i], true);
+    if (sayuri_hip_forward(g->ctx, n, g->planes, g->bsz.data(), g->prob, g->pass, g->misc, g->own))
+        ThrowHip("sayuri_hip_forward");
+    for (int i = 0; i < n; ++i) FillOutput(g, i, inputs[i], false, &outs[i]);
+    batches_.fetch_add(1, std::memory_order_relaxed);
+    evals_.fetch_add(static_cast<size_t>(n), std::memory_order_relaxed);
+    return outs;
+}
+
+}  // namespace sayuri_host

@@ -1,0 +1,107 @@
+// hip_forward_pipe.h -- the MI355X backend behind Sayuri's NetworkForwardPipe plugin interface.
+//
+// Counterpart of CudaForwardPipe (reference src/neural/cuda/cuda_forward_pipe.{h,cc}) +
+// BatchForwardPipe (reference src/neural/batch_forward_pipe.{h,cc}):
+//   * same seven entry points (Initialize / Forward / Construct / Release / Destroy / Valid /
+//     GetNumWorkers) plus BatchForward(gpu, inputs), same argument meaning, same error
+//     behaviour (device/API failures surface as std::runtime_error, cuda_common.cc:46-62);
+//   * the device side is reached only through the C-ABI of include/sayuri_hip.h;
+//   * the leaf-batch collector is rewritten: callers write their planes ONCE, straight into a
+//     pinned staging slot of the batch being assembled (the reference copies the 62 KB
+//     InputData three times per evaluation: batch_forward_pipe.cc:9, :178,
+//     cuda_forward_pipe.cc:696-701), one persistent pump thread per GPU owns its ctx and its
+//     own queue shard, and completion is a per-request flag instead of a heap-allocated
+//     mutex+condvar pair per leaf.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pipe_api.h"
+#include "weights_model.h"
+
+struct sayuri_hip_ctx;
+
+namespace sayuri_host {
+
+// What the reference reads from its global option map (config.cc:21-133): "batch_size",
+// "gpus", "fp16", "gpu_waittime", "defualt_boardsize", "fixed_nn_boardsize".
+struct HipPipeConfig {
+    int batch_size{256};
+    std::vector<int> gpus;       // empty = every visible device
+    bool fp16{true};
+    int gpu_waittime_ms{2};
+    int default_boardsize{kBoardSize};
+    int fixed_nn_boardsize{0};
+};
+
+class HipForwardPipe : public NetworkForwardPipe {
+public:
+    explicit HipForwardPipe(HipPipeConfig cfg = {});
+    ~HipForwardPipe() override;
+
+    void Initialize(std::shared_ptr<DNNWeights> weights) override;
+    OutputResult Forward(const InputData& input) override;
+    void Construct(ForwardPipeOption option, std::shared_ptr<DNNWeights> weights) override;
+    void Release() override;
+    void Destroy() override;
+    bool Valid() const override;
+    int GetNumWorkers() const override { return static_cast<int>(graphs_.size()); }
+
+    // batch_forward_pipe.h:27-28.  `inputs` are already re-padded into the NN grid.
+    std::vector<OutputResult> BatchForward(int gpu, const std::vector<InputData>& inputs);
+
+    // Non-blocking flavour for M:N self-play schedulers: the result lands in *out and
+    // *done flips to 1 (release) once the batch containing it has been evaluated.
+    void Submit(const InputData& input, OutputResult* out, std::atomic<int>* done);
+
+    int board_size() const { return board_size_; }
+    int max_batch() const { return max_batch_; }
+    bool fp16() const { return cfg_.fp16; }
+    sayuri_hip_ctx* ctx(int gpu) const;
+    size_t num_batches() const { return batches_.load(std::memory_order_relaxed); }
+    size_t num_evals() const { return evals_.load(std::memory_order_relaxed); }
+
+private:
+    struct Request {
+        const InputData* input;
+        OutputResult* output;
+        std::atomic<int>* done;
+    };
+    struct Graph {  // one per GPU (NNGraph in the reference)
+        int device{-1};
+        sayuri_hip_ctx* ctx{nullptr};
+        // pinned staging, sized for max_batch
+        float* planes{nullptr};
+        float *prob{nullptr}, *pass{nullptr}, *misc{nullptr}, *own{nullptr};
+        std::vector<int> bsz;
+        std::thread pump;
+        std::mutex dev_mu;  // owner of ctx + staging buffers (pump batch or a direct BatchForward)
+        std::mutex mu;      // guards `queue`
+        std::condition_variable cv;
+        std::deque<Request> queue;
+    };
+
+    void BuildGraphs();
+    void DestroyGraphs();
+    void PumpLoop(Graph* g);
+    void RunBatch(Graph* g, const Request* reqs, int n);
+    void StageInput(Graph* g, int slot, const InputData& in, bool already_padded);
+    void FillOutput(const Graph* g, int slot, const InputData& in, bool unpad, OutputResult* out) const;
+
+    HipPipeConfig cfg_;
+    int board_size_{0};
+    int max_batch_{0};
+    std::vector<std::unique_ptr<Graph>> graphs_;
+    std::atomic<bool> running_{false};
+    std::atomic<unsigned> next_graph_{0};
+    std::atomic<size_t> batches_{0}, evals_{0};
+};
+
+}  // namespace sayuri_host

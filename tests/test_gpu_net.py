@@ -1,0 +1,133 @@
+"""Whole-network parity of the HIP pipe against the CPU oracle and the reference goldens.
+
+Tolerances (raw, pre-softmax outputs; magnitudes are O(1)):
+  fp32 engine : abs <= 1e-4   (SURVEY.md 8c gate; north_star "within fp32 tolerance")
+  fp16 engine : abs <= 3e-2 on 6..20-block nets, and the reference's own GPU-vs-CPU SelfCheck
+                criterion L2(softmax policy ++ pass ++ wdl_winrate) <= 0.2 (network.cc:333-359)
+                as the hard floor.
+"""
+import numpy as np
+import pytest
+
+from _golden import Golden
+from _oracle import PortNet
+from golden_specs import FIXTURES
+from sayuri_amd import weights as W
+from sayuri_amd.pipe import HipForwardPipe
+
+pytestmark = pytest.mark.gpu
+
+FP32_ATOL = 1e-4
+FP16_ATOL = 3e-2
+
+
+def self_check_l2(got, exp, bs):
+    """reference Network::SelfCheck (network.cc:333-359) on post-processed outputs."""
+    a, b = PortNet.postprocess(got, bs), PortNet.postprocess(exp, bs)
+    s = bs * bs
+    va = np.concatenate([a[:s + 1], [a[2 * s + 1 + 3]]])
+    vb = np.concatenate([b[:s + 1], [b[2 * s + 1 + 3]]])
+    return float(np.sqrt(((va - vb) ** 2).sum()))
+
+
+def check(pipe, cases, atol, label):
+    planes = [c[0] for c in cases]
+    bsz = [c[1] for c in cases]
+    offs = [c[2] for c in cases]
+    for mode, outs in (("batch", pipe.BatchForward(planes, bsz, offsets=offs)),
+                       ("queue", pipe.Forward(planes, bsz, offsets=offs))):
+        for (p, bs, off, exp), got in zip(cases, outs):
+            assert got.shape == exp.shape
+            assert np.isfinite(got).all(), (label, mode)
+            err = float(np.abs(got - exp).max())
+            assert err <= atol, (label, mode, bs, off, err)
+            assert self_check_l2(got, exp, bs) <= 0.2
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("name", [fx["name"] for fx in FIXTURES if fx["name"].startswith("tiny")] + ["net_6b96"])
+def test_golden_parity(name, fp16, tmp_weights_dir):
+    """HIP pipe vs the outputs of the reference's own BlasForwardPipe (tests/golden)."""
+    g = Golden(name, tmp_weights_dir)
+    cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases if c["winograd"] == 1]
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=16, fp16=fp16)
+    try:
+        check(pipe, cases, FP16_ATOL if fp16 else FP32_ATOL, name)
+    finally:
+        pipe.Destroy()
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
+def test_20b256_golden_and_oracle(fp16, tmp_weights_dir):
+    """BASELINE.json configs[1] network: golden cases + fresh oracle evaluations."""
+    g = Golden("net_20b256", tmp_weights_dir)
+    cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
+    oracle = PortNet(g.weights_path)
+    for i, bs in enumerate((19, 9)):
+        p = W.synthetic_planes(1, bs, seed=900 + i)[0]
+        cases.append((p, bs, i, oracle.forward(p, bs, offset=i)))
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=fp16)
+    try:
+        check(pipe, cases, FP16_ATOL if fp16 else FP32_ATOL, "20b256")
+    finally:
+        pipe.Destroy()
+
+
+def test_mixed_board_batch_matches_native_evaluation(tmp_weights_dir):
+    """configs[4] mechanism: 9/13/19 samples in one batch on a 19x19 graph equal the oracle's
+    native small-board evaluation of each sample (no mask error, fp32 engine)."""
+    g = Golden("tiny_all", tmp_weights_dir)
+    oracle = PortNet(g.weights_path)
+    rng = np.random.default_rng(3)
+    bsz = [int(b) for b in rng.choice([9, 13, 19], size=24)] + [7, 2, 19]
+    planes = W.synthetic_planes(len(bsz), bsz, seed=77)
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=32, fp16=False)
+    try:
+        outs = pipe.BatchForward(planes, bsz)
+        for p, bs, got in zip(planes, bsz, outs):
+            exp = oracle.forward(p, bs)
+            assert np.abs(got - exp).max() <= FP32_ATOL, bs
+    finally:
+        pipe.Destroy()
+
+
+def test_batch256_properties_20b256(tmp_weights_dir):
+    """Full bench size (batch 256, 19x19, 20b256, fp16): size-independent properties --
+    a sample's result does not depend on its slot or on its neighbours, duplicated inputs give
+    bit-identical outputs, and a few slots agree with the oracle."""
+    g = Golden("net_20b256", tmp_weights_dir)
+    n = 256
+    base = W.synthetic_planes(8, 19, seed=1234)
+    idx = np.arange(n) % 8
+    planes = [base[i] for i in idx]
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=n, fp16=True)
+    try:
+        outs = pipe.BatchForward(planes, [19] * n)
+        for i in range(8, n):
+            np.testing.assert_array_equal(outs[i], outs[i % 8])
+        rev = pipe.BatchForward(planes[::-1], [19] * n)
+        for i in range(n):
+            np.testing.assert_array_equal(rev[i], outs[n - 1 - i])
+        oracle = PortNet(g.weights_path)
+        for i in (0, 5):
+            exp = oracle.forward(base[i], 19)
+            assert np.abs(outs[i] - exp).max() <= FP16_ATOL
+        one = pipe.BatchForward([base[3]], [19])[0]
+        assert np.abs(one - outs[3]).max() <= 1e-6  # batch of 1 vs inside a batch of 256
+    finally:
+        pipe.Destroy()
+
+
+def test_reconstruct_smaller_board(tmp_weights_dir):
+    """Network::Reconstruct path: NN board 9 graph evaluates 9x9 natively (BASELINE configs[0] net)."""
+    g = Golden("net_6b96", tmp_weights_dir)
+    oracle = PortNet(g.weights_path)
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=4, fp16=False)
+    try:
+        pipe.Construct(9, 4)
+        p = W.synthetic_planes(3, 9, seed=5)
+        outs = pipe.BatchForward(p, [9, 9, 9])
+        for x, got in zip(p, outs):
+            assert np.abs(got - oracle.forward(x, 9)).max() <= FP32_ATOL
+    finally:
+        pipe.Destroy()
