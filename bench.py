@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- NN evals/sec of the Sayuri forward pipe on MI355X.
+
+Workload = BASELINE.json configs[1]: 19x19 board, 20-block x 256-filter network (SE on every
+3rd block, 32-channel heads, Mish), batch = 256, inference only, synthetic planes, random-init
+weights (seeded).  A "step" is one pass of the whole network over one batch of 256 positions
+whose input planes are already resident in HBM; value = whole-job evals/s over all ranks.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; positions (games) shard embarrassingly, there is no data-path
+collective -- torch.distributed (RCCL) is used only for the start/stop barrier, the
+max-over-ranks timing and the stats gather.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GFLOP_PER_EVAL_20B256 = None  # computed from the layer list below
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def algorithmic_flops_per_eval(spec, board: int = 19) -> float:
+    """2*MAC of the direct convolutions + FCs of one evaluation."""
+    s = board * board
+    c = spec.channels
+    mac = 43 * c * 9 * s
+    for b in spec.blocks:
+        if b.kind == "ResidualBlock":
+            mac += 2 * c * c * 9 * s
+        elif b.kind == "BottleneckBlock":
+            i = b.bottleneck_channels or c // 2
+            mac += 2 * c * i * s + 2 * i * i * 9 * s
+        elif b.kind == "NestedBottleneckBlock":
+            i = b.bottleneck_channels or c // 2
+            mac += 2 * c * i * s + 4 * i * i * 9 * s
+        elif b.kind == "MixerBlock":
+            f = b.ffn_channels or int(1.5 * c)
+            mac += c * b.kernel_size ** 2 * s + 2 * c * f * s
+        if b.se:
+            se = c // spec.se_ratio
+            mac += 3 * c * se + se * 2 * c
+    pc, vc = spec.policy_channels, spec.value_channels
+    mac += c * pc * s + 3 * pc * pc + pc * 5 * s + pc * 5
+    mac += c * vc * s + 9 * vc * vc + vc * s + 3 * vc * 15
+    return 2.0 * mac
+
+
+def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
+    """Time the CPU pipe on this box's host cores on a bounded sample of the same workload.
+    Prefers the reference's own BlasForwardPipe (oracle/_ref, kind "reference"); falls back to
+    the C restatement (kind "port").  One independent evaluation per thread at a time, like the
+    reference's CPU mode (batch 1 per search thread, config.cc:254-265)."""
+    from _oracle import PortNet, RefNet, ref_available
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    if ref_available():
+        net, kind = RefNet(weights_path, True), "reference"
+    else:
+        net, kind = PortNet(weights_path, True), "port"
+    # single-thread calibration (also warms the caches)
+    t0 = time.perf_counter()
+    net.forward(planes[0], 19)
+    one = time.perf_counter() - t0
+    per_thread = max(1, int(round(seconds / max(one, 1e-3) / 1.5)))
+    counts = [0] * threads
+
+    def work(i):
+        for k in range(per_thread):
+            net.forward(planes[(i + k) % len(planes)], 19)
+            counts[i] += 1
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = sum(counts)
+    return {"value": round(total / dt, 3), "unit": "evals/s", "cores": threads, "kind": kind,
+            "sample": f"{total} evals of the same 20b256 19x19 net in {dt:.1f}s, {threads} threads x batch 1 "
+                      f"(1 thread alone: {1.0 / one:.2f} evals/s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--fp32", action="store_true", help="strict-parity fp32 engine instead of fp16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--profile", action="store_true", help="also print the per-kernel-class table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from sayuri_amd import _lib
+    from sayuri_amd import weights as W
+    from sayuri_amd.pipe import HipForwardPipe
+
+    lib = _lib.hip()
+    spec = W.spec_20b256()
+    wpath = f"/tmp/sayuri_bench_20b256_seed22_{os.getuid()}.bin"
+    if local_rank == 0 and not os.path.exists(wpath):
+        W.write_weights(wpath, spec, seed=22)
+    if dist is not None:
+        dist.barrier()
+    else:
+        while not os.path.exists(wpath):
+            time.sleep(0.1)
+
+    fp16 = not args.fp32
+    n = args.batch
+    pipe = HipForwardPipe(wpath, board_size=19, batch_size=n, fp16=fp16, device=local_rank)
+    ctx = pipe.ctx(0)
+    planes = W.synthetic_planes(n, 19, seed=1000 + rank)
+    grid = np.ascontiguousarray(np.stack(planes), np.float32)  # [n][43][361]
+    bsz = np.full(n, 19, np.int32)
+    fp = lambda a: a.ctypes.data_as(_lib.c_float_p)
+    if lib.sayuri_hip_upload(ctx, n, fp(grid), bsz.ctypes.data_as(_lib.c_int_p)):
+        raise RuntimeError(lib.sayuri_hip_last_error().decode())
+
+    def sync_all():
+        lib.sayuri_hip_sync(ctx)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    ms = ctypes.c_float(0)
+    if args.warmup > 0:
+        lib.sayuri_hip_mark_kernel(ctx, b"")
+        if lib.sayuri_hip_time_runs(ctx, args.warmup, ctypes.byref(ms)):
+            raise RuntimeError(lib.sayuri_hip_last_error().decode())
+    lib.sayuri_hip_mark_kernel(ctx, b"conv3x3_tower")
+
+    # ---- timed region: exactly K steps between barrier+sync pairs
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    if lib.sayuri_hip_time_runs(ctx, args.steps, ctypes.byref(ms)):
+        raise RuntimeError(lib.sayuri_hip_last_error().decode())
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    stat = _lib.KernelStat()
+    lib.sayuri_hip_timed_stat(ctx, ctypes.byref(stat))
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        flops_eval = algorithmic_flops_per_eval(spec)
+        evals = world * n * args.steps
+        value = evals / elapsed
+        dtype = "f16" if fp16 else "f32"
+        peak = PEAK_TFLOPS[dtype]
+        ach = None
+        if stat.launches > 0 and stat.total_ms > 0:
+            ach = (stat.flops / stat.launches) / (stat.total_ms / stat.launches * 1e-3) / 1e12
+        result = {
+            "metric": "nn_evals_per_sec", "value": round(value, 1), "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: 19x19, 20-block x 256-filter net (SE every 3rd block, heads 32ch, "
+                                   "mish), batch=256 inference microbench, planes resident in HBM",
+                       "batch_per_gpu": n, "global_batch": n * world, "board": 19, "parallelism": f"dp{world}",
+                       "gflop_per_eval": round(flops_eval / 1e9, 3),
+                       "whole_net_tflops": round(value * flops_eval / 1e12, 2),
+                       "whole_net_mfma_frac": round(value * flops_eval / 1e12 / (peak * world), 4),
+                       "device_ms_per_step": round(ms.value / args.steps, 4)},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (conv3x3_tower, 256->256 3x3)",
+                         "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4) if ach else None, "traffic": None,
+                         "launches_timed": int(stat.launches),
+                         "avg_launch_us": round(stat.total_ms / max(stat.launches, 1) * 1e3, 2),
+                         "flops_per_launch": stat.flops / max(stat.launches, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(wpath, planes, args.cpu_seconds)
+        if args.profile:
+            rows = (_lib.KernelStat * 32)()
+            k = lib.sayuri_hip_profile_run(ctx, rows, 32)
+            tot = sum(rows[i].total_ms for i in range(k))
+            print(f"{'kernel class':<18}{'launches':>9}{'ms':>10}{'%':>7}{'TFLOP/s':>10}{'GB/s':>9}", file=sys.stderr)
+            for i in range(k):
+                r = rows[i]
+                tf = r.flops / (r.total_ms * 1e-3) / 1e12 if r.total_ms > 0 else 0
+                gb = r.bytes / (r.total_ms * 1e-3) / 1e9 if r.total_ms > 0 else 0
+                print(f"{r.name.decode():<18}{r.launches:>9}{r.total_ms:>10.3f}{100 * r.total_ms / tot:>7.1f}"
+                      f"{tf:>10.1f}{gb:>9.0f}", file=sys.stderr)
+            print(f"{'sum (serialised)':<18}{'':>9}{tot:>10.3f}", file=sys.stderr)
+    pipe.Destroy()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

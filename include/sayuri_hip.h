@@ -131,6 +131,13 @@ typedef struct {
 } sayuri_hip_kernel_stat;
 int sayuri_hip_profile_run(sayuri_hip_ctx* ctx, sayuri_hip_kernel_stat* rows, int cap);
 
+/* Per-launch timing INSIDE the timed region: after sayuri_hip_mark_kernel(ctx, "conv3x3_tower"),
+ * every launch of that kernel class during sayuri_hip_time_runs is bracketed by an
+ * un-synchronised HIP event pair on the ctx stream; sayuri_hip_timed_stat returns their sum
+ * (launch count, total ms, algorithmic FLOPs/bytes).  NULL / "" disables marking. */
+int sayuri_hip_mark_kernel(sayuri_hip_ctx* ctx, const char* name);
+int sayuri_hip_timed_stat(sayuri_hip_ctx* ctx, sayuri_hip_kernel_stat* row);
+
 /* Page-locked host memory for the staging buffers handed to upload/download/forward
  * (replaces the cudaHostAlloc staging of reference cuda_common.cc:312-403); the host side
  * never includes a HIP header. */

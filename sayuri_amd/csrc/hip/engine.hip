@@ -160,6 +160,8 @@ public:
     virtual int download(float* prob, float* pass, float* misc, float* own) = 0;
     virtual int time_runs(int iters, float* ms) = 0;
     virtual int profile_run(sayuri_hip_kernel_stat* rows, int cap) = 0;
+    virtual int mark_kernel(const char* name) = 0;
+    virtual int timed_stat(sayuri_hip_kernel_stat* row) = 0;
     virtual size_t device_bytes() const = 0;
 };
 
@@ -257,12 +259,39 @@ public:
     int time_runs(int iters, float* ms) override {
         if (!have_batch_) return fail("time_runs before upload");
         HIP_OK(hipSetDevice(device_));
+        pool_used_ = 0;
+        light_ = !light_name_.empty();
         HIP_OK(hipEventRecord(ev0_, stream_));
         for (int i = 0; i < iters; ++i)
-            if (forward()) return -1;
+            if (forward()) { light_ = false; return -1; }
         HIP_OK(hipEventRecord(ev1_, stream_));
+        light_ = false;
         HIP_OK(hipEventSynchronize(ev1_));
         HIP_OK(hipEventElapsedTime(ms, ev0_, ev1_));
+        // fold the per-launch event pairs of the marked kernel into one stat row
+        timed_stat_ = Stat{};
+        for (size_t i = 0; i + 1 < pool_used_; i += 2) {
+            float t = 0.f;
+            HIP_OK(hipEventElapsedTime(&t, pool_[i], pool_[i + 1]));
+            timed_stat_.launches += 1;
+            timed_stat_.ms += t;
+            timed_stat_.flops += light_flops_;
+            timed_stat_.bytes += light_bytes_;
+        }
+        return 0;
+    }
+
+    int mark_kernel(const char* name) override {
+        light_name_ = name ? name : "";
+        return 0;
+    }
+    int timed_stat(sayuri_hip_kernel_stat* row) override {
+        std::memset(row, 0, sizeof(*row));
+        std::snprintf(row->name, sizeof(row->name), "%s", light_name_.c_str());
+        row->launches = timed_stat_.launches;
+        row->total_ms = timed_stat_.ms;
+        row->flops = timed_stat_.flops;
+        row->bytes = timed_stat_.bytes;
         return 0;
     }
 
@@ -462,6 +491,8 @@ private:
         (void)hipSetDevice(device_);
         for (void* p : allocs_) (void)hipFree(p);
         allocs_.clear();
+        for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
+        pool_.clear();
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
         if (stream_) (void)hipStreamDestroy(stream_);
@@ -474,8 +505,28 @@ private:
 
     template <typename F> int timed(const char* name, double flops, double bytes, F&& launch) {
         if (!profiling_) {
+            // light mode: un-synchronised event pairs around the dominant kernel only
+            const bool mark = light_ && light_name_ == name;
+            hipEvent_t a = nullptr, b = nullptr;
+            if (mark) {
+                if (pool_used_ + 2 > pool_.size()) {
+                    for (int i = 0; i < 64; ++i) {
+                        hipEvent_t e;
+                        HIP_OK(hipEventCreate(&e));
+                        pool_.push_back(e);
+                    }
+                }
+                a = pool_[pool_used_++];
+                b = pool_[pool_used_++];
+                HIP_OK(hipEventRecord(a, stream_));
+            }
             launch();
             HIP_OK(hipGetLastError());
+            if (mark) {
+                HIP_OK(hipEventRecord(b, stream_));
+                light_flops_ = flops;
+                light_bytes_ = bytes;
+            }
             return 0;
         }
         HIP_OK(hipEventRecord(ev0_, stream_));
@@ -701,6 +752,13 @@ private:
     HostGeom geom_;
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;
+    // light per-launch timing of one kernel class inside time_runs()
+    bool light_ = false;
+    std::string light_name_;
+    std::vector<hipEvent_t> pool_;
+    size_t pool_used_ = 0;
+    double light_flops_ = 0, light_bytes_ = 0;
+    Stat timed_stat_;
 
 };
 
@@ -774,6 +832,14 @@ int sayuri_hip_forward(sayuri_hip_ctx* ctx, int n, const float* planes, const in
 int sayuri_hip_time_runs(sayuri_hip_ctx* ctx, int iters, float* total_ms) {
     if (!ctx || !total_ms || iters <= 0) return fail("time_runs: bad argument");
     return ctx->eng->time_runs(iters, total_ms);
+}
+
+int sayuri_hip_mark_kernel(sayuri_hip_ctx* ctx, const char* name) {
+    return ctx ? ctx->eng->mark_kernel(name) : fail("mark_kernel: null ctx");
+}
+int sayuri_hip_timed_stat(sayuri_hip_ctx* ctx, sayuri_hip_kernel_stat* row) {
+    if (!ctx || !row) return fail("timed_stat: bad argument");
+    return ctx->eng->timed_stat(row);
 }
 
 int sayuri_hip_profile_run(sayuri_hip_ctx* ctx, sayuri_hip_kernel_stat* rows, int cap) {
