@@ -22,6 +22,7 @@
 #include "../../../include/sayuri_hip.h"
 #include "common.h"
 #include "conv_mfma.h"
+#include "conv_glds.h"
 #include "small_ops.h"
 
 namespace sayuri {
@@ -75,6 +76,62 @@ template <> void register_all_convs<float>() {
     register_conv<float, 4, 2>();
 }
 
+// tuned fp16 3x3 kernels (conv_glds.h)
+struct GldsEntry {
+    int wmt, wnt, ns;
+    void (*fn)(const GldsParams);
+    size_t lds;
+    int npos_cap;
+};
+static std::vector<GldsEntry>& glds_entries() {
+    static std::vector<GldsEntry> e;
+    return e;
+}
+template <int WMT, int WNT, int NS> static void register_glds() {
+    typedef GldsCfg<WMT, WNT, NS> Cfg;
+    glds_entries().push_back({WMT, WNT, NS, &conv_glds_kernel<WMT, WNT, NS>, Cfg::lds_bytes(), Cfg::NPOS_CAP});
+}
+template <int WMT, int WNT> static void register_glds3() {
+    typedef Glds3Cfg<WMT, WNT> Cfg;
+    glds_entries().push_back({WMT, WNT, 1, &conv_glds3_kernel<WMT, WNT>, Cfg::lds_bytes(), Cfg::NPOS_CAP});
+}
+static void register_all_glds() {
+    if (!glds_entries().empty()) return;
+    register_glds3<8, 3>(); register_glds3<8, 2>(); register_glds3<4, 3>(); register_glds3<4, 2>();
+    if (const char* abl = getenv("SAYURI_ABL")) {  // timing-only ablations of the <8,3> kernel
+        const int m = atoi(abl);
+        GldsEntry& e = glds_entries()[0];
+        switch (m) {
+        case 1: e.fn = &conv_glds3_kernel<8, 3, 1>; break;
+        case 2: e.fn = &conv_glds3_kernel<8, 3, 2>; break;
+        case 3: e.fn = &conv_glds3_kernel<8, 3, 3>; break;
+        case 4: e.fn = &conv_glds3_kernel<8, 3, 4>; break;
+        case 7: e.fn = &conv_glds3_kernel<8, 3, 7>; break;
+        case 8: e.fn = &conv_glds3_kernel<8, 3, 8>; break;
+        case 15: e.fn = &conv_glds3_kernel<8, 3, 15>; break;
+        default: break;
+        }
+    }
+    register_glds<8, 4, 4>(); register_glds<8, 3, 4>(); register_glds<8, 4, 3>(); register_glds<8, 3, 3>();
+    register_glds<8, 2, 4>();
+    register_glds<4, 4, 4>(); register_glds<4, 3, 4>(); register_glds<4, 2, 4>();
+}
+static void enable_big_lds_glds() {
+    register_all_glds();
+    for (const auto& e : glds_entries())
+        (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+}
+// SAYURI_CONV=v0 | glds[:wnt[:ns]]   (tuning / A-B switch; default = glds, auto tile)
+struct ConvOverride { bool v0 = false; int wnt = 0, ns = 0; };
+static ConvOverride conv_override() {
+    ConvOverride o;
+    const char* e = getenv("SAYURI_CONV");
+    if (!e) return o;
+    if (!strncmp(e, "v0", 2)) { o.v0 = true; return o; }
+    if (!strncmp(e, "glds", 4)) (void)sscanf(e, "glds:%d:%d", &o.wnt, &o.ns);
+    return o;
+}
+
 // allow > 64 KiB of dynamic LDS on the current device
 template <typename T> static void enable_big_lds() {
     register_all_convs<T>();
@@ -103,6 +160,12 @@ static int pick_wmt(int cout_s, bool fp16) {
 struct HostGeom {
     std::vector<int> bsz, off;  // off has n+1 entries
     int n = 0, total = 0;
+    // bs*bs when every sample has the same board size, else 0
+    int uniform_sq() const {
+        for (int i = 1; i < n; ++i)
+            if (bsz[i] != bsz[0]) return 0;
+        return n > 0 ? bsz[0] * bsz[0] : 0;
+    }
     // worst-case LDS halo positions / subregions of any PT-pixel tile
     void tile_bounds(int PT, int* npos_out, int* nsub_out) const {
         int max_pos = 0, max_sub = 0;
@@ -125,6 +188,33 @@ struct HostGeom {
         *nsub_out = max_sub;
     }
 };
+
+// Choose the tuned LDS-DMA kernel variant for an fp16 3x3 layer with `ko_pad` weight rows on
+// this batch geometry; nullptr when none applies (the generic conv_mfma kernel is used then).
+static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_out) {
+    if (ko_pad % 128 != 0) return nullptr;
+    static const ConvOverride ov = conv_override();
+    if (ov.v0) return nullptr;
+    const int wmt = ko_pad % 256 == 0 ? 8 : 4;
+    const int kot_tiles = ko_pad / (wmt * 32);
+    const GldsEntry* best = nullptr;
+    double best_cost = 1e30;
+    for (const auto& e : glds_entries()) {
+        if (e.wmt != wmt) continue;
+        if (ov.wnt && e.wnt != ov.wnt) continue;
+        if (ov.ns && e.ns != ov.ns) continue;
+        if (!ov.ns && e.ns != 1 && e.ns != 4) continue;
+        const int PT = 64 * e.wnt;
+        int npos, nsub;
+        geom.tile_bounds(PT, &npos, &nsub);
+        if (npos > e.npos_cap || nsub > kMaxSub || e.lds > kMaxLds) continue;
+        const int ntiles = (geom.total + PT - 1) / PT;
+        const double waves = std::ceil((double)ntiles * kot_tiles / kNumCU);
+        const double cost = waves * (PT + 24) * (e.ns == 1 ? 0.9 : 1.0);  // row-grouped variant preferred
+        if (cost < best_cost) { best_cost = cost; best = &e; *ntiles_out = ntiles; }
+    }
+    return best;
+}
 
 struct Stat {
     int launches = 0;
@@ -180,6 +270,7 @@ public:
         HIP_OK(hipEventCreate(&ev0_));
         HIP_OK(hipEventCreate(&ev1_));
         enable_big_lds<T>();
+        if (sizeof(T) == 2) enable_big_lds_glds();
         return describe_layers();
     }
 
@@ -224,6 +315,7 @@ public:
         }
         geom_.total = geom_.off[n];
         tile_cache_.clear();
+        glds_cache_.clear();
         HIP_OK(hipMemcpyAsync(d_off_, geom_.off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, stream_));
         HIP_OK(hipMemcpyAsync(d_bsz_, geom_.bsz.data(), sizeof(int) * n, hipMemcpyHostToDevice, stream_));
         HIP_OK(hipMemcpyAsync(d_planes_, planes, sizeof(float) * (size_t)n * desc_.input_channels * board_ * board_,
@@ -476,6 +568,7 @@ private:
         const size_t B2 = (size_t)board_ * board_;
         if (dev_alloc(&d_planes_, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
         if (dev_alloc(&d_off_, max_batch_ + 1) || dev_alloc(&d_bsz_, max_batch_)) return -1;
+        if (dev_alloc(&d_zeros_, 64)) return -1;
         if (dev_alloc(&d_gate_, (size_t)max_batch_ * 2 * desc_.residual_channels)) return -1;
         if (dev_alloc(&d_prob_, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
         if (dev_alloc(&d_pass_, (size_t)max_batch_ * desc_.pass_probability_outputs)) return -1;
@@ -569,7 +662,36 @@ private:
         return 0;
     }
 
+    struct GldsChoice { const GldsEntry* e; int ntiles; };
+    const GldsChoice* choose_glds(const ConvLayerDev& L) {
+        if (sizeof(T) != 2 || L.k != 3 || L.ko_pad % 128 != 0) return nullptr;
+        const int key = L.ko_pad % 256 == 0 ? 8 : 4;
+        auto it = glds_cache_.find(key);
+        if (it == glds_cache_.end()) {
+            GldsChoice c{nullptr, 0};
+            c.e = pick_glds(geom_, L.ko_pad, &c.ntiles);
+            it = glds_cache_.emplace(key, c).first;
+        }
+        return it->second.e ? &it->second : nullptr;
+    }
+
     int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
+        if (const GldsChoice* gc = choose_glds(L)) {
+            GldsParams gp;
+            ConvParams& p = gp.c;
+            p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
+            p.g = dgeom();
+            p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
+            p.taps = 9; p.act = act; p.npos = geom_.uniform_sq(); p.num_pix_tiles = gc->ntiles;
+            gp.zeros = d_zeros_;
+            const double px = geom_.total;
+            const double flops = 2.0 * px * L.cin * L.cout * 9;
+            const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
+            const auto fn = gc->e->fn;
+            const size_t lds = gc->e->lds;
+            const int grid = gc->ntiles * (L.ko_pad / (gc->e->wmt * 32));
+            return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, gp); });
+        }
         const int kot = L.wmt * 32, kot_tiles = L.ko_pad / kot;
         TileChoice tc;
         if (choose_tile(L.wmt, kot_tiles, &tc)) return -1;
@@ -749,7 +871,9 @@ private:
     float *d_planes_ = nullptr, *d_gate_ = nullptr, *d_prob_ = nullptr, *d_pass_ = nullptr, *d_misc_ = nullptr,
           *d_own_ = nullptr;
     int *d_off_ = nullptr, *d_bsz_ = nullptr;
+    float* d_zeros_ = nullptr;
     HostGeom geom_;
+    std::map<int, GldsChoice> glds_cache_;
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;
     // light per-launch timing of one kernel class inside time_runs()
@@ -965,16 +1089,36 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         float* db = (float*)dalloc(b.size() * 4);
         HIP_OK(hipMemcpy(dw, img.data(), img.size() * sizeof(T), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        int g_ntiles = 0;
+        const GldsEntry* ge = nullptr;
+        if (sizeof(T) == 2 && k == 3) {
+            enable_big_lds_glds();
+            ge = pick_glds(hg, ko_pad, &g_ntiles);
+        }
+        if (ge) {
+            float* dz = (float*)dalloc(256);
+            GldsParams gp;
+            ConvParams& p = gp.c;
+            p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
+            p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = hg.uniform_sq();
+            p.num_pix_tiles = g_ntiles;
+            gp.zeros = dz;
+            hipLaunchKernelGGL(ge->fn, dim3(g_ntiles * (ko_pad / (ge->wmt * 32))), dim3(512), ge->lds, 0, gp);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipDeviceSynchronize());
+        }
         const typename ConvKernelTable<T>::Entry* best = nullptr;
         int best_npos = 0;
         for (const auto& e : ConvKernelTable<T>::entries()) {
+            if (ge) break;
             if (e.wmt != wmt) continue;
             int npos, nsub;
             hg.tile_bounds(64 * e.wnt, &npos, &nsub);
             if (npos > e.npos_cap || nsub > kMaxSub || e.lds(npos) > kMaxLds) continue;
             if (!best || e.wnt > best->wnt) { best = &e; best_npos = npos; }
         }
-        if (!best) { cleanup(); return fail("test_conv: no tile configuration fits"); }
+        if (!best && !ge) { cleanup(); return fail("test_conv: no tile configuration fits"); }
+        if (best) {
         ConvParams p;
         p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
         p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = taps; p.act = act;
@@ -982,6 +1126,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         const int PT = 64 * best->wnt;
         p.num_pix_tiles = (hg.total + PT - 1) / PT;
         hipLaunchKernelGGL(best->fn, dim3(p.num_pix_tiles * (ko_pad / kot)), dim3(512), best->lds(best_npos), 0, p);
+        }
     }
     HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
