@@ -78,57 +78,51 @@ template <> void register_all_convs<float>() {
 
 // tuned fp16 3x3 kernels (conv_glds.h)
 struct GldsEntry {
-    int wmt, wnt, ns;
+    int wmt, wnt;
     void (*fn)(const GldsParams);
+    void (*setup)(BatchGeom, int*, int2*);
     size_t lds;
-    int npos_cap;
+    int npos_cap, npos, pt;
 };
 static std::vector<GldsEntry>& glds_entries() {
     static std::vector<GldsEntry> e;
     return e;
 }
-template <int WMT, int WNT, int NS> static void register_glds() {
-    typedef GldsCfg<WMT, WNT, NS> Cfg;
-    glds_entries().push_back({WMT, WNT, NS, &conv_glds_kernel<WMT, WNT, NS>, Cfg::lds_bytes(), Cfg::NPOS_CAP});
-}
-template <int WMT, int WNT> static void register_glds3() {
-    typedef Glds3Cfg<WMT, WNT> Cfg;
-    glds_entries().push_back({WMT, WNT, 1, &conv_glds3_kernel<WMT, WNT>, Cfg::lds_bytes(), Cfg::NPOS_CAP});
+template <int WMT, int WNT> static void register_glds() {
+    typedef GldsCfg<WMT, WNT> Cfg;
+    glds_entries().push_back({WMT, WNT, &conv_glds_kernel<WMT, WNT>, &tile_setup_kernel<Cfg::PT, Cfg::NPOS>,
+                              Cfg::lds_bytes(), Cfg::NPOS_CAP, Cfg::NPOS, Cfg::PT});
 }
 static void register_all_glds() {
     if (!glds_entries().empty()) return;
-    register_glds3<8, 3>(); register_glds3<8, 2>(); register_glds3<4, 3>(); register_glds3<4, 2>();
+    register_glds<8, 3>(); register_glds<8, 2>(); register_glds<8, 1>();
+    register_glds<4, 3>(); register_glds<4, 2>(); register_glds<4, 1>();
     if (const char* abl = getenv("SAYURI_ABL")) {  // timing-only ablations of the <8,3> kernel
-        const int m = atoi(abl);
         GldsEntry& e = glds_entries()[0];
-        switch (m) {
-        case 1: e.fn = &conv_glds3_kernel<8, 3, 1>; break;
-        case 2: e.fn = &conv_glds3_kernel<8, 3, 2>; break;
-        case 3: e.fn = &conv_glds3_kernel<8, 3, 3>; break;
-        case 4: e.fn = &conv_glds3_kernel<8, 3, 4>; break;
-        case 7: e.fn = &conv_glds3_kernel<8, 3, 7>; break;
-        case 8: e.fn = &conv_glds3_kernel<8, 3, 8>; break;
-        case 15: e.fn = &conv_glds3_kernel<8, 3, 15>; break;
+        switch (atoi(abl)) {
+        case 1: e.fn = &conv_glds_kernel<8, 3, 1>; break;
+        case 2: e.fn = &conv_glds_kernel<8, 3, 2>; break;
+        case 3: e.fn = &conv_glds_kernel<8, 3, 3>; break;
+        case 8: e.fn = &conv_glds_kernel<8, 3, 8>; break;
+        case 11: e.fn = &conv_glds_kernel<8, 3, 11>; break;
+        case 16: e.fn = &conv_glds_kernel<8, 3, 16>; break;
         default: break;
         }
     }
-    register_glds<8, 4, 4>(); register_glds<8, 3, 4>(); register_glds<8, 4, 3>(); register_glds<8, 3, 3>();
-    register_glds<8, 2, 4>();
-    register_glds<4, 4, 4>(); register_glds<4, 3, 4>(); register_glds<4, 2, 4>();
 }
 static void enable_big_lds_glds() {
     register_all_glds();
     for (const auto& e : glds_entries())
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
 }
-// SAYURI_CONV=v0 | glds[:wnt[:ns]]   (tuning / A-B switch; default = glds, auto tile)
-struct ConvOverride { bool v0 = false; int wnt = 0, ns = 0; };
+// SAYURI_CONV=v0 | glds[:wnt]   (tuning / A-B switch; default = glds, auto tile)
+struct ConvOverride { bool v0 = false; int wnt = 0; };
 static ConvOverride conv_override() {
     ConvOverride o;
     const char* e = getenv("SAYURI_CONV");
     if (!e) return o;
     if (!strncmp(e, "v0", 2)) { o.v0 = true; return o; }
-    if (!strncmp(e, "glds", 4)) (void)sscanf(e, "glds:%d:%d", &o.wnt, &o.ns);
+    if (!strncmp(e, "glds", 4)) (void)sscanf(e, "glds:%d", &o.wnt);
     return o;
 }
 
@@ -202,15 +196,13 @@ static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_
     for (const auto& e : glds_entries()) {
         if (e.wmt != wmt) continue;
         if (ov.wnt && e.wnt != ov.wnt) continue;
-        if (ov.ns && e.ns != ov.ns) continue;
-        if (!ov.ns && e.ns != 1 && e.ns != 4) continue;
         const int PT = 64 * e.wnt;
         int npos, nsub;
         geom.tile_bounds(PT, &npos, &nsub);
         if (npos > e.npos_cap || nsub > kMaxSub || e.lds > kMaxLds) continue;
         const int ntiles = (geom.total + PT - 1) / PT;
         const double waves = std::ceil((double)ntiles * kot_tiles / kNumCU);
-        const double cost = waves * (PT + 24) * (e.ns == 1 ? 0.9 : 1.0);  // row-grouped variant preferred
+        const double cost = waves * (PT + 24);
         if (cost < best_cost) { best_cost = cost; best = &e; *ntiles_out = ntiles; }
     }
     return best;
@@ -316,6 +308,7 @@ public:
         geom_.total = geom_.off[n];
         tile_cache_.clear();
         glds_cache_.clear();
+        for (auto& kv : tabs_) kv.second.fresh = false;
         HIP_OK(hipMemcpyAsync(d_off_, geom_.off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, stream_));
         HIP_OK(hipMemcpyAsync(d_bsz_, geom_.bsz.data(), sizeof(int) * n, hipMemcpyHostToDevice, stream_));
         HIP_OK(hipMemcpyAsync(d_planes_, planes, sizeof(float) * (size_t)n * desc_.input_channels * board_ * board_,
@@ -395,6 +388,20 @@ public:
         const int rc = forward();
         profiling_ = false;
         if (rc) return -1;
+        if (d_dbg_) {  // SAYURI_ABL=16: print the s_memtime timeline of the last tower conv
+            std::vector<unsigned long long> h(2 * 8 * 32 * 4);
+            HIP_OK(hipMemcpy(h.data(), d_dbg_, h.size() * 8, hipMemcpyDeviceToHost));
+            for (int wg = 0; wg < 2; ++wg)
+                for (int w = 0; w < 8; w += 4) {
+                    const unsigned long long* d = &h[((size_t)wg * 8 + w) * 32 * 4];
+                    const unsigned long long base = d[31 * 4 + 0];
+                    fprintf(stderr, "[timeline wg%d wave%d] loop_end=%llu epi_end=%llu\n", wg, w, d[31 * 4 + 1] - base,
+                            d[31 * 4 + 2] - base);
+                    for (int G = 0; G < 24; ++G)
+                        fprintf(stderr, "  G%02d start=%7llu vmwait=%5llu barrier=%5llu body=%5llu\n", G, d[G * 4] - base,
+                                d[G * 4 + 1] - d[G * 4], d[G * 4 + 2] - d[G * 4 + 1], d[G * 4 + 3] - d[G * 4 + 2]);
+                }
+        }
         int i = 0;
         for (auto& kv : stats_) {
             if (i >= cap) break;
@@ -569,7 +576,8 @@ private:
         if (dev_alloc(&d_planes_, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
         if (dev_alloc(&d_off_, max_batch_ + 1) || dev_alloc(&d_bsz_, max_batch_)) return -1;
         if (dev_alloc(&d_zeros_, 64)) return -1;
-        if (dev_alloc(&d_gate_, (size_t)max_batch_ * 2 * desc_.residual_channels)) return -1;
+        if (dev_alloc(&d_gate_, (size_t)max_batch_ * 2 * round_up(desc_.residual_channels, 32))) return -1;
+        if (dev_alloc(&d_separt_, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
         if (dev_alloc(&d_prob_, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
         if (dev_alloc(&d_pass_, (size_t)max_batch_ * desc_.pass_probability_outputs)) return -1;
         if (dev_alloc(&d_misc_, (size_t)max_batch_ * desc_.value_misc_outputs)) return -1;
@@ -663,6 +671,23 @@ private:
     }
 
     struct GldsChoice { const GldsEntry* e; int ntiles; };
+    struct TileTabs { int* src = nullptr; int2* pix = nullptr; bool fresh = false; };
+    // index tables of the current batch geometry for pixel-tile size 64*wnt (built on first use)
+    int tile_tabs(const GldsEntry& e, const TileTabs** out) {
+        TileTabs& t = tabs_[e.wnt];
+        if (!t.src) {
+            const size_t max_tiles = ((size_t)max_batch_ * slot_pix_ + e.pt - 1) / e.pt;
+            if (dev_alloc(&t.src, max_tiles * e.npos) || dev_alloc(&t.pix, max_tiles * e.pt)) return -1;
+        }
+        if (!t.fresh) {
+            const int ntiles = (geom_.total + e.pt - 1) / e.pt;
+            hipLaunchKernelGGL(e.setup, dim3(ntiles), dim3(256), 0, stream_, dgeom(), t.src, t.pix);
+            HIP_OK(hipGetLastError());
+            t.fresh = true;
+        }
+        *out = &t;
+        return 0;
+    }
     const GldsChoice* choose_glds(const ConvLayerDev& L) {
         if (sizeof(T) != 2 || L.k != 3 || L.ko_pad % 128 != 0) return nullptr;
         const int key = L.ko_pad % 256 == 0 ? 8 : 4;
@@ -677,12 +702,21 @@ private:
 
     int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
         if (const GldsChoice* gc = choose_glds(L)) {
+            const TileTabs* tabs = nullptr;
+            if (tile_tabs(*gc->e, &tabs)) return -1;
             GldsParams gp;
+            gp.tab_src = tabs->src;
+            gp.tab_pix = tabs->pix;
+            gp.dbg = nullptr;
+            if (getenv("SAYURI_ABL") && atoi(getenv("SAYURI_ABL")) == 16 && !strcmp(name, "conv3x3_tower")) {
+                if (!d_dbg_ && dev_alloc(&d_dbg_, 2 * 8 * 32 * 4)) return -1;
+                gp.dbg = d_dbg_;
+            }
             ConvParams& p = gp.c;
             p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
             p.g = dgeom();
             p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
-            p.taps = 9; p.act = act; p.npos = geom_.uniform_sq(); p.num_pix_tiles = gc->ntiles;
+            p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = gc->ntiles;
             gp.zeros = d_zeros_;
             const double px = geom_.total;
             const double flops = 2.0 * px * L.cin * L.cout * 9;
@@ -723,18 +757,25 @@ private:
 
     int se_unit(const FcLayerDev& sq, const FcLayerDev& ex, T* x, const T* res, int C, int cs, int act) {
         const BatchGeom g = dgeom();
-        const size_t smem = sizeof(float) * (3 * C + sq.out + 512);
         const double px = geom_.total;
-        if (timed("se_gate", 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out), sizeof(T) * px * C, [&] {
-                hipLaunchKernelGGL(se_gate_kernel<T>, dim3(geom_.n), dim3(256), smem, stream_, (const T*)x, d_gate_, g, C,
-                                   cs, sq.dev(), ex.dev(), act);
+        constexpr int EPP = ElemTraits<T>::kPieceElems;
+        if (cs / EPP > 256) return fail("SE unit: more than 256*8 channels is not supported");
+        if (timed("se_pool", 2.0 * px * C, sizeof(T) * px * C, [&] {
+                hipLaunchKernelGGL(se_pool_kernel<T>, dim3(geom_.n * kSeSplit), dim3(256), 0, stream_, (const T*)x,
+                                   d_separt_, g, cs);
             }))
             return -1;
-        const int EPP = ElemTraits<T>::kPieceElems;
-        const size_t total = (size_t)geom_.total * (cs / EPP);
-        const int grid = (int)((total + 255) / 256);
+        const size_t smem = sizeof(float) * (3 * C + sq.out + 256);
+        if (timed("se_fc", 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out),
+                  4.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out), [&] {
+                      hipLaunchKernelGGL(se_fc_kernel, dim3(geom_.n), dim3(256), smem, stream_,
+                                         (const float*)d_separt_, d_gate_, g, C, cs, sq.dev(), ex.dev(), act);
+                  }))
+            return -1;
+        const int ppr = cs / EPP;
+        const dim3 grid((slot_pix_ * ppr + 256 * kScaleUnroll - 1) / (256 * kScaleUnroll), geom_.n);
         return timed("se_scale", 3.0 * px * C, sizeof(T) * px * C * 3, [&] {
-            hipLaunchKernelGGL(se_scale_kernel<T>, dim3(grid), dim3(256), 0, stream_, (const T*)x, res, x,
+            hipLaunchKernelGGL(se_scale_kernel<T>, grid, dim3(256), 0, stream_, (const T*)x, res, x,
                                (const float*)d_gate_, g, C, cs, act);
         });
     }
@@ -762,7 +803,7 @@ private:
         {
             const ConvLayerDev& L = cv(SAYURI_L_INPUT_CONV);
             const int in = take();
-            const int grid = (geom_.total + 255) / 256;
+            const int grid = (int)(((size_t)geom_.total * (L.cin_s / ElemTraits<T>::kPieceElems) + 255) / 256);
             const double px = geom_.total;
             T* dst = bufs_[in];
             const int cin = d.input_channels, cs = L.cin_s, board = board_;
@@ -868,12 +909,14 @@ private:
     size_t dev_bytes_ = 0;
     T* bufs_[kNumBufs] = {};
     bool busy_[kNumBufs] = {};
-    float *d_planes_ = nullptr, *d_gate_ = nullptr, *d_prob_ = nullptr, *d_pass_ = nullptr, *d_misc_ = nullptr,
+    float *d_planes_ = nullptr, *d_gate_ = nullptr, *d_separt_ = nullptr, *d_prob_ = nullptr, *d_pass_ = nullptr, *d_misc_ = nullptr,
           *d_own_ = nullptr;
     int *d_off_ = nullptr, *d_bsz_ = nullptr;
     float* d_zeros_ = nullptr;
+    unsigned long long* d_dbg_ = nullptr;
     HostGeom geom_;
     std::map<int, GldsChoice> glds_cache_;
+    std::map<int, TileTabs> tabs_;
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;
     // light per-launch timing of one kernel class inside time_runs()
@@ -1097,10 +1140,17 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         }
         if (ge) {
             float* dz = (float*)dalloc(256);
+            int* tsrc = (int*)dalloc(sizeof(int) * (size_t)g_ntiles * ge->npos);
+            int2* tpix = (int2*)dalloc(sizeof(int2) * (size_t)g_ntiles * ge->pt);
+            if (!dz || !tsrc || !tpix) { cleanup(); return fail("test_conv: hipMalloc failed"); }
+            hipLaunchKernelGGL(ge->setup, dim3(g_ntiles), dim3(256), 0, 0, g, tsrc, tpix);
             GldsParams gp;
+            gp.tab_src = tsrc;
+            gp.tab_pix = tpix;
+            gp.dbg = nullptr;
             ConvParams& p = gp.c;
             p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
-            p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = hg.uniform_sq();
+            p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;
             p.num_pix_tiles = g_ntiles;
             gp.zeros = dz;
             hipLaunchKernelGGL(ge->fn, dim3(g_ntiles * (ko_pad / (ge->wmt * 32))), dim3(512), ge->lds, 0, gp);

@@ -1,6 +1,6 @@
 // The non-GEMM kernels of the forward pipe (all HBM/latency-bound, fp32 math):
 //   pack_input_kernel  planes [n][C][B*B] (NN grid, fp32) -> compact NHWC activations
-//   se_gate_kernel     global pooling + squeeze FC + excite FC of one SE unit, one WG per sample
+//   se_pool / se_fc    global pooling, then squeeze FC + excite FC of one SE unit
 //                      (reference se_unit.cc:9-128 / cuda_kernels.cu:241-321 + two cuBLAS gemms)
 //   se_scale_kernel    act(sigmoid(gamma)*x + beta + residual)   (cuda_kernels.cu:391-440)
 //   depthwise_kernel   k x k depthwise conv, bias, act, optional post-activation residual
@@ -16,10 +16,13 @@
 namespace sayuri {
 
 template <typename T>
-__global__ void pack_input_kernel(const float* __restrict__ planes, T* __restrict__ out, BatchGeom g,
-                                  int cin, int cs, int board) {
-    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= g.total_pix) return;
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ planes, T* __restrict__ out,
+                                                         BatchGeom g, int cin, int cs, int board) {
+    constexpr int EPP = ElemTraits<T>::kPieceElems;
+    const int ppr = cs / EPP;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, 16-byte piece)
+    if (idx >= (size_t)g.total_pix * ppr) return;
+    const int gi = (int)(idx / ppr), piece = (int)(idx - (size_t)gi * ppr);
     int lo = 0, hi = g.n_samples;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -27,9 +30,15 @@ __global__ void pack_input_kernel(const float* __restrict__ planes, T* __restric
     }
     const int n = lo, bs = g.bsz[n], pp = gi - g.sample_off[n];
     const int y = pp / bs, x = pp - y * bs;
-    const float* src = planes + (size_t)n * cin * board * board + y * board + x;
-    T* dst = out + ((size_t)n * g.slot_pix + pp) * cs;
-    for (int c = 0; c < cs; ++c) dst[c] = from_float<T>(c < cin ? src[(size_t)c * board * board] : 0.f);
+    const size_t B2 = (size_t)board * board;
+    const float* src = planes + (size_t)n * cin * B2 + y * board + x;
+    T v[EPP];
+#pragma unroll
+    for (int e = 0; e < EPP; ++e) {
+        const int c = piece * EPP + e;
+        v[e] = from_float<T>(c < cin ? src[(size_t)c * B2] : 0.f);
+    }
+    *(uint4*)(out + ((size_t)n * g.slot_pix + pp) * cs + piece * EPP) = *(uint4*)v;
 }
 
 struct FcDev {
@@ -39,11 +48,22 @@ struct FcDev {
 };
 
 // y[o] = act(b[o] + sum_i x[i] * wt[i][o]); x and y in LDS; all threads of the block cooperate.
+// The i-loop is unrolled so that 8 independent weight loads are in flight per thread: these
+// launches run one workgroup per CU and are bound by L2 latency, not bandwidth.
 __device__ __forceinline__ void block_fc(const FcDev fc, const float* x, float* y, int act, int tid, int nt) {
     for (int o = tid; o < fc.out; o += nt) {
-        float s = 0.f;
-        for (int i = 0; i < fc.in; ++i) s += x[i] * fc.wt[(size_t)i * fc.out + o];
-        y[o] = activate(fc.b[o] + s, act);
+        float s0 = 0.f, s1 = 0.f;
+        const float* w = fc.wt + o;
+        int i = 0;
+        for (; i + 8 <= fc.in; i += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(i + u) * fc.out];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { s0 += x[i + u] * wv[u]; s1 += x[i + u + 1] * wv[u + 1]; }
+        }
+        for (; i < fc.in; ++i) s0 += x[i] * w[(size_t)i * fc.out];
+        y[o] = activate(fc.b[o] + (s0 + s1), act);
     }
 }
 
@@ -60,6 +80,7 @@ __device__ __forceinline__ void block_pool(const T* __restrict__ x, int npix, in
         const int c = c0 + cl;
         float sum = 0.f, mx = -5000.f;
         if (part < parts && c < cs) {
+#pragma unroll 8
             for (int p = part; p < npix; p += parts) {
                 const float v = to_float(x[(size_t)p * cs + c]);
                 sum += v;
@@ -84,61 +105,166 @@ __device__ __forceinline__ void block_pool(const T* __restrict__ x, int npix, in
     }
 }
 
-// One SE unit's gate: pooling + squeeze + excite.  gate[n][0..C) = sigmoid(gamma), [C..2C) = beta.
+// ---- SE unit, three bandwidth-shaped launches -------------------------------------------------
+// se_pool_kernel : grid (n, SPLIT): each workgroup sums / maxes a slice of the sample's pixels with
+//                  16-byte loads and writes per-channel partials  part[n][split][2][cs]
+// se_fc_kernel   : grid n: folds the partials into (mean, scaled mean, max), squeeze FC, excite FC
+//                  -> gate[n][0..C) = sigmoid(gamma), gate[n][C..2C) = beta
+// se_scale_kernel: out = act(gamma * x + beta + residual), 16-byte loads/stores, no index search
+constexpr int kSeSplit = 4;
+
 template <typename T>
-__global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ x, float* __restrict__ gate,
-                                                      BatchGeom g, int C, int cs, FcDev squeeze, FcDev excite,
-                                                      int act) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* pool = (float*)smem;           // [3C]
-    float* mid = pool + 3 * C;            // [se_size]
-    float* scratch = mid + squeeze.out;   // [2*256]
-    const int n = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int bs = g.bsz[n];
-    block_pool<T>(x + (size_t)n * g.slot_pix * cs, bs * bs, C, cs, bs, false, pool, scratch, tid, nt);
-    block_fc(squeeze, pool, mid, act, tid, nt);
+__global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, float* __restrict__ part, BatchGeom g,
+                                                      int cs) {
+    constexpr int EPP = ElemTraits<T>::kPieceElems;
+    __shared__ float red[2][256 * 8 / 8 * 8];  // [sum|max][thread][EPP<=8]
+    const int n = blockIdx.x / kSeSplit, sp = blockIdx.x % kSeSplit;
+    const int tid = threadIdx.x;
+    const int bs = g.bsz[n], npix = bs * bs;
+    const int ppr = cs / EPP;                 // 16-byte pieces per pixel row
+    const int prows = 256 / ppr;              // pixel rows handled concurrently (>=1 when cs <= 256*EPP)
+    const int piece = tid % ppr, prow = tid / ppr;
+    const int per = (npix + kSeSplit - 1) / kSeSplit;
+    const int p0 = sp * per, p1 = min(npix, p0 + per);
+    float sum[EPP], mx[EPP];
+#pragma unroll
+    for (int e = 0; e < EPP; ++e) { sum[e] = 0.f; mx[e] = -5000.f; }
+    if (prow < prows) {
+        const T* xs = x + (size_t)n * g.slot_pix * cs + piece * EPP;
+#pragma unroll 4
+        for (int p = p0 + prow; p < p1; p += prows) {
+            T v[EPP];
+            *(uint4*)v = *(const uint4*)(xs + (size_t)p * cs);
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) {
+                const float f = to_float(v[e]);
+                sum[e] += f;
+                mx[e] = fmaxf(mx[e], f);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPP; ++e) { red[0][tid * EPP + e] = sum[e]; red[1][tid * EPP + e] = mx[e]; }
     __syncthreads();
-    for (int o = tid; o < excite.out; o += nt) {
-        float s = 0.f;
-        for (int i = 0; i < excite.in; ++i) s += mid[i] * excite.wt[(size_t)i * excite.out + o];
-        s += excite.b[o];
-        gate[(size_t)n * 2 * C + o] = o < C ? 1.0f / (1.0f + fast_exp(-s)) : s;
+    if (prow == 0 && piece < ppr) {
+        for (int q = 1; q < prows; ++q) {
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) {
+                sum[e] += red[0][(q * ppr + piece) * EPP + e];
+                mx[e] = fmaxf(mx[e], red[1][(q * ppr + piece) * EPP + e]);
+            }
+        }
+        float* dst = part + ((size_t)(n * kSeSplit + sp) * 2) * cs + piece * EPP;
+#pragma unroll
+        for (int e = 0; e < EPP; ++e) { dst[e] = sum[e]; dst[cs + e] = mx[e]; }
     }
 }
 
-// out = act(gate_gamma[n][c] * x + beta[n][c] + res), 8 channels (fp16) / 4 (fp32) per thread.
-template <typename T>
-__global__ void se_scale_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ out,
-                                const float* __restrict__ gate, BatchGeom g, int C, int cs, int act) {
-    constexpr int EPP = ElemTraits<T>::kPieceElems;
-    const int ppp = cs / EPP;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)g.total_pix * ppp;
-    if (idx >= total) return;
-    const int gi = (int)(idx / ppp), piece = (int)(idx - (size_t)gi * ppp);
-    int lo = 0, hi = g.n_samples;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (g.sample_off[mid] <= gi) lo = mid; else hi = mid;
-    }
-    const int n = lo, pp = gi - g.sample_off[n];
-    const size_t o = ((size_t)n * g.slot_pix + pp) * cs + piece * EPP;
-    const float* gm = gate + (size_t)n * 2 * C;
-    T vx[EPP], vr[EPP], vo[EPP];
-    *(uint4*)vx = *(const uint4*)(x + o);
-    if (res) *(uint4*)vr = *(const uint4*)(res + o);
-#pragma unroll
-    for (int e = 0; e < EPP; ++e) {
-        const int c = piece * EPP + e;
-        float v = 0.f;
-        if (c < C) {
-            v = gm[c] * to_float(vx[e]) + gm[C + c];
-            if (res) v += to_float(vr[e]);
-            v = activate(v, act);
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ part, float* __restrict__ gate,
+                                                    BatchGeom g, int C, int cs, FcDev squeeze, FcDev excite, int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* pool = (float*)smem;          // [3C]
+    float* mid = pool + 3 * C;           // [se_size]
+    float* scratch = mid + squeeze.out;  // [256]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int bs = g.bsz[n];
+    const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f, m = -5000.f;
+        for (int sp = 0; sp < kSeSplit; ++sp) {
+            const float* src = part + ((size_t)(n * kSeSplit + sp) * 2) * cs;
+            s += src[c];
+            m = fmaxf(m, src[cs + c]);
         }
-        vo[e] = from_float<T>(v);
+        const float mean = s / npix;
+        pool[c] = mean;
+        pool[C + c] = mean * (bd / 10.f);
+        pool[2 * C + c] = m;
     }
-    *(uint4*)(out + o) = *(uint4*)vo;
+    __syncthreads();
+    // squeeze: 256 threads = (out/4 column quads) x (row groups); each thread streams 16-byte weight
+    // loads (unrolled: 8 in flight), partial sums are folded through LDS
+    const int so = squeeze.out;
+    if ((so & 3) == 0 && so <= 256) {
+        const int quads = so / 4, groups = 256 / quads;
+        const int oq = tid % quads, grp = tid / quads;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        if (grp < groups) {
+            const float* w = squeeze.wt + oq * 4;
+#pragma unroll 8
+            for (int i = grp; i < squeeze.in; i += groups) s4 += pool[i] * *(const f32x4*)(w + (size_t)i * so);
+        }
+        __syncthreads();  // pool no longer needed below this point except via s4
+        float* red = scratch;  // [groups][so] would exceed 256 floats: fold in rounds of 256 floats
+        for (int g0 = 0; g0 < groups; g0 += 256 / so) {
+            if (grp >= g0 && grp < g0 + 256 / so) *(f32x4*)(red + (grp - g0) * so + oq * 4) = s4;
+            __syncthreads();
+            if (tid < so) {
+                float a = g0 == 0 ? squeeze.b[tid] : mid[tid];
+                for (int q = 0; q < 256 / so && g0 + q < groups; ++q) a += red[q * so + tid];
+                mid[tid] = a;
+            }
+            __syncthreads();
+        }
+        if (tid < so) mid[tid] = activate(mid[tid], act);
+    } else {
+        block_fc(squeeze, pool, mid, act, tid, 256);
+    }
+    __syncthreads();
+    for (int o = tid; o < excite.out; o += 256) {
+        float s = excite.b[o];
+        const float* w = excite.wt + o;
+#pragma unroll 16
+        for (int i = 0; i < excite.in; ++i) s += mid[i] * w[(size_t)i * excite.out];
+        // gate[n][0][c] = sigmoid(gamma_c), gate[n][1][c] = beta_c; channel stride cs, pads stay 0
+        gate[(size_t)n * 2 * cs + (o < C ? o : cs + (o - C))] = o < C ? 1.0f / (1.0f + fast_exp(-s)) : s;
+    }
+}
+
+// out = act(gate_gamma[n][c] * x + beta[n][c] + res).  grid (ceil(slot_pix*ppr / (256*4)), n);
+// each thread owns 4 16-byte pieces (all loads issued before the math).
+constexpr int kScaleUnroll = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                       T* __restrict__ out, const float* __restrict__ gate,
+                                                       BatchGeom g, int C, int cs, int act) {
+    constexpr int EPP = ElemTraits<T>::kPieceElems;
+    const int n = blockIdx.y;
+    const int bs = g.bsz[n], npix = bs * bs;
+    const int ppr = cs / EPP, total = npix * ppr;
+    const size_t base = (size_t)n * g.slot_pix * cs;
+    const float* gm = gate + (size_t)n * 2 * cs;  // [2][cs], pad channels hold 0
+    uint4 vx[kScaleUnroll], vr[kScaleUnroll];
+    int idx[kScaleUnroll];
+#pragma unroll
+    for (int u = 0; u < kScaleUnroll; ++u) {
+        idx[u] = (blockIdx.x * kScaleUnroll + u) * 256 + threadIdx.x;
+        if (idx[u] < total) {
+            vx[u] = *(const uint4*)(x + base + (size_t)idx[u] * EPP);
+            if (res) vr[u] = *(const uint4*)(res + base + (size_t)idx[u] * EPP);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kScaleUnroll; ++u) {
+        if (idx[u] >= total) continue;
+        const int c0 = (idx[u] % ppr) * EPP;
+        const T* px = (const T*)&vx[u];
+        const T* pr = (const T*)&vr[u];
+        float ga[EPP], be[EPP];
+#pragma unroll
+        for (int e = 0; e < EPP; e += 4) {
+            *(f32x4*)(ga + e) = *(const f32x4*)(gm + c0 + e);
+            *(f32x4*)(be + e) = *(const f32x4*)(gm + cs + c0 + e);
+        }
+        T vo[EPP];
+#pragma unroll
+        for (int e = 0; e < EPP; ++e) {
+            float v = ga[e] * to_float(px[e]) + be[e];  // pad channels: 0 * 0 + 0
+            if (res) v += to_float(pr[e]);
+            vo[e] = from_float<T>(activate(v, act));
+        }
+        *(uint4*)(out + base + (size_t)idx[u] * EPP) = *(uint4*)vo;
+    }
 }
 
 // Depthwise k x k convolution.  wt = [k*k][cs] fp32 (transposed), bias [cs].
