@@ -176,9 +176,12 @@ def main():
     lib.sayuri_hip_timed_stat(ctx, ctypes.byref(stat))
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # the path's only exchange: one small stats record per rank (RCCL all-gather)
+        from sayuri_amd.shard import gather_stats
+        stats = gather_stats({"games_done": 0, "nn_queries": n * args.steps, "nn_batches": args.steps,
+                              "elapsed": elapsed})
+        elapsed = stats["elapsed_max"]
+        assert stats["nn_queries"] == world * n * args.steps
 
     result = None
     if rank == 0:

@@ -14,6 +14,7 @@
 // as a prebuilt checker / "reference" CPU baseline.
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,12 @@
 #include "neural/loader.h"
 #include "neural/network_basic.h"
 #include "utils/option.h"
+
+#ifdef WITH_HIP_PIPE
+// The product pipe compiled IN the reference tree (-DSAYURI_IN_TREE: reference headers, reference
+// types): the drop-in configuration of INTEGRATION.md, used by tests/test_gpu_dropin.py.
+#include "hip_forward_pipe.h"
+#endif
 
 namespace {
 std::shared_ptr<DNNWeights> g_weights;
@@ -212,5 +219,78 @@ int ref_forward(int board_size, float komi, int side_to_move, int offset, const 
         return -1;
     }
 }
+
+#ifdef WITH_HIP_PIPE
+namespace {
+std::unique_ptr<HipForwardPipe> g_hip;
+}
+
+// Build HipForwardPipe on the weights the REFERENCE loader parsed (ref_init must have run).
+int ref_hip_init(int board, int batch, int fp16, int device) {
+    if (!g_weights) { g_err = "ref_init first"; return -1; }
+    try {
+        HipPipeConfig cfg;
+        cfg.batch_size = batch;
+        cfg.fp16 = fp16 != 0;
+        cfg.default_boardsize = board;
+        if (device >= 0) cfg.gpus = {device};
+        g_hip = std::make_unique<HipForwardPipe>(cfg);
+        g_hip->Initialize(g_weights);
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        g_hip.reset();
+        return -1;
+    }
+}
+
+// n concurrent NetworkForwardPipe::Forward calls (reference InputData / OutputResult) through
+// the MI355X pipe; same packing as ref_forward, stride 2*361+9 per sample.
+int ref_hip_forward(int n, const int* board_sizes, const int* offsets, const float* planes, float* out) {
+    if (!g_hip) { g_err = "ref_hip_init first"; return -1; }
+    try {
+        std::vector<InputData> in(n);
+        std::vector<OutputResult> res(n);
+        const int PL = kInputChannels * kNumIntersections, OL = 2 * kNumIntersections + 9;
+        for (int i = 0; i < n; ++i) {
+            in[i].board_size = board_sizes[i];
+            in[i].komi = 7.5f;
+            in[i].offset = static_cast<PolicyBufferOffset>(offsets[i]);
+            std::memcpy(in[i].planes.data(), planes + static_cast<size_t>(i) * PL, sizeof(float) * PL);
+        }
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(n);
+        for (int i = 0; i < n; ++i)
+            th.emplace_back([&, i] {
+                try {
+                    res[i] = g_hip->Forward(in[i]);
+                } catch (const std::exception& e) {
+                    errs[i] = e.what();
+                }
+            });
+        for (auto& t : th) t.join();
+        for (auto& e : errs)
+            if (!e.empty()) throw std::runtime_error(e);
+        for (int i = 0; i < n; ++i) {
+            float* o = out + static_cast<size_t>(i) * OL;
+            const OutputResult& r = res[i];
+            const int s = board_sizes[i] * board_sizes[i];
+            std::memset(o, 0, sizeof(float) * OL);
+            std::memcpy(o, r.probabilities.data(), sizeof(float) * s);
+            std::memcpy(o + kNumIntersections, r.ownership.data(), sizeof(float) * s);
+            float* t = o + 2 * kNumIntersections;
+            t[0] = r.pass_probability; t[1] = r.wdl[0]; t[2] = r.wdl[1]; t[3] = r.wdl[2];
+            t[4] = r.stm_winrate; t[5] = r.final_score; t[6] = r.q_error; t[7] = r.score_error;
+            t[8] = static_cast<float>(static_cast<int>(r.offset));
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+void ref_hip_destroy() { g_hip.reset(); }
+#endif
 
 } // extern "C"

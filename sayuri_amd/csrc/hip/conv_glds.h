@@ -161,43 +161,58 @@ __global__ __launch_bounds__(256) void tile_setup_kernel(BatchGeom g, int* __res
     }
 }
 
-// Cooperative second half of the epilogue: whole rows out of the fp32 staging tile.  All row ids
-// and residual rows of the phase are fetched up front (independent loads, one exposed latency).
-template <int ACT, int KO_T, int PT>
-__device__ __forceinline__ void glds_store_rows(const GldsParams& gp, const unsigned char* stage, const int* rowid,
-                                                int phase, int kt, int wave, int lane) {
-    constexpr int HALF = PT / 2, RS = KO_T * 4 + 16;
-    constexpr int LPR = KO_T / 4;          // lanes per row (4 channels each)
-    constexpr int RPI = 64 / LPR;          // rows per wave instruction
-    constexpr int NR = HALF / (8 * RPI);   // rows per lane per phase
+// Cooperative second half of the epilogue: whole rows out of the fp32 staging tile.
+// EpiRows holds, per lane, the output row ids and residual rows of one phase; they are fetched for
+// BOTH phases before the first staging pass, so one memory latency covers the whole epilogue.
+template <int KO_T, int PT> struct EpiRows {
+    static constexpr int HALF = PT / 2;
+    static constexpr int LPR = KO_T / 4;         // lanes per row (4 channels each)
+    static constexpr int RPI = 64 / LPR;         // rows per wave instruction
+    static constexpr int NR = HALF / (8 * RPI);  // rows per lane per phase
     static_assert(HALF % (8 * RPI) == 0, "rows must split evenly over the waves");
-    const ConvParams& p = gp.c;
-    f16* __restrict__ gout = (f16*)p.out;
-    const f16* __restrict__ gres = (const f16*)p.res;
-    const int col = (lane % LPR) * 4;
-    const int ko = kt * KO_T + col;
-    const bool ko_ok = ko < p.cout_s;
-    const int r0 = wave * RPI + lane / LPR;
     int grow[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) grow[k] = ko_ok ? rowid[phase * HALF + r0 + k * 8 * RPI] : -1;
     f16x4 rr[NR];
+};
+
+template <int KO_T, int PT>
+__device__ __forceinline__ void epi_fetch(EpiRows<KO_T, PT>& e, const GldsParams& gp, const int* rowid, int phase,
+                                          int kt, int wave, int lane) {
+    using E = EpiRows<KO_T, PT>;
+    const ConvParams& p = gp.c;
+    const f16* __restrict__ gres = (const f16*)p.res;
+    const int ko = kt * KO_T + (lane % E::LPR) * 4;
+    const bool ko_ok = ko < p.cout_s;
+    const int r0 = wave * E::RPI + lane / E::LPR;
+#pragma unroll
+    for (int k = 0; k < E::NR; ++k) e.grow[k] = ko_ok ? rowid[phase * E::HALF + r0 + k * 8 * E::RPI] : -1;
     if (gres) {
 #pragma unroll
-        for (int k = 0; k < NR; ++k)
-            rr[k] = grow[k] >= 0 ? *(const f16x4*)(gres + (size_t)grow[k] * p.cout_s + ko) : f16x4{0, 0, 0, 0};
+        for (int k = 0; k < E::NR; ++k)
+            e.rr[k] = e.grow[k] >= 0 ? *(const f16x4*)(gres + (size_t)e.grow[k] * p.cout_s + ko) : f16x4{0, 0, 0, 0};
     }
+}
+
+template <int ACT, int KO_T, int PT>
+__device__ __forceinline__ void epi_store(const EpiRows<KO_T, PT>& e, const GldsParams& gp, const unsigned char* stage,
+                                          int kt, int wave, int lane) {
+    using E = EpiRows<KO_T, PT>;
+    constexpr int RS = KO_T * 4 + 16;
+    const ConvParams& p = gp.c;
+    f16* __restrict__ gout = (f16*)p.out;
+    const int col = (lane % E::LPR) * 4;
+    const int ko = kt * KO_T + col;
+    const int r0 = wave * E::RPI + lane / E::LPR;
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        f32x4 v = *(const f32x4*)(stage + (r0 + k * 8 * RPI) * RS + col * 4);
-        if (gres) {
+    for (int k = 0; k < E::NR; ++k) {
+        f32x4 v = *(const f32x4*)(stage + (r0 + k * 8 * E::RPI) * RS + col * 4);
+        if (p.res) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += (float)rr[k][q];
+            for (int q = 0; q < 4; ++q) v[q] += (float)e.rr[k][q];
         }
         f16x4 h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) h[q] = (f16)activate(v[q], ACT);
-        if (grow[k] >= 0) *(f16x4*)(gout + (size_t)grow[k] * p.cout_s + ko) = h;
+        if (e.grow[k] >= 0) *(f16x4*)(gout + (size_t)e.grow[k] * p.cout_s + ko) = h;
     }
 }
 
@@ -376,11 +391,24 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
 
     // ---- epilogue: fp32 accumulators (+ bias) -> LDS [pixel][channel], two phases of PT/2
     // pixels (wave columns 0-1, then 2-3), then whole rows: + residual, activation, fp16 store.
+    // Barriers here are raw s_barrier + lgkmcnt(0): a __syncthreads() would also drain vmcnt,
+    // i.e. wait for the previous phase's global stores to be acknowledged.
     constexpr int RS = Cfg::STAGE_RS;
     unsigned char* stage = smem;
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    lds_barrier();  // rowid visible, rings no longer read
+    EpiRows<KO_T, PT> rows0, rows1;
+    epi_fetch(rows0, gp, rowid, 0, kt, wave, lane);
+    epi_fetch(rows1, gp, rowid, 1, kt, wave, lane);
 #pragma unroll
     for (int phase = 0; phase < 2; ++phase) {
-        __syncthreads();  // ring / previous phase no longer read
+        if (phase) lds_barrier();  // staging tile of the previous phase fully read
+        if constexpr (ABL & 16) {
+            if (dbg) dbg[(28 + phase) * 4 + 0] = __builtin_amdgcn_s_memtime();
+        }
         if ((wave_n >> 1) == phase) {
 #pragma unroll
             for (int i = 0; i < WMT; ++i) {
@@ -393,16 +421,23 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        if constexpr (ABL & 16) {
+            if (dbg) dbg[(28 + phase) * 4 + 1] = __builtin_amdgcn_s_memtime();
+        }
+        const EpiRows<KO_T, PT>& rows = phase ? rows1 : rows0;
         switch (p.act) {
-        case kMish: glds_store_rows<kMish, KO_T, PT>(gp, stage, rowid, phase, kt, wave, lane); break;
-        case kIdentity: glds_store_rows<kIdentity, KO_T, PT>(gp, stage, rowid, phase, kt, wave, lane); break;
-        case kReLU: glds_store_rows<kReLU, KO_T, PT>(gp, stage, rowid, phase, kt, wave, lane); break;
-        case kSwish: glds_store_rows<kSwish, KO_T, PT>(gp, stage, rowid, phase, kt, wave, lane); break;
-        case kELU: glds_store_rows<kELU, KO_T, PT>(gp, stage, rowid, phase, kt, wave, lane); break;
-        case kSELU: glds_store_rows<kSELU, KO_T, PT>(gp, stage, rowid, phase, kt, wave, lane); break;
-        case kGELU: glds_store_rows<kGELU, KO_T, PT>(gp, stage, rowid, phase, kt, wave, lane); break;
-        default: glds_store_rows<kHardSwish, KO_T, PT>(gp, stage, rowid, phase, kt, wave, lane); break;
+        case kMish: epi_store<kMish, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        case kIdentity: epi_store<kIdentity, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        case kReLU: epi_store<kReLU, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        case kSwish: epi_store<kSwish, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        case kELU: epi_store<kELU, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        case kSELU: epi_store<kSELU, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        case kGELU: epi_store<kGELU, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        default: epi_store<kHardSwish, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        }
+        if constexpr (ABL & 16) {
+            if (dbg) dbg[(28 + phase) * 4 + 2] = __builtin_amdgcn_s_memtime();
         }
     }
     if constexpr (ABL & 16) {

@@ -397,6 +397,10 @@ public:
                     const unsigned long long base = d[31 * 4 + 0];
                     fprintf(stderr, "[timeline wg%d wave%d] loop_end=%llu epi_end=%llu\n", wg, w, d[31 * 4 + 1] - base,
                             d[31 * 4 + 2] - base);
+                    for (int ph = 0; ph < 2; ++ph)
+                        fprintf(stderr, "  epilogue phase %d: sync0 @%llu  staged+sync1 +%llu  rows done +%llu\n", ph,
+                                d[(28 + ph) * 4] - base, d[(28 + ph) * 4 + 1] - d[(28 + ph) * 4],
+                                d[(28 + ph) * 4 + 2] - d[(28 + ph) * 4 + 1]);
                     for (int G = 0; G < 24; ++G)
                         fprintf(stderr, "  G%02d start=%7llu vmwait=%5llu barrier=%5llu body=%5llu\n", G, d[G * 4] - base,
                                 d[G * 4 + 1] - d[G * 4], d[G * 4 + 2] - d[G * 4 + 1], d[G * 4 + 3] - d[G * 4 + 2]);

@@ -8,10 +8,12 @@
 
 #include "../../../include/sayuri_hip.h"
 
-namespace sayuri_host {
+SAYURI_HOST_BEGIN
 
+#ifndef SAYURI_IN_TREE
 std::string NetworkForwardPipe::GetName() const { return Valid() ? weights_->name : "random"; }
 int NetworkForwardPipe::GetVersion() const { return Valid() ? weights_->version : -1; }
+#endif
 
 namespace {
 
@@ -30,7 +32,7 @@ void LoadFc(sayuri_hip_ctx* ctx, int id, LinearLayer& f) {
         ThrowHip("sayuri_hip_load_tensor");
 }
 
-int BlockTypeCode(const BlockBasic& b) {
+int BlockTypeCode(BlockBasic& b) {  // the reference's Is*Block() are non-const
     if (b.IsResidualBlock()) return SAYURI_BLOCK_RESIDUAL;
     if (b.IsBottleneckBlock()) return SAYURI_BLOCK_BOTTLENECK;
     if (b.IsNestedBottleneckBlock()) return SAYURI_BLOCK_NESTED_BOTTLENECK;
@@ -232,7 +234,7 @@ void HipForwardPipe::StageInput(Graph* g, int slot, const InputData& in, bool al
 // pass[0] for every offset, cuda_forward_pipe.cc:1074, is a known discrepancy) fused with the
 // un-padding of SendQueryAndWait (batch_forward_pipe.cc:48-68).
 void HipForwardPipe::FillOutput(const Graph* g, int slot, const InputData& in, bool unpad, OutputResult* out) const {
-    const DNNWeights& w = *weights_;
+    DNNWeights& w = *weights_;
     const int B = board_size_, B2 = B * B, bs = in.board_size;
     const bool v1 = w.version <= 2;  // Encoder::GetEncoderVersion, encoder.h:64-77
     int offset = v1 ? 0 : static_cast<int>(in.offset);
@@ -367,4 +369,4 @@ std::vector<OutputResult> HipForwardPipe::BatchForward(int gpu, const std::vecto
     return outs;
 }
 
-}  // namespace sayuri_host
+SAYURI_HOST_END

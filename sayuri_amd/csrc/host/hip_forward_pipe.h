@@ -23,12 +23,22 @@
 #include <thread>
 #include <vector>
 
+#ifdef SAYURI_IN_TREE
+// Built inside the reference tree: the reference's own plugin types (global namespace).
+#include "neural/description.h"
+#include "neural/network_basic.h"
+#define SAYURI_HOST_BEGIN
+#define SAYURI_HOST_END
+#else
 #include "pipe_api.h"
 #include "weights_model.h"
+#define SAYURI_HOST_BEGIN namespace sayuri_host {
+#define SAYURI_HOST_END }
+#endif
 
 struct sayuri_hip_ctx;
 
-namespace sayuri_host {
+SAYURI_HOST_BEGIN
 
 // What the reference reads from its global option map (config.cc:21-133): "batch_size",
 // "gpus", "fp16", "gpu_waittime", "defualt_boardsize", "fixed_nn_boardsize".
@@ -104,4 +114,4 @@ private:
     std::atomic<size_t> batches_{0}, evals_{0};
 };
 
-}  // namespace sayuri_host
+SAYURI_HOST_END

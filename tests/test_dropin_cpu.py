@@ -1,0 +1,46 @@
+"""CPU-side drop-in checks: the host pipe compiles against the REFERENCE's headers when
+/root/reference is mounted (dev container only), and the sharded bench path works under gloo."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference tree not mounted")
+def test_pipe_compiles_in_reference_tree():
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-DSAYURI_IN_TREE", "-I/root/reference/src",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "sayuri_amd", "csrc", "host"),
+           os.path.join(ROOT, "sayuri_amd", "csrc", "host", "hip_forward_pipe.cc")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_sharded_stats_gather_gloo_world2(tmp_path):
+    """The only multi-GPU exchange of the path: barrier + max-over-ranks time + stats gather
+    (bench.py / DESIGN.md section 6), exercised with 2 gloo ranks on CPU."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from sayuri_amd.shard import shard_range, gather_stats\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "lo, hi = shard_range(1000, r, w)\n"
+        "stats = gather_stats({'games_done': hi - lo, 'nn_queries': 10 * (r + 1), 'elapsed': 1.0 + r})\n"
+        "if r == 0:\n"
+        "    assert stats['games_done'] == 1000, stats\n"
+        "    assert stats['nn_queries'] == 30, stats\n"
+        "    assert stats['elapsed_max'] == 2.0, stats\n"
+        "    assert stats['per_rank'][1]['games_done'] == 500\n"
+        "    print('OK')\n"
+        "dist.barrier()\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
