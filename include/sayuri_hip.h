@@ -116,6 +116,14 @@ int sayuri_hip_run(sayuri_hip_ctx* ctx);   /* asynchronous on the ctx stream */
 int sayuri_hip_sync(sayuri_hip_ctx* ctx);
 int sayuri_hip_download(sayuri_hip_ctx* ctx, float* prob, float* pass, float* misc, float* own);
 
+/* Pipelined form for the pump thread: enqueue H2D + the whole graph + D2H on the ctx stream and
+ * return at once; `ticket` (0 or 1, two batches may be in flight) is waited for / polled later.
+ * All host buffers must be page-locked (sayuri_hip_host_alloc) and stay valid until the wait. */
+int sayuri_hip_submit(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes, float* prob,
+                      float* pass, float* misc, float* own, int* ticket);
+int sayuri_hip_wait(sayuri_hip_ctx* ctx, int ticket);
+int sayuri_hip_query(sayuri_hip_ctx* ctx, int ticket); /* 1 = finished, 0 = still running, -1 = error */
+
 /* Time `iters` back-to-back runs of the uploaded batch with HIP events on the ctx stream
  * (torch.cuda.Event cannot see this stream). total_ms = wall of all iters on the device. */
 int sayuri_hip_time_runs(sayuri_hip_ctx* ctx, int iters, float* total_ms);

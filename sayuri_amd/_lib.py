@@ -19,7 +19,7 @@ class KernelStat(ctypes.Structure):
 # every symbol include/sayuri_hip.h declares
 HIP_SYMBOLS = [
     "sayuri_hip_device_count", "sayuri_hip_create", "sayuri_hip_load_tensor", "sayuri_hip_forward",
-    "sayuri_hip_upload", "sayuri_hip_run", "sayuri_hip_sync", "sayuri_hip_download", "sayuri_hip_time_runs",
+    "sayuri_hip_submit", "sayuri_hip_wait", "sayuri_hip_query", "sayuri_hip_upload", "sayuri_hip_run", "sayuri_hip_sync", "sayuri_hip_download", "sayuri_hip_time_runs",
     "sayuri_hip_profile_run", "sayuri_hip_mark_kernel", "sayuri_hip_timed_stat", "sayuri_hip_host_alloc", "sayuri_hip_host_free", "sayuri_hip_device_bytes",
     "sayuri_hip_destroy", "sayuri_hip_last_error", "sayuri_hip_test_conv",
 ]
@@ -84,5 +84,10 @@ def host() -> ctypes.CDLL:
         lib.sayuri_pipe_reconstruct.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         lib.sayuri_pipe_eval.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
                                          c_int_p, c_float_p, c_int_p, c_float_p]
+        lib.sayuri_pipe_pump_times.restype = None
+        lib.sayuri_pipe_pump_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                               ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
+        lib.sayuri_pipe_netbench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
         _host = lib
     return _host

@@ -166,12 +166,12 @@ __global__ __launch_bounds__(256) void tile_setup_kernel(BatchGeom g, int* __res
 // BOTH phases before the first staging pass, so one memory latency covers the whole epilogue.
 template <int KO_T, int PT> struct EpiRows {
     static constexpr int HALF = PT / 2;
-    static constexpr int LPR = KO_T / 4;         // lanes per row (4 channels each)
+    static constexpr int LPR = KO_T / 8;         // lanes per row (8 channels = 16 B of fp16 each)
     static constexpr int RPI = 64 / LPR;         // rows per wave instruction
     static constexpr int NR = HALF / (8 * RPI);  // rows per lane per phase
     static_assert(HALF % (8 * RPI) == 0, "rows must split evenly over the waves");
     int grow[NR];
-    f16x4 rr[NR];
+    f16x8 rr[NR];
 };
 
 template <int KO_T, int PT>
@@ -180,15 +180,16 @@ __device__ __forceinline__ void epi_fetch(EpiRows<KO_T, PT>& e, const GldsParams
     using E = EpiRows<KO_T, PT>;
     const ConvParams& p = gp.c;
     const f16* __restrict__ gres = (const f16*)p.res;
-    const int ko = kt * KO_T + (lane % E::LPR) * 4;
-    const bool ko_ok = ko < p.cout_s;
+    const int ko = kt * KO_T + (lane % E::LPR) * 8;
+    const bool ko_ok = ko < p.cout_s;  // cout_s is a multiple of 32, so 8-channel groups never straddle it
     const int r0 = wave * E::RPI + lane / E::LPR;
 #pragma unroll
     for (int k = 0; k < E::NR; ++k) e.grow[k] = ko_ok ? rowid[phase * E::HALF + r0 + k * 8 * E::RPI] : -1;
     if (gres) {
 #pragma unroll
         for (int k = 0; k < E::NR; ++k)
-            e.rr[k] = e.grow[k] >= 0 ? *(const f16x4*)(gres + (size_t)e.grow[k] * p.cout_s + ko) : f16x4{0, 0, 0, 0};
+            e.rr[k] = e.grow[k] >= 0 ? *(const f16x8*)(gres + (size_t)e.grow[k] * p.cout_s + ko)
+                                     : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
 }
 
@@ -199,20 +200,22 @@ __device__ __forceinline__ void epi_store(const EpiRows<KO_T, PT>& e, const Glds
     constexpr int RS = KO_T * 4 + 16;
     const ConvParams& p = gp.c;
     f16* __restrict__ gout = (f16*)p.out;
-    const int col = (lane % E::LPR) * 4;
+    const int col = (lane % E::LPR) * 8;
     const int ko = kt * KO_T + col;
     const int r0 = wave * E::RPI + lane / E::LPR;
 #pragma unroll
     for (int k = 0; k < E::NR; ++k) {
-        f32x4 v = *(const f32x4*)(stage + (r0 + k * 8 * E::RPI) * RS + col * 4);
+        const unsigned char* src = stage + (r0 + k * 8 * E::RPI) * RS + col * 4;
+        const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 16);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (p.res) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += (float)e.rr[k][q];
+            for (int q = 0; q < 8; ++q) v[q] += (float)e.rr[k][q];
         }
-        f16x4 h;
+        f16x8 h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h[q] = (f16)activate(v[q], ACT);
-        if (e.grow[k] >= 0) *(f16x4*)(gout + (size_t)e.grow[k] * p.cout_s + ko) = h;
+        for (int q = 0; q < 8; ++q) h[q] = (f16)activate(v[q], ACT);
+        if (e.grow[k] >= 0) *(f16x8*)(gout + (size_t)e.grow[k] * p.cout_s + ko) = h;
     }
 }
 
@@ -343,8 +346,9 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
                 constexpr int dx = q / WMT, i = q % WMT;
                 // DMA of the next group, front-loaded: block 0: tap 0 + halo piece 0, block WMT/2:
                 // tap 1, block WMT: tap 2 + halo piece 1, block 3*WMT/2: halo piece 2.
-                if constexpr (q % (WMT / 2) == 0 && q / (WMT / 2) < 4) {
-                    constexpr int slot = q / (WMT / 2);
+                constexpr int SP = (ABL & 32) ? (WMT / 4 > 0 ? WMT / 4 : 1) : WMT / 2;  // DMA slot spacing
+                if constexpr (q % SP == 0 && q / SP < 4) {
+                    constexpr int slot = q / SP;
                     constexpr int bpiece = slot == 0 ? 0 : slot == 2 ? 1 : slot == 3 ? 2 : -1;
                     constexpr int atap = slot < 3 ? slot : -1;
                     if constexpr (!(ABL & 2) && bpiece >= 0 && bpiece < BI) {
@@ -352,6 +356,18 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
                     }
                     if constexpr (!(ABL & 1) && atap >= 0) {
                         if (more_a) issue_a(G + 1, atap);
+                    }
+                }
+                if constexpr ((ABL & 64) && q == NQ / 2) {
+                    // warm L2 / Infinity Cache with this tile's residual rows while the MFMAs run:
+                    // group G touches rows G*8+wave .. (PT rows total => PT/8 groups)
+                    if (p.res && G < PT / 8) {
+                        const int grow = rowid[G * 8 + wave];
+                        if (grow >= 0) {
+                            const char* src = (const char*)p.res + ((size_t)grow * p.cout_s + kt * KO_T) * 2 + (lane % (KO_T / 8)) * 16;
+                            uint4 dummy;
+                            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dummy) : "v"(src) : "memory");
+                        }
                     }
                 }
                 if constexpr (i == IB && dx < 2) {

@@ -106,6 +106,11 @@ static void register_all_glds() {
         case 8: e.fn = &conv_glds_kernel<8, 3, 8>; break;
         case 11: e.fn = &conv_glds_kernel<8, 3, 11>; break;
         case 16: e.fn = &conv_glds_kernel<8, 3, 16>; break;
+        case 32: e.fn = &conv_glds_kernel<8, 3, 32>; break;
+        case 64: e.fn = &conv_glds_kernel<8, 3, 64>; break;
+        case 96: e.fn = &conv_glds_kernel<8, 3, 96>; break;
+        case 48: e.fn = &conv_glds_kernel<8, 3, 48>; break;
+        case 80: e.fn = &conv_glds_kernel<8, 3, 80>; break;
         default: break;
         }
     }
@@ -242,6 +247,10 @@ public:
     virtual int download(float* prob, float* pass, float* misc, float* own) = 0;
     virtual int time_runs(int iters, float* ms) = 0;
     virtual int profile_run(sayuri_hip_kernel_stat* rows, int cap) = 0;
+    virtual int submit(int n, const float* planes, const int* bsz, float* prob, float* pass, float* misc, float* own,
+                       int* ticket) = 0;
+    virtual int wait(int ticket) = 0;
+    virtual int query(int ticket) = 0;
     virtual int mark_kernel(const char* name) = 0;
     virtual int timed_stat(sayuri_hip_kernel_stat* row) = 0;
     virtual size_t device_bytes() const = 0;
@@ -291,10 +300,52 @@ public:
     }
 
     // -------------------------------------------------------------- batch i/o
+    // asynchronous: H2D, graph, D2H enqueued on the stream, an event marks the end
+    int submit(int n, const float* planes, const int* board_sizes, float* prob, float* pass, float* misc, float* own,
+               int* ticket) override {
+        if (enqueue_inputs(n, planes, board_sizes)) return -1;
+        have_batch_ = true;
+        if (forward()) return -1;
+        const size_t B2 = (size_t)board_ * board_;
+        HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, stream_));
+        HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, stream_));
+        const int t = next_ticket_;
+        next_ticket_ ^= 1;
+        if (!tick_ev_[t]) HIP_OK(hipEventCreateWithFlags(&tick_ev_[t], hipEventDisableTiming));
+        HIP_OK(hipEventRecord(tick_ev_[t], stream_));
+        *ticket = t;
+        return 0;
+    }
+    int wait(int ticket) override {
+        if (ticket < 0 || ticket > 1 || !tick_ev_[ticket]) return fail("wait: bad ticket");
+        HIP_OK(hipSetDevice(device_));
+        HIP_OK(hipEventSynchronize(tick_ev_[ticket]));
+        return 0;
+    }
+    int query(int ticket) override {
+        if (ticket < 0 || ticket > 1 || !tick_ev_[ticket]) return fail("query: bad ticket");
+        const hipError_t e = hipEventQuery(tick_ev_[ticket]);
+        if (e == hipSuccess) return 1;
+        if (e == hipErrorNotReady) return 0;
+        return fail(std::string("hipEventQuery: ") + hipGetErrorString(e));
+    }
+
     int upload(int n, const float* planes, const int* board_sizes) override {
+        if (enqueue_inputs(n, planes, board_sizes)) return -1;
+        HIP_OK(hipStreamSynchronize(stream_));
+        have_batch_ = true;
+        return 0;
+    }
+
+    // geometry + planes H2D on the stream (no sync).  The geometry arrays are staged in a
+    // 2-deep pinned ring so a second batch can be enqueued while the first is still copying.
+    int enqueue_inputs(int n, const float* planes, const int* board_sizes) {
         HIP_OK(hipSetDevice(device_));
         if (n <= 0 || n > max_batch_) return fail("batch size out of range");
         if (finalize()) return -1;
+        prev_bsz_.swap(geom_.bsz);
         geom_.n = n;
         geom_.bsz.resize(n);
         geom_.off.resize(n + 1);
@@ -306,15 +357,19 @@ public:
             geom_.off[i + 1] = geom_.off[i] + bs * bs;
         }
         geom_.total = geom_.off[n];
-        tile_cache_.clear();
-        glds_cache_.clear();
-        for (auto& kv : tabs_) kv.second.fresh = false;
-        HIP_OK(hipMemcpyAsync(d_off_, geom_.off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, stream_));
-        HIP_OK(hipMemcpyAsync(d_bsz_, geom_.bsz.data(), sizeof(int) * n, hipMemcpyHostToDevice, stream_));
+        if (geom_.bsz != prev_bsz_) {  // tile choices and index tables depend on the geometry only
+            tile_cache_.clear();
+            glds_cache_.clear();
+            for (auto& kv : tabs_) kv.second.fresh = false;
+        }
+        int* hg = h_geom_ + (size_t)geom_slot_ * (2 * max_batch_ + 1);
+        geom_slot_ ^= 1;
+        std::memcpy(hg, geom_.off.data(), sizeof(int) * (n + 1));
+        std::memcpy(hg + max_batch_ + 1, geom_.bsz.data(), sizeof(int) * n);
+        HIP_OK(hipMemcpyAsync(d_off_, hg, sizeof(int) * (n + 1), hipMemcpyHostToDevice, stream_));
+        HIP_OK(hipMemcpyAsync(d_bsz_, hg + max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, stream_));
         HIP_OK(hipMemcpyAsync(d_planes_, planes, sizeof(float) * (size_t)n * desc_.input_channels * board_ * board_,
                               hipMemcpyHostToDevice, stream_));
-        HIP_OK(hipStreamSynchronize(stream_));
-        have_batch_ = true;
         return 0;
     }
 
@@ -580,6 +635,7 @@ private:
         if (dev_alloc(&d_planes_, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
         if (dev_alloc(&d_off_, max_batch_ + 1) || dev_alloc(&d_bsz_, max_batch_)) return -1;
         if (dev_alloc(&d_zeros_, 64)) return -1;
+        HIP_OK(hipHostMalloc((void**)&h_geom_, sizeof(int) * 2 * (2 * max_batch_ + 1), hipHostMallocDefault));
         if (dev_alloc(&d_gate_, (size_t)max_batch_ * 2 * round_up(desc_.residual_channels, 32))) return -1;
         if (dev_alloc(&d_separt_, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
         if (dev_alloc(&d_prob_, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
@@ -596,6 +652,9 @@ private:
         (void)hipSetDevice(device_);
         for (void* p : allocs_) (void)hipFree(p);
         allocs_.clear();
+        if (h_geom_) (void)hipHostFree(h_geom_);
+        h_geom_ = nullptr;
+        for (hipEvent_t& e : tick_ev_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
         pool_.clear();
         if (ev0_) (void)hipEventDestroy(ev0_);
@@ -918,7 +977,11 @@ private:
     int *d_off_ = nullptr, *d_bsz_ = nullptr;
     float* d_zeros_ = nullptr;
     unsigned long long* d_dbg_ = nullptr;
+    int* h_geom_ = nullptr;  // pinned 2-slot ring: [slot][off(max_batch+1) | bsz(max_batch)]
+    int geom_slot_ = 0, next_ticket_ = 0;
+    hipEvent_t tick_ev_[2] = {nullptr, nullptr};
     HostGeom geom_;
+    std::vector<int> prev_bsz_;
     std::map<int, GldsChoice> glds_cache_;
     std::map<int, TileTabs> tabs_;
     std::map<int, TileChoice> tile_cache_;
@@ -999,6 +1062,14 @@ int sayuri_hip_forward(sayuri_hip_ctx* ctx, int n, const float* planes, const in
     if (ctx->eng->run()) return -1;
     return ctx->eng->download(prob, pass, misc, own);
 }
+
+int sayuri_hip_submit(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes, float* prob,
+                      float* pass, float* misc, float* own, int* ticket) {
+    if (!ctx || !planes || !prob || !pass || !misc || !own || !ticket) return fail("submit: null argument");
+    return ctx->eng->submit(n, planes, board_sizes, prob, pass, misc, own, ticket);
+}
+int sayuri_hip_wait(sayuri_hip_ctx* ctx, int ticket) { return ctx ? ctx->eng->wait(ticket) : fail("wait: null ctx"); }
+int sayuri_hip_query(sayuri_hip_ctx* ctx, int ticket) { return ctx ? ctx->eng->query(ticket) : fail("query: null ctx"); }
 
 int sayuri_hip_time_runs(sayuri_hip_ctx* ctx, int iters, float* total_ms) {
     if (!ctx || !total_ms || iters <= 0) return fail("time_runs: bad argument");

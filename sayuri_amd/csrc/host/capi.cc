@@ -136,6 +136,12 @@ void sayuri_pipe_destroy(void* hp) {
     delete h;
 }
 
+void sayuri_pipe_pump_times(void* hp, double* out4, long* batches, long* evals) {
+    auto* h = static_cast<PipeHandle*>(hp);
+    h->pipe->pump_times(out4);
+    *batches = static_cast<long>(h->pipe->num_batches());
+    *evals = static_cast<long>(h->pipe->num_evals());
+}
 int sayuri_pipe_num_workers(void* hp) { return static_cast<PipeHandle*>(hp)->pipe->GetNumWorkers(); }
 void* sayuri_pipe_ctx(void* hp, int gpu) { return static_cast<PipeHandle*>(hp)->pipe->ctx(gpu); }
 int sayuri_pipe_reconstruct(void* hp, int board, int batch) {
@@ -147,6 +153,12 @@ int sayuri_pipe_reconstruct(void* hp, int board, int batch) {
         return -1;
     }
 }
+
+// netbench: the reference's own definition of "NN evals/s" (GTP `netbench`, src/game/gtp.cc:1468-1568):
+// `threads` host threads hammer NetworkForwardPipe::Forward with cache off for `seconds`; the count
+// includes queueing, staging, H2D / D2H.  (The reference also runs the encoder per call; the
+// encoder is not part of this backend yet, so each thread re-submits a fixed random position.)
+int sayuri_pipe_netbench(void* hp, int threads, double seconds, int board, double* evals_per_sec, long* total);
 
 // n evaluations.  planes [n][43*361] in InputData layout (each sample packed with its OWN board
 // stride), out [n][2*361 + 9] = prob[bs*bs], own[bs*bs] (both packed with the sample's stride,
@@ -226,6 +238,60 @@ extern "C" int sayuri_pipe_eval(void* hp, int mode, int gpu, int n, const float*
             t[4] = r.stm_winrate; t[5] = r.final_score; t[6] = r.q_error; t[7] = r.score_error;
             t[8] = static_cast<float>(static_cast<int>(r.offset));
         }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+#include <atomic>
+#include <chrono>
+#include <random>
+
+extern "C" int sayuri_pipe_netbench(void* hp, int threads, double seconds, int board, double* evals_per_sec,
+                                    long* total) {
+    auto* h = static_cast<PipeHandle*>(hp);
+    if (!h || threads <= 0 || seconds <= 0) return -1;
+    try {
+        std::atomic<long> count{0};
+        std::atomic<bool> stop{false}, failed{false};
+        std::string err;
+        std::mutex err_mu;
+        std::vector<std::thread> th;
+        const int C = h->weights->input_channels;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < threads; ++t)
+            th.emplace_back([&, t] {
+                auto in = std::make_unique<InputData>();
+                std::mt19937 rng(1234 + t);
+                in->board_size = board;
+                in->komi = 7.5f;
+                in->offset = PolicyBufferOffset::kNormal;
+                const int s = board * board;
+                for (int c = 0; c < C; ++c)
+                    for (int i = 0; i < s; ++i) in->planes[c * s + i] = c < 37 ? float((rng() % 5) == 0) : (c == 42 ? 1.f : 0.3f);
+                try {
+                    while (!stop.load(std::memory_order_relaxed)) {
+                        OutputResult r = h->pipe->Forward(*in);
+                        (void)r;
+                        count.fetch_add(1, std::memory_order_relaxed);
+                    }
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    err = e.what();
+                    failed.store(true);
+                }
+            });
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds && !failed.load())
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        const long n = count.load();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stop.store(true);
+        for (auto& t : th) t.join();
+        if (failed.load()) throw std::runtime_error(err);
+        *evals_per_sec = n / dt;
+        *total = n;
         return 0;
     } catch (const std::exception& e) {
         g_err = e.what();

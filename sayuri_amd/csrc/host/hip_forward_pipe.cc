@@ -6,6 +6,12 @@
 #include <cstring>
 #include <stdexcept>
 
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <climits>
+
 #include "../../../include/sayuri_hip.h"
 
 SAYURI_HOST_BEGIN
@@ -16,6 +22,18 @@ int NetworkForwardPipe::GetVersion() const { return Valid() ? weights_->version 
 #endif
 
 namespace {
+
+// Completion is a per-request 32-bit flag; blocked callers sleep in the kernel on that word
+// (futex) instead of polling, so hundreds of waiting search threads leave the host cores to
+// the pump thread and the encoder.  (The reference parks each caller on its own heap-allocated
+// mutex + condition variable, batch_forward_pipe.cc:35-46.)
+static_assert(sizeof(std::atomic<int>) == sizeof(int), "futex needs a plain 32-bit word");
+inline void FutexWait(std::atomic<int>* w, int expected) {
+    syscall(SYS_futex, reinterpret_cast<int*>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void FutexWakeAll(std::atomic<int>* w) {
+    syscall(SYS_futex, reinterpret_cast<int*>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
 
 [[noreturn]] void ThrowHip(const char* what) {
     throw std::runtime_error(std::string(what) + ": " + sayuri_hip_last_error());
@@ -175,12 +193,15 @@ void HipForwardPipe::BuildGraphs() {
             if (!p) ThrowHip("sayuri_hip_host_alloc");
             return p;
         };
-        g->planes = pinned(static_cast<size_t>(max_batch_) * w.input_channels * B2);
-        g->prob = pinned(static_cast<size_t>(max_batch_) * w.probabilities_channels * B2);
-        g->pass = pinned(static_cast<size_t>(max_batch_) * w.pass_probability_outputs);
-        g->misc = pinned(static_cast<size_t>(max_batch_) * w.value_misc_outputs);
-        g->own = pinned(static_cast<size_t>(max_batch_) * B2);
-        g->bsz.resize(max_batch_);
+        for (Staging& s : g->st) {
+            s.planes = pinned(static_cast<size_t>(max_batch_) * w.input_channels * B2);
+            s.prob = pinned(static_cast<size_t>(max_batch_) * w.probabilities_channels * B2);
+            s.pass = pinned(static_cast<size_t>(max_batch_) * w.pass_probability_outputs);
+            s.misc = pinned(static_cast<size_t>(max_batch_) * w.value_misc_outputs);
+            s.own = pinned(static_cast<size_t>(max_batch_) * B2);
+            s.bsz.assign(max_batch_, board_size_);
+            s.reqs.resize(max_batch_);
+        }
         graphs_.push_back(std::move(g));
     }
     running_.store(true);
@@ -198,11 +219,13 @@ void HipForwardPipe::DestroyGraphs() {
     for (auto& g : graphs_)
         if (g->pump.joinable()) g->pump.join();
     for (auto& g : graphs_) {
-        sayuri_hip_host_free(g->planes);
-        sayuri_hip_host_free(g->prob);
-        sayuri_hip_host_free(g->pass);
-        sayuri_hip_host_free(g->misc);
-        sayuri_hip_host_free(g->own);
+        for (Staging& s : g->st) {
+            sayuri_hip_host_free(s.planes);
+            sayuri_hip_host_free(s.prob);
+            sayuri_hip_host_free(s.pass);
+            sayuri_hip_host_free(s.misc);
+            sayuri_hip_host_free(s.own);
+        }
         if (g->ctx) sayuri_hip_destroy(g->ctx);
     }
     graphs_.clear();
@@ -214,11 +237,11 @@ void HipForwardPipe::Destroy() { DestroyGraphs(); }
 
 // Copy one request into staging slot `slot`, re-padding a smaller board top-left into the NN
 // grid (what SendQueryAndWait does with a temporary InputData, batch_forward_pipe.cc:15-33).
-void HipForwardPipe::StageInput(Graph* g, int slot, const InputData& in, bool already_padded) {
+void HipForwardPipe::StageInput(Staging* st, int slot, const InputData& in, bool already_padded) {
     const int B = board_size_, bs = in.board_size, C = weights_->input_channels;
     if (bs < 2 || bs > B) throw std::runtime_error("InputData board size does not fit the NN board");
-    float* dst = g->planes + static_cast<size_t>(slot) * C * B * B;
-    g->bsz[slot] = bs;
+    float* dst = st->planes + static_cast<size_t>(slot) * C * B * B;
+    st->bsz[slot] = bs;
     if (bs == B || already_padded) {
         std::memcpy(dst, in.planes.data(), sizeof(float) * C * B * B);
         return;
@@ -233,7 +256,7 @@ void HipForwardPipe::StageInput(Graph* g, int slot, const InputData& in, bool al
 // FillOutputs of the CPU pipe (blas_forward_pipe.cc:565-619 -- the oracle; the CUDA pipe's
 // pass[0] for every offset, cuda_forward_pipe.cc:1074, is a known discrepancy) fused with the
 // un-padding of SendQueryAndWait (batch_forward_pipe.cc:48-68).
-void HipForwardPipe::FillOutput(const Graph* g, int slot, const InputData& in, bool unpad, OutputResult* out) const {
+void HipForwardPipe::FillOutput(const Staging* g, int slot, const InputData& in, bool unpad, OutputResult* out) const {
     DNNWeights& w = *weights_;
     const int B = board_size_, B2 = B * B, bs = in.board_size;
     const bool v1 = w.version <= 2;  // Encoder::GetEncoderVersion, encoder.h:64-77
@@ -274,80 +297,166 @@ void HipForwardPipe::FillOutput(const Graph* g, int slot, const InputData& in, b
     out->fp16 = cfg_.fp16;
 }
 
-void HipForwardPipe::RunBatch(Graph* g, const Request* reqs, int n) {
+void HipForwardPipe::SubmitBatch(Graph* g, Staging* s, int n) {
+    const auto t0 = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> dev(g->dev_mu);
-    for (int i = 0; i < n; ++i) StageInput(g, i, *reqs[i].input, false);
-    if (sayuri_hip_forward(g->ctx, n, g->planes, g->bsz.data(), g->prob, g->pass, g->misc, g->own))
-        ThrowHip("sayuri_hip_forward");
-    for (int i = 0; i < n; ++i) {
-        FillOutput(g, i, *reqs[i].input, true, reqs[i].output);
-        reqs[i].done->store(1, std::memory_order_release);
-    }
-    batches_.fetch_add(1, std::memory_order_relaxed);
-    evals_.fetch_add(static_cast<size_t>(n), std::memory_order_relaxed);
+    if (sayuri_hip_submit(g->ctx, n, s->planes, s->bsz.data(), s->prob, s->pass, s->misc, s->own, &s->ticket))
+        ThrowHip("sayuri_hip_submit");
+    s->n_inflight = n;
+    pump_ns_[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// One persistent pump per GPU.  Gathers up to batch_size requests; if fewer are waiting it
-// sleeps at most gpu_waittime_ms for more, and once a wait times out with work pending it
-// stops waiting until the queue runs dry again (the adaptive 0 <-> base wait of
+void HipForwardPipe::FinishBatch(Graph* g, Staging* s, int n) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    {
+        std::lock_guard<std::mutex> dev(g->dev_mu);
+        rc = sayuri_hip_wait(g->ctx, s->ticket);
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) {
+        if (rc == 0) FillOutput(s, i, *s->reqs[i].input, true, s->reqs[i].output);
+        s->reqs[i].done->store(rc == 0 ? 1 : -1, std::memory_order_release);
+        FutexWakeAll(s->reqs[i].done);
+    }
+    const auto t2 = std::chrono::steady_clock::now();
+    pump_ns_[3] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    pump_ns_[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+    batches_.fetch_add(1, std::memory_order_relaxed);
+    evals_.fetch_add(static_cast<size_t>(n), std::memory_order_relaxed);
+    s->n_inflight = 0;
+    s->ready.store(0, std::memory_order_relaxed);
+    s->reserved.store(0, std::memory_order_release);  // re-open for callers
+}
+
+// One persistent pump per GPU, two batches deep.  While batch A runs on the GPU the callers fill
+// staging set B; as soon as B holds batch_size requests it is ENQUEUED behind A (H2D, graph, D2H are
+// all stream-ordered), and only then does the pump block on A, hand out A's results and re-open A.
+// A set that is not full is sent after gpu_waittime_ms, and once that happened the pump stops
+// waiting until a set comes up empty again (the adaptive 0 <-> base wait of
 // batch_forward_pipe.cc:99-193).
 void HipForwardPipe::PumpLoop(Graph* g) {
-    std::vector<Request> batch;
+    using clock = std::chrono::steady_clock;
+    auto count = [](const Staging& s) { return s.reserved.load(std::memory_order_acquire) & ~Staging::kClosed; };
+    auto closed = [](const Staging& s) { return (s.reserved.load(std::memory_order_acquire) & Staging::kClosed) != 0; };
+    const unsigned want = static_cast<unsigned>(std::min(cfg_.batch_size, max_batch_));
+    int cur = 0;           // set currently filling
+    int inflight[2];       // FIFO of sets on the GPU
+    int n_in = 0;
     bool eager = false;
+    clock::time_point first_seen{};
+    bool timing = false;
+
+    // close set `i`, point callers at the other one, wait for plane copies, enqueue
+    auto launch = [&](int i) {
+        Staging& s = g->st[i];
+        const unsigned prev = s.reserved.fetch_or(Staging::kClosed, std::memory_order_acq_rel);
+        const int n = static_cast<int>(std::min<unsigned>(prev & ~Staging::kClosed, static_cast<unsigned>(max_batch_)));
+        g->fill.store(i ^ 1, std::memory_order_release);
+        if (n == 0) {
+            s.reserved.store(0, std::memory_order_release);
+            return;
+        }
+        while (s.ready.load(std::memory_order_acquire) < static_cast<unsigned>(n)) std::this_thread::yield();
+        try {
+            SubmitBatch(g, &s, n);
+            inflight[n_in++] = i;
+        } catch (const std::exception&) {
+            for (int k = 0; k < n; ++k) {
+                s.reqs[k].done->store(-1, std::memory_order_release);
+                FutexWakeAll(s.reqs[k].done);
+            }
+            s.ready.store(0, std::memory_order_relaxed);
+            s.reserved.store(0, std::memory_order_release);
+        }
+    };
+    auto finish_oldest = [&] {
+        Staging& s = g->st[inflight[0]];
+        FinishBatch(g, &s, s.n_inflight);
+        inflight[0] = inflight[1];
+        --n_in;
+    };
+
     while (true) {
-        batch.clear();
+        Staging& s = g->st[cur];
+        const unsigned c = closed(s) ? 0u : count(s);
+        if (!running_.load() && n_in == 0 && count(g->st[0]) == 0 && count(g->st[1]) == 0) return;
+
+        if (closed(s)) {  // both sets are on the GPU: retire the older one, it becomes the fill set
+            finish_oldest();
+            timing = false;
+            continue;
+        }
+        if (c >= want || (c > 0 && (eager || cfg_.gpu_waittime_ms <= 0 || !running_.load()))) {
+            if (c >= want) eager = false;  // traffic fills whole batches again
+            launch(cur);
+            cur ^= 1;
+            timing = false;
+            continue;
+        }
+        if (c > 0) {  // partial batch: give it gpu_waittime_ms, then send it and turn eager
+            if (!timing) { timing = true; first_seen = clock::now(); }
+            if (clock::now() - first_seen >= std::chrono::milliseconds(cfg_.gpu_waittime_ms)) {
+                eager = true;
+                continue;
+            }
+        } else {
+            timing = false;
+            eager = false;  // the fill set ran dry
+        }
+        // nothing to send yet: retire a finished batch if there is one, else nap
+        if (n_in > 0) {
+            int q;
+            {
+                std::lock_guard<std::mutex> dev(g->dev_mu);
+                q = sayuri_hip_query(g->ctx, g->st[inflight[0]].ticket);
+            }
+            if (q != 0) {
+                finish_oldest();
+                continue;
+            }
+        }
+        const auto tw0 = clock::now();
         {
             std::unique_lock<std::mutex> lk(g->mu);
-            g->cv.wait(lk, [&] { return !running_.load() || !g->queue.empty(); });
-            if (!running_.load() && g->queue.empty()) return;
-            const int want = std::min(cfg_.batch_size, max_batch_);
-            if (static_cast<int>(g->queue.size()) < want && !eager && cfg_.gpu_waittime_ms > 0) {
-                const bool full = g->cv.wait_for(lk, std::chrono::milliseconds(cfg_.gpu_waittime_ms), [&] {
-                    return !running_.load() || static_cast<int>(g->queue.size()) >= want;
-                });
-                if (!full) eager = true;
-            }
-            const int take = std::min<int>(static_cast<int>(g->queue.size()), want);
-            for (int i = 0; i < take; ++i) {
-                batch.push_back(g->queue.front());
-                g->queue.pop_front();
-            }
-            if (g->queue.empty()) eager = false;
+            g->cv.wait_for(lk, std::chrono::microseconds(n_in > 0 ? 50 : 200));
         }
-        if (batch.empty()) continue;
-        try {
-            RunBatch(g, batch.data(), static_cast<int>(batch.size()));
-        } catch (const std::exception&) {
-            // surface the failure to every waiter: done = -1 (Forward rethrows)
-            for (auto& r : batch) r.done->store(-1, std::memory_order_release);
-        }
+        pump_ns_[2] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - tw0).count();
     }
 }
 
 void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atomic<int>* done) {
     if (graphs_.empty()) throw std::runtime_error("HipForwardPipe is not constructed");
+    if (input.board_size < 2 || input.board_size > board_size_)
+        throw std::runtime_error("InputData board size does not fit the NN board");
     done->store(0, std::memory_order_relaxed);
     Graph* g = graphs_[next_graph_.fetch_add(1, std::memory_order_relaxed) % graphs_.size()].get();
-    bool wake;
-    {
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->queue.push_back(Request{&input, out, done});
-        wake = static_cast<int>(g->queue.size()) >= std::min(cfg_.batch_size, max_batch_) || g->queue.size() == 1;
+    const unsigned cap = static_cast<unsigned>(max_batch_);
+    const unsigned want = static_cast<unsigned>(std::min(cfg_.batch_size, max_batch_));
+    for (int spins = 0;; ++spins) {
+        Staging& s = g->st[g->fill.load(std::memory_order_acquire)];
+        const unsigned r = s.reserved.fetch_add(1, std::memory_order_acq_rel);
+        if (!(r & Staging::kClosed) && r < cap) {
+            const int slot = static_cast<int>(r);
+            StageInput(&s, slot, input, false);  // the one copy of the planes, by the calling thread
+            s.reqs[slot] = Request{&input, out, done};
+            s.ready.fetch_add(1, std::memory_order_release);
+            if (r == 0 || r + 1 >= want) g->cv.notify_one();
+            return;
+        }
+        // set closed or full: the pump is about to rotate; back off briefly and retry
+        if (spins < 16) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (!running_.load()) throw std::runtime_error("HipForwardPipe is shutting down");
     }
-    if (wake) g->cv.notify_one();
 }
 
 OutputResult HipForwardPipe::Forward(const InputData& input) {
     OutputResult out;
     std::atomic<int> done{0};
     Submit(input, &out, &done);
-    // short spin, then yield: a batch takes O(100 us .. ms)
-    int spins = 0;
     int st;
-    while ((st = done.load(std::memory_order_acquire)) == 0) {
-        if (++spins < 64) continue;
-        std::this_thread::sleep_for(std::chrono::microseconds(20));
-    }
+    while ((st = done.load(std::memory_order_acquire)) == 0) FutexWait(&done, 0);
     if (st < 0) throw std::runtime_error("HIP forward pipe failed while evaluating a batch");
     return out;
 }
@@ -359,11 +468,21 @@ std::vector<OutputResult> HipForwardPipe::BatchForward(int gpu, const std::vecto
     std::vector<OutputResult> outs(inputs.size());
     if (n == 0) return outs;
     Graph* g = graphs_[gpu].get();
-    std::lock_guard<std::mutex> dev(g->dev_mu);  // keep the pump out while we own the staging buffers
-    for (int i = 0; i < n; ++i) StageInput(g, i, inputs[i], true);
-    if (sayuri_hip_forward(g->ctx, n, g->planes, g->bsz.data(), g->prob, g->pass, g->misc, g->own))
-        ThrowHip("sayuri_hip_forward");
-    for (int i = 0; i < n; ++i) FillOutput(g, i, inputs[i], false, &outs[i]);
+    // pageable scratch staging of its own: the pinned sets belong to the queue path
+    DNNWeights& w = *weights_;
+    const size_t B2 = static_cast<size_t>(board_size_) * board_size_;
+    Staging s;
+    std::vector<float> planes(static_cast<size_t>(n) * w.input_channels * B2), prob(static_cast<size_t>(n) * w.probabilities_channels * B2),
+        pass(static_cast<size_t>(n) * w.pass_probability_outputs), misc(static_cast<size_t>(n) * w.value_misc_outputs), own(static_cast<size_t>(n) * B2);
+    s.planes = planes.data(); s.prob = prob.data(); s.pass = pass.data(); s.misc = misc.data(); s.own = own.data();
+    s.bsz.assign(n, board_size_);
+    for (int i = 0; i < n; ++i) StageInput(&s, i, inputs[i], true);
+    {
+        std::lock_guard<std::mutex> dev(g->dev_mu);  // keep the pump's batches out while we use the ctx
+        if (sayuri_hip_forward(g->ctx, n, s.planes, s.bsz.data(), s.prob, s.pass, s.misc, s.own))
+            ThrowHip("sayuri_hip_forward");
+    }
+    for (int i = 0; i < n; ++i) FillOutput(&s, i, inputs[i], false, &outs[i]);
     batches_.fetch_add(1, std::memory_order_relaxed);
     evals_.fetch_add(static_cast<size_t>(n), std::memory_order_relaxed);
     return outs;

@@ -16,7 +16,6 @@
 
 #include <atomic>
 #include <condition_variable>
-#include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -77,6 +76,11 @@ public:
     sayuri_hip_ctx* ctx(int gpu) const;
     size_t num_batches() const { return batches_.load(std::memory_order_relaxed); }
     size_t num_evals() const { return evals_.load(std::memory_order_relaxed); }
+    // pump time split since construction, microseconds: [0] inside sayuri_hip_forward, [1] filling
+    // outputs + signalling, [2] waiting for a batch to form, [3] waiting for plane copies
+    void pump_times(double out[4]) const {
+        for (int i = 0; i < 4; ++i) out[i] = static_cast<double>(pump_ns_[i].load(std::memory_order_relaxed)) * 1e-3;
+    }
 
 private:
     struct Request {
@@ -84,26 +88,38 @@ private:
         OutputResult* output;
         std::atomic<int>* done;
     };
-    struct Graph {  // one per GPU (NNGraph in the reference)
-        int device{-1};
-        sayuri_hip_ctx* ctx{nullptr};
-        // pinned staging, sized for max_batch
+    // One batch being assembled or evaluated.  Callers reserve a slot with one atomic add and copy
+    // their planes straight into the pinned buffer the GPU will read (one copy per evaluation,
+    // done in parallel by the calling threads); `ready` counts finished copies.
+    struct Staging {
+        static constexpr unsigned kClosed = 1u << 31;
         float* planes{nullptr};
         float *prob{nullptr}, *pass{nullptr}, *misc{nullptr}, *own{nullptr};
         std::vector<int> bsz;
+        std::vector<Request> reqs;
+        std::atomic<unsigned> reserved{0};  // slot counter | kClosed
+        std::atomic<unsigned> ready{0};
+        int n_inflight{0};   // pump-private: batch size while on the GPU
+        int ticket{-1};      // pump-private: sayuri_hip_submit ticket
+    };
+    struct Graph {  // one per GPU (NNGraph in the reference)
+        int device{-1};
+        sayuri_hip_ctx* ctx{nullptr};
+        Staging st[2];               // double buffer: one fills while the other is on the GPU
+        std::atomic<int> fill{0};    // index of the staging set new requests go to
         std::thread pump;
-        std::mutex dev_mu;  // owner of ctx + staging buffers (pump batch or a direct BatchForward)
-        std::mutex mu;      // guards `queue`
+        std::mutex dev_mu;  // owner of ctx (pump batch or a direct BatchForward)
+        std::mutex mu;      // pump sleep / wake-up only
         std::condition_variable cv;
-        std::deque<Request> queue;
     };
 
     void BuildGraphs();
     void DestroyGraphs();
     void PumpLoop(Graph* g);
-    void RunBatch(Graph* g, const Request* reqs, int n);
-    void StageInput(Graph* g, int slot, const InputData& in, bool already_padded);
-    void FillOutput(const Graph* g, int slot, const InputData& in, bool unpad, OutputResult* out) const;
+    void SubmitBatch(Graph* g, Staging* s, int n);
+    void FinishBatch(Graph* g, Staging* s, int n);
+    void StageInput(Staging* s, int slot, const InputData& in, bool already_padded);
+    void FillOutput(const Staging* s, int slot, const InputData& in, bool unpad, OutputResult* out) const;
 
     HipPipeConfig cfg_;
     int board_size_{0};
@@ -112,6 +128,7 @@ private:
     std::atomic<bool> running_{false};
     std::atomic<unsigned> next_graph_{0};
     std::atomic<size_t> batches_{0}, evals_{0};
+    mutable std::atomic<long long> pump_ns_[4] = {};
 };
 
 SAYURI_HOST_END

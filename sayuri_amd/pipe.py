@@ -99,6 +99,22 @@ class HipForwardPipe:
         except Exception:
             pass
 
+    def netbench(self, threads: int, seconds: float = 5.0, board: int = MAX_BOARD):
+        """The reference's `netbench` measure (gtp.cc:1468-1568): threads blocked in Forward()
+        for `seconds`; returns (evals_per_sec, total_evals).  Includes queue + PCIe both ways."""
+        eps, tot = ctypes.c_double(0), ctypes.c_long(0)
+        if _lib.host().sayuri_pipe_netbench(self._h, threads, seconds, board, ctypes.byref(eps), ctypes.byref(tot)):
+            raise RuntimeError(_lib.host().sayuri_host_last_error().decode())
+        return eps.value, tot.value
+
+    def pump_times(self):
+        """-> dict of pump-thread time (us) since construction + batch / eval counters."""
+        t = (ctypes.c_double * 4)()
+        b, e = ctypes.c_long(0), ctypes.c_long(0)
+        _lib.host().sayuri_pipe_pump_times(self._h, t, ctypes.byref(b), ctypes.byref(e))
+        return {"forward_us": t[0], "fill_us": t[1], "wait_batch_us": t[2], "wait_copies_us": t[3],
+                "batches": b.value, "evals": e.value}
+
     def ctx(self, gpu: int = 0) -> int:
         c = _lib.host().sayuri_pipe_ctx(self._h, gpu)
         if not c:
