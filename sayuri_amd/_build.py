@@ -18,6 +18,7 @@ PKG = os.path.join(ROOT, "sayuri_amd")
 LIB = os.path.join(PKG, "lib")
 HIP_SRC = os.path.join(PKG, "csrc", "hip")
 HOST_SRC = os.path.join(PKG, "csrc", "host")
+ENGINE_SRC = os.path.join(PKG, "csrc", "engine")
 HIP_SO = os.path.join(LIB, "libsayuri_hip.so")
 HOST_SO = os.path.join(LIB, "libsayuri_host.so")
 
@@ -53,11 +54,29 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
+    """g++ every host/ and engine/ translation unit to an object (rebuilt only when it or a header
+    changed), then link libsayuri_host.so against libsayuri_hip.so."""
+    from concurrent.futures import ThreadPoolExecutor
     build_hip(force=False, verbose=verbose)
-    srcs = _files(HOST_SRC, (".cc", ".h")) + [os.path.join(ROOT, "include", "sayuri_hip.h")]
-    if force or _newer(HOST_SO, srcs + [HIP_SO]):
-        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra"] + _files(HOST_SRC, (".cc",)) + \
-              ["-o", HOST_SO, "-L" + LIB, "-lsayuri_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+    objdir = os.path.join(LIB, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = _files(HOST_SRC, (".h",)) + _files(ENGINE_SRC, (".h",)) + [os.path.join(ROOT, "include", f)
+                                                                          for f in os.listdir(os.path.join(ROOT, "include"))]
+    jobs, objs = [], []
+    for src in _files(HOST_SRC, (".cc",)) + _files(ENGINE_SRC, (".cc",)):
+        obj = os.path.join(objdir, os.path.basename(os.path.dirname(src)) + "_" + os.path.basename(src)[:-3] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers):
+            jobs.append(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-I" + HOST_SRC, "-I" + ENGINE_SRC,
+                         "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+    if jobs:
+        if verbose:
+            for j in jobs:
+                print(" ".join(j), file=sys.stderr)
+        with ThreadPoolExecutor(max_workers=min(16, len(jobs))) as ex:
+            list(ex.map(subprocess.check_call, jobs))
+    if jobs or force or _newer(HOST_SO, objs + [HIP_SO]):
+        cmd = ["g++", "-shared", "-o", HOST_SO] + objs + ["-L" + LIB, "-lsayuri_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

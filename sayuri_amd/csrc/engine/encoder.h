@@ -1,0 +1,22 @@
+// Network input planes from a GameState.
+//
+// Same plane semantics, order and values as the reference encoder (src/neural/encoder.h:24-61,
+// src/neural/encoder.cc:14-49,101-368):  v3+ nets use encoder v2 (43 planes), v1/v2 nets encoder v1 (38).
+// Writes straight into a caller-provided buffer (e.g. a pinned staging slot of the HIP pipe) instead of
+// building and copying std::vectors.
+#pragma once
+
+#include "game_state.h"
+
+namespace sayuri_go {
+
+struct Encoder {
+    static constexpr int kHistory = 8;
+    static constexpr int EncoderVersion(int weights_version) { return (weights_version == 1 || weights_version == 2) ? 1 : 2; }
+    static constexpr int InputChannels(int weights_version) { return EncoderVersion(weights_version) == 1 ? 38 : 43; }
+
+    // planes: [InputChannels][board*board] of the state's own board size, already symmetry-transformed.
+    static void Planes(const GameState& state, int symmetry, int weights_version, float* planes);
+};
+
+} // namespace sayuri_go

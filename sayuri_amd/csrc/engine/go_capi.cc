@@ -1,0 +1,130 @@
+// C entry points of the Go engine for the Python face (sayuri_amd/engine.py) and the parity tests.
+// Moves cross this boundary as intersection indices: 0..N-1, N = pass, -1 = resign.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+
+#include "encoder.h"
+#include "game_state.h"
+
+using namespace sayuri_go;
+
+namespace {
+inline GameState* G(void* h) { return static_cast<GameState*>(h); }
+int ToVertex(const GameState* g, int move) {
+    if (move < 0) return kResignMove;
+    if (move == g->GetNumIntersections()) return kPassMove;
+    return g->IndexToVertex(move);
+}
+std::uint64_t ToIndex(const GameState* g, int v) {
+    if (v == kNoVertex) return static_cast<std::uint64_t>(-1);
+    if (v == kPassMove) return static_cast<std::uint64_t>(g->GetNumIntersections());
+    if (v == kResignMove) return static_cast<std::uint64_t>(-2);
+    return static_cast<std::uint64_t>(g->VertexToIndex(v));
+}
+} // namespace
+
+extern "C" {
+
+void* sayuri_go_new(int board, float komi, int scoring) {
+    auto* g = new GameState();
+    g->Reset(board, komi, scoring);
+    return g;
+}
+void* sayuri_go_clone(void* h) { return new GameState(*G(h)); }
+void sayuri_go_free(void* h) { delete G(h); }
+int sayuri_go_play(void* h, int move, int color) {
+    auto* g = G(h);
+    return g->PlayMove(ToVertex(g, move), color < 0 ? g->GetToMove() : color) ? 1 : 0;
+}
+int sayuri_go_append(void* h, int move, int color) { return G(h)->AppendMove(ToVertex(G(h), move), color) ? 1 : 0; }
+int sayuri_go_undo(void* h) { return G(h)->UndoMove() ? 1 : 0; }
+int sayuri_go_fixed_handicap(void* h, int n) { return G(h)->SetFixedHandicap(n) ? 1 : 0; }
+void sayuri_go_set_komi(void* h, float komi) { G(h)->SetKomi(komi); }
+void sayuri_go_set_rule(void* h, int scoring) { G(h)->SetRule(scoring); }
+void sayuri_go_set_to_move(void* h, int color) { G(h)->SetToMove(color); }
+void sayuri_go_freeze(void* h) { G(h)->Freeze(); }
+
+// info[0..15] -- same fields as the oracle tap ref_game_info (oracle/ref_game_driver.cc)
+void sayuri_go_info(void* h, std::uint64_t* info) {
+    auto* g = G(h);
+    info[0] = g->GetHash();
+    info[1] = g->GetKoHash();
+    info[2] = static_cast<std::uint64_t>(g->GetToMove());
+    info[3] = ToIndex(g, g->GetLastMove());
+    info[4] = ToIndex(g, g->GetKoMove());
+    info[5] = static_cast<std::uint64_t>(g->GetPasses());
+    info[6] = static_cast<std::uint64_t>(g->GetPrisoner(kBlack));
+    info[7] = static_cast<std::uint64_t>(g->GetPrisoner(kWhite));
+    info[8] = static_cast<std::uint64_t>(g->GetMoveNumber());
+    info[9] = g->IsSuperko();
+    info[10] = g->IsGameOver();
+    info[11] = static_cast<std::uint64_t>(g->GetHandicap());
+    info[12] = static_cast<std::uint64_t>(g->GetWinner());
+    info[13] = static_cast<std::uint64_t>(g->GetBoardSize());
+    info[14] = static_cast<std::uint64_t>(g->GetScoringRule());
+    std::uint64_t x = 0;
+    for (int s = 0; s < 8; ++s) x ^= g->ComputeSymmetryHash(s) * static_cast<std::uint64_t>(2 * s + 1);
+    info[15] = x;
+}
+
+void sayuri_go_scalars(void* h, float* out) {
+    auto* g = G(h);
+    out[0] = g->GetKomi();
+    out[1] = g->GetKomiWithPenalty();
+    out[2] = g->GetWave();
+    out[3] = g->GetFinalScore(kBlack);
+    out[4] = g->GetPenalty();
+    out[5] = g->GetPenaltyOffset(kAreaScoring, kTerritoryScoring);
+}
+
+int sayuri_go_planes(void* h, int symmetry, int weights_version, float* out) {
+    Encoder::Planes(*G(h), symmetry, weights_version, out);
+    return Encoder::InputChannels(weights_version) * G(h)->GetNumIntersections();
+}
+
+void sayuri_go_maps(void* h, std::uint8_t* out) {
+    auto* g = G(h);
+    const Position& b = g->board_;
+    const int n = g->GetNumIntersections();
+    const int c = g->GetToMove();
+    std::memset(out, 0, static_cast<size_t>(9 * (n + 1)));
+    std::uint8_t ladders[kMaxPoints];
+    b.LadderMap(ladders);
+    auto safe = g->GetStrictSafeArea();
+    auto own = g->GetOwnership();
+    auto raw = g->GetRawOwnership();
+    for (int i = 0; i < n; ++i) {
+        const int v = g->IndexToVertex(i);
+        const int s = b.At(v);
+        out[0 * (n + 1) + i] = static_cast<std::uint8_t>(s);
+        out[1 * (n + 1) + i] = g->IsLegalMove(v, c);
+        out[2 * (n + 1) + i] = (s == kBlack || s == kWhite) ? static_cast<std::uint8_t>(std::min(b.Liberties(v), 255)) : 0;
+        out[3 * (n + 1) + i] = ladders[i];
+        out[4 * (n + 1) + i] = safe[static_cast<size_t>(i)];
+        out[5 * (n + 1) + i] = static_cast<std::uint8_t>(own[static_cast<size_t>(i)]);
+        out[6 * (n + 1) + i] = static_cast<std::uint8_t>(raw[static_cast<size_t>(i)]);
+        out[7 * (n + 1) + i] = g->IsSeki(v);
+        std::uint8_t t = 0;
+        if (s == kEmpty) {
+            t |= b.IsCaptureMove(v, c) ? 1 : 0;
+            t |= b.IsAtariMove(v, c) ? 2 : 0;
+            t |= b.IsEscapeMove(v, c) ? 4 : 0;
+            t |= b.IsSelfAtariMove(v, c) ? 8 : 0;
+            t |= b.IsRealEye(v, c) ? 16 : 0;
+            t |= b.IsSimpleEye(v, c) ? 32 : 0;
+        }
+        out[8 * (n + 1) + i] = t;
+    }
+    out[1 * (n + 1) + n] = 1;
+}
+
+void sayuri_go_rng_stream(std::uint64_t seed, int n, std::uint32_t range, double prob, std::uint64_t* out) {
+    Rng rng(seed);
+    for (int i = 0; i < n; ++i) out[i] = rng.Next();
+    for (int i = 0; i < n; ++i) out[n + i] = rng.Below(range);
+    for (int i = 0; i < n; ++i) out[2 * n + i] = rng.Chance(prob);
+}
+void sayuri_go_set_territory_helper_from_ownership(void* h) { G(h)->SetTerritoryHelper(G(h)->GetOwnership()); }
+
+} // extern "C"

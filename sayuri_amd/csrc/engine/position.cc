@@ -1,0 +1,974 @@
+#include "position.h"
+
+#include <algorithm>
+#include <memory>
+
+namespace sayuri_go {
+
+namespace {
+constexpr int kNoChain = kMaxVertices; // sentinel slot of next_/head_/libs_/stones_
+constexpr int kBlackShift = 0, kWhiteShift = 4, kEmptyShift = 8;
+constexpr int kLadderNodeLimit = 2000; // reference types.h:73
+enum LadderVerdict { kHunterWins = 0, kPreyWins = 1, kLadderOpen = 2 };
+
+inline bool Contains(const int* buf, int n, int v) {
+    for (int i = 0; i < n; ++i)
+        if (buf[i] == v) return true;
+    return false;
+}
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+void Position::Reset(int board_size) {
+    board_size = std::min(std::max(board_size, kMinBoard), kMaxBoard);
+    size_ = static_cast<std::int16_t>(board_size);
+    letter_ = static_cast<std::int16_t>(board_size + 2);
+    points_ = static_cast<std::int16_t>(board_size * board_size);
+    vertices_ = static_cast<std::int16_t>(letter_ * letter_);
+
+    for (int v = 0; v < kMaxVertices; ++v) {
+        cell_[v] = kWall;
+        nbr_[v] = 0;
+    }
+    for (int y = 0; y < size_; ++y) {
+        for (int x = 0; x < size_; ++x) {
+            const int v = Vertex(x, y);
+            cell_[v] = kEmpty;
+            // per axis: an edge has one wall (counted as a black and a white neighbour) and one empty
+            // neighbour, an interior cell has two empty neighbours
+            const bool xe = (x == 0 || x == size_ - 1), ye = (y == 0 || y == size_ - 1);
+            const int wall = (1 << kBlackShift) | (1 << kWhiteShift) | (1 << kEmptyShift);
+            nbr_[v] = static_cast<std::uint16_t>((xe ? wall : (2 << kEmptyShift)) + (ye ? wall : (2 << kEmptyShift)));
+        }
+    }
+    for (int v = 0; v <= kMaxVertices; ++v) {
+        next_[v] = head_[v] = kNoChain;
+        libs_[v] = stones_[v] = 0;
+    }
+    libs_[kNoChain] = 16384;
+
+    prisoners_[0] = prisoners_[1] = 0;
+    played_[0] = played_[1] = 0;
+    ko_move_ = last_move_ = last_move2_ = kNoVertex;
+    to_move_ = kBlack;
+    passes_ = 0;
+    const int l = letter_;
+    const int d[8] = {-l, -1, +1, +l, -l - 1, -l + 1, +l - 1, +l + 1};
+    for (int k = 0; k < 8; ++k) dir_[k] = static_cast<std::int16_t>(d[k]);
+
+    const ZobristKeys& z = ZobristKeys::Get();
+    ko_hash_ = ZobristKeys::kEmptyBoard;
+    for (int v = 0; v < vertices_; ++v)
+        if (cell_[v] != kWall) ko_hash_ ^= z.state[cell_[v]][v];
+    hash_ = ko_hash_ ^ ZobristKeys::kBlackToMove ^ z.prisoner[kBlack][0] ^ z.prisoner[kWhite][0] ^ z.pass[0] ^
+            z.ko[kNoVertex];
+}
+
+std::uint64_t Position::SymmetryKoHash(int symm) const {
+    const ZobristKeys& z = ZobristKeys::Get();
+    const SymmetryTables& t = SymmetryTables::Get();
+    std::uint64_t h = ZobristKeys::kEmptyBoard;
+    for (int v = 0; v < vertices_; ++v)
+        if (cell_[v] != kWall) h ^= z.state[cell_[v]][t.Vertex(size_, symm, v)];
+    return h;
+}
+
+std::uint64_t Position::SymmetryHash(int symm) const {
+    const ZobristKeys& z = ZobristKeys::Get();
+    std::uint64_t h = SymmetryKoHash(symm);
+    if (to_move_ == kBlack) h ^= ZobristKeys::kBlackToMove;
+    h ^= z.prisoner[kBlack][prisoners_[kBlack]] ^ z.prisoner[kWhite][prisoners_[kWhite]] ^ z.pass[passes_];
+    h ^= z.ko[SymmetryTables::Get().Vertex(size_, symm, ko_move_)];
+    return h;
+}
+
+std::uint64_t Position::MoveHash(int v, int c) const {
+    std::uint64_t h = ZobristKeys::Get().state[c][v];
+    if (c == to_move_) h ^= ZobristKeys::kBlackToMove;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+void Position::SetToMove(int c) {
+    if (c != to_move_) hash_ ^= ZobristKeys::kBlackToMove;
+    to_move_ = static_cast<std::int16_t>(c);
+}
+
+void Position::PlaceStone(int v, int c) {
+    const ZobristKeys& z = ZobristKeys::Get();
+    cell_[v] = static_cast<std::uint8_t>(c);
+    const std::uint64_t dz = z.state[kEmpty][v] ^ z.state[c][v];
+    hash_ ^= dz;
+    ko_hash_ ^= dz;
+    int seen[4], ns = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        nbr_[a] = static_cast<std::uint16_t>(nbr_[a] + (1 << (4 * c)) - (1 << kEmptyShift));
+        const int h = head_[a];
+        if (!Contains(seen, ns, h)) { // every distinct neighbouring chain loses this liberty once
+            libs_[h]--;
+            seen[ns++] = h;
+        }
+    }
+}
+
+void Position::LiftStone(int v, int c) {
+    const ZobristKeys& z = ZobristKeys::Get();
+    cell_[v] = kEmpty;
+    const std::uint64_t dz = z.state[kEmpty][v] ^ z.state[c][v];
+    hash_ ^= dz;
+    ko_hash_ ^= dz;
+    int seen[4], ns = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        nbr_[a] = static_cast<std::uint16_t>(nbr_[a] + (1 << kEmptyShift) - (1 << (4 * c)));
+        const int h = head_[a];
+        if (!Contains(seen, ns, h)) {
+            libs_[h]++;
+            seen[ns++] = h;
+        }
+    }
+}
+
+void Position::Merge(int keep, int gone) {
+    // liberties of `gone` that `keep` does not touch yet, then splice the two rings
+    stones_[keep] = static_cast<std::uint16_t>(stones_[keep] + stones_[gone]);
+    int p = gone;
+    do {
+        for (int k = 0; k < 4; ++k) {
+            const int a = p + dir_[k];
+            if (cell_[a] != kEmpty) continue;
+            bool shared = false;
+            for (int kk = 0; kk < 4; ++kk) {
+                if (head_[a + dir_[kk]] == keep) {
+                    shared = true;
+                    break;
+                }
+            }
+            if (!shared) libs_[keep]++;
+        }
+        head_[p] = static_cast<std::uint16_t>(keep);
+        p = next_[p];
+    } while (p != gone);
+    std::swap(next_[gone], next_[keep]);
+}
+
+int Position::RemoveChain(int v) {
+    const int c = cell_[v];
+    int p = v, n = 0;
+    do {
+        LiftStone(p, c);
+        head_[p] = kNoChain;
+        ++n;
+        p = next_[p];
+    } while (p != v);
+    return n;
+}
+
+void Position::AddPrisoners(int c, int n) {
+    const ZobristKeys& z = ZobristKeys::Get();
+    hash_ ^= z.prisoner[c][prisoners_[c]];
+    prisoners_[c] += n;
+    hash_ ^= z.prisoner[c][prisoners_[c]];
+}
+
+int Position::PutAndResolve(int v, int c) {
+    PlaceStone(v, c);
+    next_[v] = head_[v] = static_cast<std::uint16_t>(v);
+    libs_[v] = static_cast<std::uint16_t>(EmptyNeighbours(v));
+    stones_[v] = 1;
+
+    const bool in_opp_eye = IsSimpleEye(v, Opp(c));
+    int captured = 0, captured_at = kNoVertex;
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        const int s = cell_[a];
+        if (s == Opp(c)) {
+            if (libs_[head_[a]] == 0) {
+                captured += RemoveChain(a);
+                captured_at = a;
+            }
+        } else if (s == c) {
+            const int mine = head_[v], other = head_[a];
+            if (mine != other) {
+                if (stones_[mine] >= stones_[other]) Merge(mine, other);
+                else Merge(other, mine);
+            }
+        }
+    }
+    if (libs_[head_[v]] == 0) AddPrisoners(Opp(c), RemoveChain(v)); // suicide (never legal, kept for parity)
+    if (captured) AddPrisoners(c, captured);
+    return (captured == 1 && in_opp_eye) ? captured_at : kNoVertex;
+}
+
+void Position::Play(int v, int c) {
+    const ZobristKeys& z = ZobristKeys::Get();
+    SetToMove(c);
+    const int old_ko = ko_move_;
+    if (v == kPassMove) {
+        const int np = std::min(passes_ + 1, 4);
+        hash_ ^= z.pass[passes_] ^ z.pass[np];
+        passes_ = static_cast<std::int16_t>(np);
+        ko_move_ = kNoVertex;
+    } else {
+        if (passes_ != 0) {
+            hash_ ^= z.pass[passes_] ^ z.pass[0];
+            passes_ = 0;
+        }
+        ko_move_ = static_cast<std::int16_t>(PutAndResolve(v, c));
+        played_[c] += 1;
+    }
+    if (ko_move_ != old_ko) hash_ ^= z.ko[old_ko] ^ z.ko[ko_move_];
+    last_move2_ = last_move_;
+    last_move_ = static_cast<std::int16_t>(v);
+    to_move_ ^= 1;
+    hash_ ^= ZobristKeys::kBlackToMove;
+}
+
+void Position::RemoveMarked(const int* vertices, int n) {
+    int removed[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int c = cell_[vertices[i]];
+        if (c == kBlack || c == kWhite) removed[c] += RemoveChain(vertices[i]);
+    }
+    AddPrisoners(kBlack, removed[kWhite]);
+    AddPrisoners(kWhite, removed[kBlack]);
+}
+
+// ---------------------------------------------------------------------------------------------
+bool Position::IsSuicide(int v, int c) const {
+    if (EmptyNeighbours(v)) return false;
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        const int l = libs_[head_[a]];
+        if (cell_[a] == c && l > 1) return false;       // joins a chain that keeps a liberty
+        if (cell_[a] == Opp(c) && l <= 1) return false; // captures
+    }
+    return true;
+}
+
+bool Position::IsLegal(int v, int c) const {
+    if (v == kPassMove || v == kResignMove) return true;
+    if (cell_[v] != kEmpty) return false;
+    if (IsSuicide(v, c)) return false;
+    return v != ko_move_;
+}
+
+bool Position::IsSimpleEye(int v, int c) const { return (nbr_[v] & (4 << (4 * c))) != 0; }
+
+bool Position::IsRealEye(int v, int c) const {
+    if (cell_[v] != kEmpty || !IsSimpleEye(v, c)) return false;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int k = 4; k < 8; ++k) cnt[cell_[v + dir_[k]]]++;
+    return cnt[kWall] == 0 ? cnt[Opp(c)] <= 1 : cnt[Opp(c)] == 0;
+}
+
+bool Position::IsCaptureMove(int v, int c) const {
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        if (cell_[a] == Opp(c) && libs_[head_[a]] == 1) return true;
+    }
+    return false;
+}
+
+bool Position::IsAtariMove(int v, int c) const {
+    if (IsSuicide(v, c)) return false;
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        if (cell_[a] == Opp(c) && libs_[head_[a]] == 2) return true;
+    }
+    return false;
+}
+
+bool Position::IsEscapeMove(int v, int c) const { return !IsSuicide(v, c) && IsCaptureMove(v, Opp(c)); }
+
+bool Position::IsSelfAtariMove(int v, int c) const {
+    int own = EmptyNeighbours(v);
+    int buf[kMaxPoints + 1], n = 0;
+    buf[n++] = v;
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        if (cell_[a] == c) ChainLiberties(a, buf, n);
+        else if (cell_[a] == Opp(c) && libs_[head_[a]] <= 1) own += 1;
+    }
+    return (n - 1) + own == 1;
+}
+
+bool Position::IsNeighbourColor(int v, int c) const {
+    for (int k = 0; k < 4; ++k)
+        if (cell_[v + dir_[k]] == c) return true;
+    return false;
+}
+
+bool Position::IsAdjacent(int a, int b) const {
+    for (int k = 0; k < 4; ++k)
+        if (a + dir_[k] == b) return true;
+    return false;
+}
+
+int Position::ChainMembers(int v, int* out) const {
+    const int start = head_[v];
+    int p = start, n = 0;
+    do {
+        out[n++] = p;
+        p = next_[p];
+    } while (p != start);
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ladder reading.
+int Position::ChainLiberties(int v, int* buf, int& n) const {
+    int found = 0, p = v;
+    do {
+        for (int k = 0; k < 4; ++k) {
+            const int a = p + dir_[k];
+            if (cell_[a] == kEmpty && !Contains(buf, n, a)) {
+                buf[n++] = a;
+                ++found;
+            }
+        }
+        p = next_[p];
+    } while (p != v);
+    return found;
+}
+
+int Position::CaptureGainLiberties(int v, int* buf, int& n) const {
+    const int opp = Opp(cell_[v]);
+    int found = 0, p = v;
+    do {
+        for (int k = 0; k < 4; ++k) {
+            const int a = p + dir_[k];
+            if (cell_[a] == opp && libs_[head_[a]] == 1) found += ChainLiberties(a, buf, n);
+        }
+        p = next_[p];
+    } while (p != v);
+    return found;
+}
+
+void Position::LadderLibertyBounds(int v, int c, int& lo, int& hi) const {
+    const int own = EmptyNeighbours(v);
+    int captures = 0, capture_gain = 0, connect_sum = 0, connect_max = own;
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        if (cell_[a] == c) {
+            const int l = libs_[head_[a]] - 1;
+            connect_sum += l;
+            connect_max = std::max(connect_max, l);
+        } else if (cell_[a] == Opp(c)) {
+            if (libs_[head_[a]] == 1) {
+                ++captures;
+                capture_gain += stones_[head_[a]];
+            }
+        }
+    }
+    lo = captures + connect_max;
+    hi = own + capture_gain + connect_sum;
+}
+
+int Position::PreyCandidates(int prey, int target, int* sel, int& n, bool think_ko) const {
+    n = 0;
+    // two liberties: escaped. A pending simple ko after the hunter's move also counts as escaped, so that
+    // ko-dependent ladders never read as working (and the recursion cannot loop).
+    if (libs_[head_[target]] >= 2 || (ko_move_ != kNoVertex && think_ko)) return kPreyWins;
+    ChainLiberties(target, sel, n);
+    const int extend = sel[0];
+    CaptureGainLiberties(target, sel, n);
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (IsLegal(sel[i], prey)) sel[m++] = sel[i];
+    n = m;
+    if (n == 0) return kHunterWins;
+    if (Contains(sel, n, extend)) {
+        int lo, hi;
+        LadderLibertyBounds(extend, prey, lo, hi);
+        if (lo >= 3) return kPreyWins;
+        if (n == 1 && hi == 1) return kHunterWins;
+    }
+    return kLadderOpen;
+}
+
+int Position::HunterCandidates(int prey, int target, int* sel, int& n) const {
+    n = 0;
+    const int l = libs_[head_[target]];
+    if (l >= 3) return kPreyWins;
+    if (l <= 1) return kHunterWins;
+    int lib[kMaxPoints], nl = 0;
+    ChainLiberties(target, lib, nl);
+    const int a = lib[0], b = lib[1], hunter = Opp(prey);
+    if (!IsAdjacent(a, b)) {
+        const int la = EmptyNeighbours(a), lb = EmptyNeighbours(b);
+        if (la >= 3 && lb >= 3) return kPreyWins;
+        if (la >= 3) {
+            if (IsLegal(a, hunter)) sel[n++] = a;
+        } else if (lb >= 3) {
+            if (IsLegal(b, hunter)) sel[n++] = b;
+        } else {
+            if (IsLegal(a, hunter)) sel[n++] = a;
+            if (IsLegal(b, hunter)) sel[n++] = b;
+        }
+    } else {
+        sel[n++] = a;
+        sel[n++] = b;
+    }
+    return n == 0 ? kPreyWins : kLadderOpen;
+}
+
+int Position::PreyTurn(Position& b, int hunter_move, int prey, int target, int& nodes) const {
+    if (++nodes >= kLadderNodeLimit) return kPreyWins;
+    if (hunter_move != kNoVertex) b.Play(hunter_move, Opp(prey));
+    int sel[kMaxPoints], n;
+    int verdict = b.PreyCandidates(prey, target, sel, n, hunter_move != kNoVertex);
+    if (verdict != kLadderOpen) return verdict;
+    for (int i = 0; i < n; ++i) {
+        if (n == 1) {
+            verdict = HunterTurn(b, sel[i], prey, target, nodes); // forced line: continue in place
+        } else {
+            auto fork = std::make_unique<Position>(b);
+            verdict = HunterTurn(*fork, sel[i], prey, target, nodes);
+        }
+        if (verdict == kPreyWins) break;
+    }
+    return verdict;
+}
+
+int Position::HunterTurn(Position& b, int prey_move, int prey, int target, int& nodes) const {
+    if (++nodes >= kLadderNodeLimit) return kPreyWins;
+    if (prey_move != kNoVertex) b.Play(prey_move, prey);
+    int sel[4], n;
+    int verdict = b.HunterCandidates(prey, target, sel, n);
+    if (verdict != kLadderOpen) return verdict;
+    for (int i = 0; i < n; ++i) {
+        if (n == 1) {
+            verdict = PreyTurn(b, sel[i], prey, target, nodes);
+        } else {
+            auto fork = std::make_unique<Position>(b);
+            verdict = PreyTurn(*fork, sel[i], prey, target, nodes);
+        }
+        if (verdict == kHunterWins) break;
+    }
+    return verdict;
+}
+
+bool Position::IsLadder(int v, int* vital, int* num_vital) const {
+    *num_vital = 0;
+    if (v == kPassMove) return false;
+    const int prey = cell_[v];
+    if (prey == kEmpty || prey == kWall) return false;
+    int lib[kMaxPoints], nl = 0;
+    ChainLiberties(v, lib, nl);
+    int nodes = 0;
+    if (nl == 1) {
+        Position work = *this;
+        if (PreyTurn(work, kNoVertex, prey, v, nodes) == kHunterWins) vital[(*num_vital)++] = lib[0];
+    } else if (nl == 2) {
+        for (int i = 0; i < 2; ++i) {
+            Position work = *this;
+            if (!work.IsLegal(lib[i], Opp(prey))) continue;
+            // the hunter ataris first
+            if (PreyTurn(work, lib[i], prey, v, nodes) == kHunterWins) vital[(*num_vital)++] = lib[i];
+        }
+    }
+    return *num_vital > 0;
+}
+
+void Position::LadderMap(std::uint8_t* out) const {
+    std::memset(out, kLadderNone, points_);
+    std::uint8_t verdict[kMaxVertices + 1]; // per chain head: 0 unknown, 1 ladder, 2 not a ladder
+    std::memset(verdict, 0, sizeof(verdict));
+    for (int idx = 0; idx < points_; ++idx) {
+        const int v = IndexToVertex(idx);
+        if (cell_[v] == kEmpty) continue;
+        const int h = head_[v];
+        int vital[2], nv = 0;
+        bool first = false;
+        if (verdict[h] == 0) {
+            if (IsLadder(v, vital, &nv)) {
+                verdict[h] = 1;
+                first = true;
+            } else {
+                verdict[h] = 2;
+            }
+        }
+        if (verdict[h] != 1) continue;
+        const int l = libs_[h];
+        out[idx] = (l == 1) ? kLadderDeath : kLadderEscapable;
+        if (first)
+            for (int i = 0; i < nv; ++i) out[VertexToIndex(vital[i])] = (l == 1) ? kLadderTake : kLadderAtari;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Areas.
+int Position::ReachGroup(int start, int spread, bool* seen) const {
+    int queue[kMaxVertices], qh = 0, qt = 0, n = 1;
+    seen[start] = true;
+    queue[qt++] = start;
+    while (qh < qt) {
+        const int v = queue[qh++];
+        for (int k = 0; k < 4; ++k) {
+            const int a = v + dir_[k];
+            if (!seen[a] && cell_[a] == spread) {
+                seen[a] = true;
+                queue[qt++] = a;
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
+void Position::ReachArea(int* out) const {
+    // Tromp-Taylor: a point belongs to a colour when it is that colour or reaches only that colour through empties
+    bool reach[2][kMaxVertices];
+    for (int c = 0; c < 2; ++c) {
+        std::memset(reach[c], 0, sizeof(reach[c]));
+        int queue[kMaxVertices], qh = 0, qt = 0;
+        for (int i = 0; i < points_; ++i) {
+            const int v = IndexToVertex(i);
+            if (cell_[v] == c) {
+                reach[c][v] = true;
+                queue[qt++] = v;
+            }
+        }
+        while (qh < qt) {
+            const int v = queue[qh++];
+            for (int k = 0; k < 4; ++k) {
+                const int a = v + dir_[k];
+                if (!reach[c][a] && cell_[a] == kEmpty) {
+                    reach[c][a] = true;
+                    queue[qt++] = a;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        out[i] = (reach[kBlack][v] && !reach[kWhite][v]) ? kBlack : (reach[kWhite][v] && !reach[kBlack][v]) ? kWhite : kEmpty;
+    }
+}
+
+void Position::ScoreArea(int* out, int scoring, const int* helper) const {
+    if (scoring == kTerritoryScoring) {
+        // stones the helper assigns to the other side are dead: lift them, then score by area
+        Position fork = *this;
+        int dead[kMaxPoints], nd = 0;
+        for (int i = 0; i < points_; ++i) {
+            const int v = IndexToVertex(i);
+            if ((helper[i] == kBlack && cell_[v] == kWhite) || (helper[i] == kWhite && cell_[v] == kBlack)) dead[nd++] = v;
+        }
+        fork.RemoveMarked(dead, nd);
+        fork.ScoreArea(out, kAreaScoring, helper);
+        return;
+    }
+    ReachArea(out);
+    bool alive[kMaxPoints];
+    for (int c = 0; c < 2; ++c) {
+        std::memset(alive, 0, sizeof(alive));
+        PassAliveArea(alive, c, true, true);
+        for (int i = 0; i < points_; ++i)
+            if (alive[i]) out[i] = c;
+    }
+}
+
+int Position::ScoreOnBoard(int color, int scoring, const int* helper) const {
+    int area[kMaxPoints], lead = 0;
+    ScoreArea(area, scoring, helper);
+    for (int i = 0; i < points_; ++i) lead += (area[i] == kBlack) - (area[i] == kWhite);
+    return color == kBlack ? lead : -lead;
+}
+
+void Position::SafeArea(bool* out, bool mark_seki) const {
+    std::memset(out, 0, points_ * sizeof(bool));
+    PassAliveArea(out, kBlack, true, true);
+    PassAliveArea(out, kWhite, true, true);
+    if (mark_seki)
+        for (int i = 0; i < points_; ++i)
+            if (IsSeki(IndexToVertex(i))) out[i] = true;
+}
+
+// Connected groups of one feature value: ring links, group ids (from 1, 0 = on board but other value,
+// -1 = off board), heads in scan order.  Ring order is fixed: members ascending, each linking to its
+// predecessor, the lowest vertex linking to the highest (the order the reference's classification yields).
+struct Position::Groups {
+    std::int16_t id[kMaxVertices];
+    std::uint16_t next[kMaxVertices];
+    std::uint16_t heads[kMaxPoints];
+    int count;
+};
+
+void Position::Classify(int target, const std::uint8_t* feat, Groups& g) const {
+    for (int v = 0; v < kMaxVertices; ++v) {
+        g.id[v] = -1;
+        g.next[v] = kNoVertex;
+    }
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        g.id[v] = 0;
+        g.next[v] = static_cast<std::uint16_t>(v);
+    }
+    g.count = 0;
+    int stack[kMaxVertices];
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        if (g.id[v] != 0 || feat[v] != target) continue;
+        const int gid = ++g.count;
+        g.heads[gid - 1] = static_cast<std::uint16_t>(v);
+        int sp = 0;
+        stack[sp++] = v;
+        g.id[v] = static_cast<std::int16_t>(gid);
+        while (sp) {
+            const int p = stack[--sp];
+            for (int k = 0; k < 4; ++k) {
+                const int a = p + dir_[k];
+                if (g.id[a] == 0 && feat[a] == target) {
+                    g.id[a] = static_cast<std::int16_t>(gid);
+                    stack[sp++] = a;
+                }
+            }
+        }
+    }
+    // link every group's members in ascending vertex order
+    std::uint16_t last[kMaxPoints + 1];
+    std::memset(last, 0, sizeof(last));
+    for (int v = 0; v < vertices_; ++v) {
+        const int gid = g.id[v];
+        if (gid <= 0) continue;
+        if (last[gid]) g.next[v] = last[gid];
+        last[gid] = static_cast<std::uint16_t>(v);
+    }
+    for (int k = 0; k < g.count; ++k) g.next[g.heads[k]] = last[k + 1];
+}
+
+bool Position::ChainPassAlive(int v, const bool* vital, const Groups& regions, const Groups& chains) const {
+    // Benson: a chain is unconditionally alive when at least two vital regions have all their empty points
+    // adjacent to it
+    const int me = chains.id[v];
+    int first = -1;
+    int p = v;
+    do {
+        for (int k = 0; k < 4; ++k) {
+            const int a = p + dir_[k];
+            if (!vital[a]) continue;
+            bool all_adjacent = true;
+            int r = a;
+            do {
+                if (cell_[r] == kEmpty) {
+                    bool adj = false;
+                    for (int kk = 0; kk < 4; ++kk) {
+                        if (chains.id[r + dir_[kk]] == me) {
+                            adj = true;
+                            break;
+                        }
+                    }
+                    if (!adj) {
+                        all_adjacent = false;
+                        break;
+                    }
+                }
+                r = regions.next[r];
+            } while (r != a);
+            if (all_adjacent) {
+                const int rid = regions.id[a];
+                if (first < 0) first = rid;
+                else if (rid != first) return true; // second distinct vital region
+            }
+        }
+        p = chains.next[p];
+    } while (p != v);
+    return false;
+}
+
+void Position::InnerRegions(int v, int c, const Groups& regions, bool* inner) const {
+    // groups of the complement of this region that do not touch the edge are enclosed by it
+    std::uint8_t surround[kMaxVertices];
+    std::memset(surround, kWall, sizeof(surround));
+    std::memset(inner, 0, kMaxVertices * sizeof(bool));
+    for (int i = 0; i < points_; ++i) surround[IndexToVertex(i)] = kEmpty;
+    int p = v;
+    do {
+        surround[p] = static_cast<std::uint8_t>(Opp(c));
+        p = regions.next[p];
+    } while (p != v);
+
+    auto rest = std::make_unique<Groups>();
+    Classify(kEmpty, surround, *rest);
+    int cnt = rest->count;
+    // NOTE: after dropping an edge-touching group the scan advances past the group that slid into its slot;
+    // that group is kept without being tested (reference board.cc:2078-2097).  Kept for identical planes.
+    for (int i = 0; i < cnt; ++i) {
+        const int h = rest->heads[i];
+        bool edge = false;
+        p = h;
+        do {
+            for (int k = 0; k < 4; ++k) {
+                if (surround[p + dir_[k]] == kWall) {
+                    edge = true;
+                    break;
+                }
+            }
+            if (edge) break;
+            p = rest->next[p];
+        } while (p != h);
+        if (edge) {
+            for (int j = i; j + 1 < rest->count; ++j) rest->heads[j] = rest->heads[j + 1];
+            cnt -= 1;
+        }
+    }
+    for (int i = 0; i < cnt; ++i) {
+        const int h = rest->heads[i];
+        p = h;
+        do {
+            inner[p] = true;
+            p = rest->next[p];
+        } while (p != h);
+    }
+}
+
+bool Position::RegionPassDead(int v, int c, const std::uint8_t* feat, const Groups& regions) const {
+    // `c` tries to live inside this region; it needs two separate potential eyes
+    bool inner[kMaxVertices];
+    InnerRegions(v, c, regions, inner);
+    int eyes[kMaxPoints], ne = 0;
+    int p = v;
+    do {
+        bool eye = cell_[p] != c; // own stones cannot become own eyes (suicide is forbidden)
+        if (eye) {
+            int side[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4; ++k) side[feat[p + dir_[k]]]++;
+            if (side[Opp(c)] != 0) eye = false;
+        }
+        if (eye) {
+            int corner[4] = {0, 0, 0, 0};
+            for (int k = 4; k < 8; ++k) {
+                const int a = p + dir_[k];
+                corner[inner[a] ? c : feat[a]]++;
+            }
+            if (corner[kWall] == 0 ? corner[Opp(c)] > 1 : corner[Opp(c)] > 0) eye = false;
+        }
+        if (eye) eyes[ne++] = p;
+        p = regions.next[p];
+    } while (p != v);
+    if (ne == 2 && IsAdjacent(eyes[0], eyes[1])) ne = 1;
+    return ne < 2;
+}
+
+void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_pass_dead) const {
+    std::uint8_t occ[kMaxVertices];
+    std::memset(occ, kWall, sizeof(occ));
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        occ[v] = cell_[v] == color ? static_cast<std::uint8_t>(color) : static_cast<std::uint8_t>(kEmpty);
+    }
+    auto regions = std::make_unique<Groups>();
+    auto chains = std::make_unique<Groups>();
+    Classify(kEmpty, occ, *regions);
+    const int region_count = regions->count;
+    std::uint16_t region_heads[kMaxPoints];
+    std::memcpy(region_heads, regions->heads, sizeof(region_heads));
+
+    // potentially vital regions: every empty point touches a `color` stone (enemy stones inside are fine)
+    bool vital[kMaxVertices];
+    std::memset(vital, 0, sizeof(vital));
+    for (int r = 0; r < region_count; ++r) {
+        const int h = region_heads[r];
+        bool ok = true;
+        int p = h;
+        do {
+            if (cell_[p] == kEmpty) {
+                bool touch = false;
+                for (int k = 0; k < 4; ++k) {
+                    if (occ[p + dir_[k]] == color) {
+                        touch = true;
+                        break;
+                    }
+                }
+                if (!touch) {
+                    ok = false;
+                    break;
+                }
+            }
+            p = regions->next[p];
+        } while (p != h);
+        if (ok) {
+            p = h;
+            do {
+                vital[p] = true;
+                p = regions->next[p];
+            } while (p != h);
+        }
+    }
+
+    Classify(color, occ, *chains);
+    int alive_count = chains->count;
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (int i = 0; i < alive_count; ++i) {
+            const int h = chains->heads[i];
+            if (ChainPassAlive(h, vital, *regions, *chains)) continue;
+            // drop the chain; the regions it touches stop being vital
+            int p = h;
+            do {
+                chains->id[p] = 0;
+                occ[p] = kEmpty;
+                for (int k = 0; k < 4; ++k) {
+                    const int a = p + dir_[k];
+                    if (vital[a]) {
+                        int r = a;
+                        do {
+                            vital[r] = false;
+                            r = regions->next[r];
+                        } while (r != a);
+                    }
+                }
+                p = chains->next[p];
+            } while (p != h);
+            for (int j = i; j + 1 < alive_count; ++j) chains->heads[j] = chains->heads[j + 1];
+            alive_count -= 1;
+            changed = true;
+            break;
+        }
+    }
+
+    for (int i = 0; i < alive_count; ++i) {
+        const int h = chains->heads[i];
+        int p = h;
+        do {
+            out[VertexToIndex(p)] = true;
+            p = chains->next[p];
+        } while (p != h);
+    }
+    if (mark_vitals) {
+        for (int r = 0; r < region_count; ++r) {
+            const int h = region_heads[r];
+            int p = h;
+            do {
+                if (vital[p]) {
+                    out[VertexToIndex(p)] = true;
+                    occ[p] = static_cast<std::uint8_t>(color);
+                }
+                p = regions->next[p];
+            } while (p != h);
+        }
+    }
+    if (mark_pass_dead) {
+        Classify(kEmpty, occ, *regions);
+        for (int r = 0; r < regions->count; ++r) {
+            const int h = regions->heads[r];
+            if (!RegionPassDead(h, Opp(color), occ, *regions)) continue;
+            int p = h;
+            do {
+                out[VertexToIndex(p)] = true;
+                p = regions->next[p];
+            } while (p != h);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Seki.
+void Position::ChainSurround(int v, int c, int* libbuf, int& nl, int* chainbuf, int& nc) const {
+    int p = v;
+    do {
+        for (int k = 0; k < 4; ++k) {
+            const int a = p + dir_[k];
+            if (cell_[a] == kEmpty) {
+                if (!Contains(libbuf, nl, a)) libbuf[nl++] = a;
+            } else if (cell_[a] == Opp(c)) {
+                if (!Contains(chainbuf, nc, head_[a])) chainbuf[nc++] = head_[a];
+            }
+        }
+        p = next_[p];
+    } while (p != v);
+}
+
+bool Position::IsSeki(int v) const {
+    if (cell_[v] != kEmpty) return false;
+    int chain[2] = {kNoVertex, kNoVertex};
+    for (int k = 0; k < 4; ++k) {
+        const int a = v + dir_[k];
+        const int s = cell_[a];
+        if (s == kBlack || s == kWhite) {
+            if (chain[s] == kNoVertex) chain[s] = head_[a];
+            else if (chain[s] != head_[a]) return false; // one chain per colour
+        }
+    }
+    for (int c = 0; c < 2; ++c)
+        if (chain[c] == kNoVertex || libs_[chain[c]] != 2) return false;
+
+    int lib[kMaxPoints], nl = 0, around_b[kMaxPoints], nb = 0, around_w[kMaxPoints], nw = 0;
+    ChainSurround(chain[kBlack], kBlack, lib, nl, around_b, nb);
+    ChainSurround(chain[kWhite], kWhite, lib, nl, around_w, nw);
+    if (nl == 3) return true; // shared liberty plus one private liberty each (includes false seki)
+
+    int inner = kWall;
+    if (nb == 1) inner = kBlack;
+    else if (nw == 1) inner = kWhite;
+    if (inner == kWall) return true; // plain two-liberty seki without eyes
+
+    // the inner chain plus this point form an eye space of the outer side: seki unless that shape is killable
+    std::uint16_t eye_next[kMaxVertices];
+    std::memset(eye_next, 0, sizeof(eye_next));
+    int eye_size = 1;
+    int nxt = chain[inner], pos;
+    do {
+        pos = nxt;
+        nxt = next_[nxt];
+        eye_next[pos] = static_cast<std::uint16_t>(nxt);
+        ++eye_size;
+    } while (nxt != chain[inner]);
+    eye_next[pos] = static_cast<std::uint16_t>(v);
+    eye_next[v] = static_cast<std::uint16_t>(nxt);
+    return !KillableSekiEye(v, eye_size, eye_next);
+}
+
+bool Position::KillableSekiEye(int v, int eye_size, const std::uint16_t* eye_next) const {
+    if (eye_size <= 3) return true;
+    if (eye_size >= 7) return false;
+    bool in_eye[kMaxVertices];
+    std::memset(in_eye, 0, sizeof(in_eye));
+    int border = 0, p = v;
+    do {
+        in_eye[p] = true;
+        if (IsBorder(p)) ++border;
+        p = eye_next[p];
+    } while (p != v);
+
+    // nakade points: cells that touch (8-neighbourhood) every other cell of the eye and leave diagonal eyes
+    int nakade = 0;
+    int first_eye_cnt = 0, first_eye_vtx = kNoVertex;
+    p = v;
+    do {
+        int touch = 0, diag[4], nd = 0;
+        for (int k = 0; k < 8; ++k) {
+            const int a = p + dir_[k];
+            if (in_eye[a]) {
+                ++touch;
+                if (k >= 4) diag[nd++] = a;
+            }
+        }
+        if (touch + 1 == eye_size && nd > 0) {
+            if (nakade == 0) {
+                first_eye_cnt = nd;
+                first_eye_vtx = diag[0];
+            }
+            ++nakade;
+        }
+        p = eye_next[p];
+    } while (p != v);
+    if (nakade == 0) return false;
+
+    auto sides_in_eye = [&](int e) {
+        int n = 0;
+        for (int k = 0; k < 4; ++k) n += in_eye[e + dir_[k]] ? 1 : 0;
+        return n;
+    };
+    const bool bulky = first_eye_cnt == 1 && sides_in_eye(first_eye_vtx) == 2;
+    if (eye_size == 4) return border == 4 || bulky;      // bent four in the corner, squared four
+    if (eye_size == 5) return bulky;                      // bulky five
+    if (nakade == 1) return bulky;                        // rabbitty six
+    if (nakade == 2) return border == 4;                  // rectangular six in the corner
+    return false;
+}
+
+} // namespace sayuri_go
