@@ -77,16 +77,22 @@ const char* ref_last_error() { return g_err.c_str(); }
 
 // Load a weights file with the reference loader.  winograd=0 => "--no-winograd".
 // Returns 0 on success, -1 when the reference refused the file.
+// Build the reference's option map / tables once (ArgsParser, config.cc:336-381).
+int ref_ensure_args(int winograd) {
+    if (!g_args_ready) {
+        std::vector<std::string> args = {"sayuri", "--quiet", "-t", "1", "-p", "1"};
+        if (!winograd) args.emplace_back("--no-winograd");
+        std::vector<char*> argv;
+        for (auto& a : args) argv.push_back(a.data());
+        ArgsParser(static_cast<int>(argv.size()), argv.data());
+        g_args_ready = true;
+    }
+    return 0;
+}
+
 int ref_init(const char* weights_path, int winograd) {
     try {
-        if (!g_args_ready) {
-            std::vector<std::string> args = {"sayuri", "--quiet", "-t", "1", "-p", "1"};
-            if (!winograd) args.emplace_back("--no-winograd");
-            std::vector<char*> argv;
-            for (auto& a : args) argv.push_back(a.data());
-            ArgsParser(static_cast<int>(argv.size()), argv.data());
-            g_args_ready = true;
-        }
+        ref_ensure_args(winograd);
         SetOption("winograd", static_cast<bool>(winograd));
         g_weights = std::make_shared<DNNWeights>();
         DNNLoader::Get().FromFile(g_weights, weights_path);

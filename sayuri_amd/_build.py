@@ -19,6 +19,10 @@ LIB = os.path.join(PKG, "lib")
 HIP_SRC = os.path.join(PKG, "csrc", "hip")
 HOST_SRC = os.path.join(PKG, "csrc", "host")
 ENGINE_SRC = os.path.join(PKG, "csrc", "engine")
+# The evaluation post-processing and the tree-search arithmetic are built with the floating-point flags of the
+# reference's own build (CMakeLists.txt:192-203: -O3 -ffast-math, here with x86-64-v3 instead of -march=native) so
+# that a fixed-seed search rounds like the reference binary does.
+FASTMATH_UNITS = {"network.cc", "tree.cc", "search.cc", "search_params.cc"}
 HIP_SO = os.path.join(LIB, "libsayuri_hip.so")
 HOST_SO = os.path.join(LIB, "libsayuri_host.so")
 
@@ -67,7 +71,10 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, os.path.basename(os.path.dirname(src)) + "_" + os.path.basename(src)[:-3] + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
-            jobs.append(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-I" + HOST_SRC, "-I" + ENGINE_SRC,
+            opt = ["-O2"]
+            if os.path.basename(src) in FASTMATH_UNITS:
+                opt = ["-O3", "-ffast-math", "-march=x86-64-v3"]
+            jobs.append(["g++", "-std=c++17"] + opt + ["-fPIC", "-Wall", "-Wextra", "-I" + HOST_SRC, "-I" + ENGINE_SRC,
                          "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
     if jobs:
         if verbose:

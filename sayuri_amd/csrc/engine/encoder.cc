@@ -46,12 +46,9 @@ void Encoder::Planes(const GameState& state, int symmetry, int weights_version, 
     } else {
         // pass-alive area by owner, then Tromp-Taylor area by owner; nothing under territory scoring
         if (state.GetScoringRule() != kTerritoryScoring) {
-            int owner[kMaxPoints], helper[kMaxPoints];
-            std::fill(helper, helper + kMaxPoints, static_cast<int>(kEmpty));
+            int owner[kMaxPoints];
             bool safe[kMaxPoints];
-            for (int i = 0; i < n; ++i) helper[i] = kEmpty;
-            b.ScoreArea(owner, kAreaScoring, helper);
-            b.SafeArea(safe, false);
+            b.ScoreAndSafeArea(owner, safe);
             for (int i = 0; i < n; ++i) {
                 if (safe[i]) {
                     if (owner[i] == me) area[i] = 1.f;

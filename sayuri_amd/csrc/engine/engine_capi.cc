@@ -1,0 +1,162 @@
+// C entry points of the evaluation facade and the tree search for the Python face and the parity tests.
+// Result layouts match the oracle taps of oracle/ref_search_driver.cc field for field.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <string>
+
+#include "engine_options.h"
+#include "search.h"
+
+using namespace sayuri_engine;
+using sayuri_go::kNoVertex;
+using sayuri_go::kPassMove;
+using sayuri_go::kResignMove;
+
+namespace {
+
+// A NetworkForwardPipe that forwards to a C function: parity tests plug the reference's CPU pipe in here
+// (tests only -- the product backend is HipForwardPipe).
+// out: prob[N], own[N], pass, wdl[3], stm, score, q_err, score_err   (N = board_size^2, raw network outputs)
+using ForwardFn = int (*)(int board_size, float komi, int side_to_move, int offset, const float* planes, float* out);
+
+class CallbackPipe : public sayuri_host::NetworkForwardPipe {
+public:
+    explicit CallbackPipe(ForwardFn fn) : fn_(fn) {}
+    void Initialize(std::shared_ptr<sayuri_host::DNNWeights>) override {}
+    OutputResult Forward(const InputData& in) override {
+        const int n = in.board_size * in.board_size;
+        float out[2 * sayuri_go::kMaxPoints + 8];
+        fn_(in.board_size, in.komi, in.side_to_move, static_cast<int>(in.offset), in.planes.data(), out);
+        OutputResult r;
+        r.board_size = in.board_size;
+        r.komi = in.komi;
+        r.offset = in.offset;
+        std::memcpy(r.probabilities.data(), out, sizeof(float) * static_cast<size_t>(n));
+        std::memcpy(r.ownership.data(), out + n, sizeof(float) * static_cast<size_t>(n));
+        const float* s = out + 2 * n;
+        r.pass_probability = s[0];
+        r.wdl = {s[1], s[2], s[3]};
+        r.stm_winrate = s[4];
+        r.final_score = s[5];
+        r.q_error = s[6];
+        r.score_error = s[7];
+        return r;
+    }
+    void Construct(sayuri_host::ForwardPipeOption, std::shared_ptr<sayuri_host::DNNWeights>) override {}
+    void Release() override {}
+    void Destroy() override {}
+    bool Valid() const override { return fn_ != nullptr; }
+
+private:
+    ForwardFn fn_;
+};
+
+int MoveToIndex(const GameState& g, int v) {
+    if (v == kNoVertex) return -3;
+    if (v == kPassMove) return g.GetNumIntersections();
+    if (v == kResignMove) return -1;
+    return g.VertexToIndex(v);
+}
+
+void Export(const GameState& g, const ComputationResult& r, int* ints, float* floats, int* visits, float* estq,
+            float* target, float* own) {
+    const int n = g.GetNumIntersections();
+    ints[0] = MoveToIndex(g, r.best_move);
+    ints[1] = MoveToIndex(g, r.best_no_pass_move);
+    ints[2] = MoveToIndex(g, r.random_move);
+    ints[3] = MoveToIndex(g, r.gumbel_move);
+    ints[4] = MoveToIndex(g, r.gumbel_no_pass_move);
+    ints[5] = MoveToIndex(g, r.capture_all_dead_move);
+    ints[6] = MoveToIndex(g, r.high_priority_move);
+    ints[7] = r.visits;
+    ints[8] = r.playouts;
+    ints[9] = r.to_move;
+    ints[10] = r.side_resign;
+    floats[0] = r.root_eval;
+    floats[1] = r.root_score_lead;
+    floats[2] = r.best_eval;
+    floats[3] = r.root_score_stddev;
+    floats[4] = r.root_eval_stddev;
+    floats[5] = r.policy_kld;
+    if (static_cast<int>(r.root_searched_visits.size()) == n + 1) {
+        for (int i = 0; i <= n; ++i) {
+            visits[i] = r.root_searched_visits[static_cast<size_t>(i)];
+            estq[i] = r.root_estimated_q[static_cast<size_t>(i)];
+            target[i] = r.target_policy_dist[static_cast<size_t>(i)];
+        }
+        for (int i = 0; i < n; ++i) own[i] = r.root_ownership[static_cast<size_t>(i)];
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// options: "key=value key=value ..." (names of the reference's option map, engine_options.h)
+void* sayuri_engine_net_new_callback(void* forward_fn, int weights_version, const char* options) {
+    EngineOptions opt;
+    opt.Parse(options ? options : "");
+    auto* net = new Network();
+    std::shared_ptr<NetworkForwardPipe> pipe;
+    if (forward_fn) pipe = std::make_shared<CallbackPipe>(reinterpret_cast<ForwardFn>(forward_fn));
+    net->Initialize(pipe, weights_version, opt.network);
+    return net;
+}
+void sayuri_engine_net_free(void* n) { delete static_cast<Network*>(n); }
+unsigned long sayuri_engine_net_queries(void* n) { return static_cast<Network*>(n)->GetNumQueries(); }
+
+void sayuri_engine_net_output(void* n, void* game, int ensemble, int symmetry, float temperature, int use_cache,
+                              std::uint64_t seed, float* out) {
+    auto* g = static_cast<GameState*>(game);
+    Rng rng(seed);
+    auto q = Network::Query::Get().SetTemperature(temperature).SetSymmetry(symmetry).SetCache(use_cache != 0);
+    auto r = static_cast<Network*>(n)->GetOutput(*g, static_cast<Network::Ensemble>(ensemble), q, rng);
+    const int N = g->GetNumIntersections();
+    std::memcpy(out, r.probabilities.data(), sizeof(float) * static_cast<size_t>(N));
+    std::memcpy(out + N, r.ownership.data(), sizeof(float) * static_cast<size_t>(N));
+    float* s = out + 2 * N;
+    s[0] = r.pass_probability;
+    s[1] = r.wdl[0];
+    s[2] = r.wdl[1];
+    s[3] = r.wdl[2];
+    s[4] = r.wdl_winrate;
+    s[5] = r.stm_winrate;
+    s[6] = r.final_score;
+    s[7] = r.q_error;
+    s[8] = r.score_error;
+}
+
+void* sayuri_engine_search_new(void* game, void* net, const char* options) {
+    EngineOptions opt;
+    opt.Parse(options ? options : "");
+    return new Search(*static_cast<GameState*>(game), *static_cast<Network*>(net), opt.search);
+}
+void sayuri_engine_search_free(void* s) { delete static_cast<Search*>(s); }
+void sayuri_engine_search_seed(void* s, std::uint64_t caller_seed, std::uint64_t playout_seed) {
+    static_cast<Search*>(s)->Seed(caller_seed, playout_seed);
+}
+void sayuri_engine_search_computation(void* s, void* game, int playouts, int tag, int* ints, float* floats, int* visits,
+                                      float* estq, float* target, float* own) {
+    auto r = static_cast<Search*>(s)->Computation(playouts, tag);
+    Export(*static_cast<GameState*>(game), r, ints, floats, visits, estq, target, own);
+}
+int sayuri_engine_search_selfplay_move(void* s, void* game, int tag) {
+    return MoveToIndex(*static_cast<GameState*>(game), static_cast<Search*>(s)->GetSelfPlayMove(tag));
+}
+int sayuri_engine_search_think(void* s, void* game) {
+    return MoveToIndex(*static_cast<GameState*>(game), static_cast<Search*>(s)->ThinkBestMove());
+}
+void sayuri_engine_search_update_territory_helper(void* s) { static_cast<Search*>(s)->UpdateTerritoryHelper(); }
+long sayuri_engine_search_gather(void* s, char* buf, long cap) {
+    std::vector<TrainingData> chunk;
+    static_cast<Search*>(s)->GatherTrainingBuffer(chunk);
+    std::ostringstream oss;
+    for (auto& d : chunk) d.StreamOut(oss);
+    const std::string str = oss.str();
+    if (static_cast<long>(str.size()) <= cap) std::memcpy(buf, str.data(), str.size());
+    return static_cast<long>(str.size());
+}
+
+} // extern "C"

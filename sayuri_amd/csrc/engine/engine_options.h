@@ -1,0 +1,38 @@
+// Engine options as "key=value" text, with the names of the reference's option map (src/config.cc:21-133)
+// so a settings file written for the reference reads the same here.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "network.h"
+#include "search_params.h"
+
+namespace sayuri_engine {
+
+struct SelfplayOptions {
+    int num_games{0};
+    int parallel_games{1};
+    float komi_stddev{0.f};
+    float komi_big_stddev{0.f};
+    float komi_big_stddev_prob{0.f};
+    float handicap_fair_komi_prob{0.f};
+    float random_opening_prob{0.f};
+    float random_opening_temp{1.f};
+    int default_boardsize{19};
+    float default_komi{7.5f};
+    int scoring_rule{0};
+    std::vector<std::string> selfplay_queries; // "bkp:19:7.5:0.2", "bhp:9:2:0.1", "srs:area:territory"
+    std::string target_directory;
+    std::uint64_t seed{0}; // 0 = from the clock
+};
+
+struct EngineOptions {
+    SearchParams search;
+    NetworkOptions network;
+    SelfplayOptions selfplay;
+    // Parses whitespace-separated key=value pairs; unknown keys throw std::invalid_argument.
+    void Parse(const std::string& text);
+};
+
+} // namespace sayuri_engine

@@ -54,7 +54,7 @@ void GameState::Reset(int boardsize, float komi, int scoring) {
     winner_ = kUndecided;
     handicap_ = 0;
     move_number_ = 0;
-    territory_helper_.assign(static_cast<size_t>(GetNumIntersections()), kEmpty);
+    territory_helper_.fill(kEmpty);
 }
 
 void GameState::SetBoardSize(int boardsize) { Reset(boardsize, GetKomi(), GetScoringRule()); }
@@ -184,8 +184,8 @@ bool GameState::PlayHandicapStones(const std::vector<int>& vertices, bool kata_l
     return true;
 }
 
-float GameState::GetFinalScore(int color, const std::vector<int>& territory_helper) const {
-    const float black = static_cast<float>(board_.ScoreOnBoard(kBlack, scoring_, territory_helper.data())) - GetKomiWithPenalty();
+float GameState::FinalScoreWith(int color, const int* territory_helper) const {
+    const float black = static_cast<float>(board_.ScoreOnBoard(kBlack, scoring_, territory_helper)) - GetKomiWithPenalty();
     return color == kBlack ? black : -black;
 }
 

@@ -8,6 +8,7 @@
 // of 0.4 KB frames -- so forking a state for a playout costs one Position memcpy and one pointer copy.
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -59,12 +60,14 @@ public:
     void SetWinner(int w) { winner_ = w; }
     void SetRule(int scoring);
     void SetHandicap(int h) { handicap_ = h; }
-    void SetTerritoryHelper(const std::vector<int>& ownership) { territory_helper_ = ownership; }
+    void SetTerritoryHelper(const std::vector<int>& ownership) {
+        for (size_t i = 0; i < ownership.size() && i < territory_helper_.size(); ++i) territory_helper_[i] = ownership[i];
+    }
     bool SetFixedHandicap(int handicap); // game_state.cc:394-452
     bool PlayHandicapStones(const std::vector<int>& vertices, bool kata_like_style); // game_state.cc:476-505
 
-    float GetFinalScore(int color) const { return GetFinalScore(color, territory_helper_); }
-    float GetFinalScore(int color, const std::vector<int>& territory_helper) const;
+    float GetFinalScore(int color) const { return FinalScoreWith(color, territory_helper_.data()); }
+    float GetFinalScore(int color, const std::vector<int>& territory_helper) const { return FinalScoreWith(color, territory_helper.data()); }
     std::vector<bool> GetStrictSafeArea() const;
     std::vector<int> GetOwnership() const;    // pass-alive aware Tromp-Taylor owner per intersection
     std::vector<int> GetRawOwnership() const; // plain Tromp-Taylor reach
@@ -102,7 +105,6 @@ public:
     std::uint64_t GetHash() const { return board_.Hash() ^ komi_hash_ ^ scoring_hash_; }
     std::uint64_t ComputeSymmetryHash(int symm) const { return board_.SymmetryHash(symm) ^ komi_hash_ ^ scoring_hash_; }
     std::uint64_t GetMoveHash(int vtx, int color) const { return board_.MoveHash(vtx, color); }
-    const std::vector<int>& GetTerritoryHelper() const { return territory_helper_; }
 
     int GetVertex(int x, int y) const { return board_.Vertex(x, y); }
     int GetIndex(int x, int y) const { return board_.Index(x, y); }
@@ -125,10 +127,11 @@ public:
 
 private:
     void PushFrame(int vtx, int color);
+    float FinalScoreWith(int color, const int* territory_helper) const;
 
     FrameLog log_; // log_[i] = board after move i (0 = start position incl. set-up stones)
     std::vector<std::pair<int, int>> setup_; // AppendMove stones
-    std::vector<int> territory_helper_;
+    std::array<int, kMaxPoints> territory_helper_; // inline: forking a state allocates nothing
     std::uint8_t scoring_ = kAreaScoring;
     int handicap_ = 0;
     int komi_integer_ = 0;

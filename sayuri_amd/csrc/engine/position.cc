@@ -571,6 +571,22 @@ void Position::ScoreArea(int* out, int scoring, const int* helper) const {
     }
 }
 
+void Position::ScoreAndSafeArea(int* owner, bool* safe) const {
+    ReachArea(owner);
+    std::memset(safe, 0, points_ * sizeof(bool));
+    bool alive[kMaxPoints];
+    for (int c = 0; c < 2; ++c) {
+        std::memset(alive, 0, sizeof(alive));
+        PassAliveArea(alive, c, true, true);
+        for (int i = 0; i < points_; ++i) {
+            if (alive[i]) {
+                owner[i] = c;
+                safe[i] = true;
+            }
+        }
+    }
+}
+
 int Position::ScoreOnBoard(int color, int scoring, const int* helper) const {
     int area[kMaxPoints], lead = 0;
     ScoreArea(area, scoring, helper);

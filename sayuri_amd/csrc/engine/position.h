@@ -86,6 +86,9 @@ public:
     void ReachArea(int* out) const;                                            // board.cc:1547-1579
     void ScoreArea(int* out, int scoring, const int* territory_helper) const;  // board.cc:1581-1616
     void SafeArea(bool* out, bool mark_seki) const;                            // board.cc:1706-1718
+    // Area-scoring owner map and safe area in one pass (each colour's Benson analysis runs once; the two
+    // separate calls above would run it twice each).  Same results as ScoreArea(kAreaScoring) + SafeArea(false).
+    void ScoreAndSafeArea(int* owner, bool* safe) const;
     int ScoreOnBoard(int color, int scoring, const int* territory_helper) const; // board.cc:1526-1545
     void PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_pass_dead) const; // board.cc:1720-1901
     int ReachGroup(int start, int spread, bool* seen /*[NumVertices]*/) const;  // board.cc:264-300
