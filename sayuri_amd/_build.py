@@ -83,7 +83,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(16, len(jobs))) as ex:
             list(ex.map(subprocess.check_call, jobs))
     if jobs or force or _newer(HOST_SO, objs + [HIP_SO]):
-        cmd = ["g++", "-shared", "-o", HOST_SO] + objs + ["-L" + LIB, "-lsayuri_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        cmd = ["g++", "-shared", "-o", HOST_SO] + objs + ["-L" + LIB, "-lsayuri_hip", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lz"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

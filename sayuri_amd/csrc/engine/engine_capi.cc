@@ -8,6 +8,7 @@
 
 #include "engine_options.h"
 #include "search.h"
+#include "selfplay.h"
 
 using namespace sayuri_engine;
 using sayuri_go::kNoVertex;
@@ -16,19 +17,24 @@ using sayuri_go::kResignMove;
 
 namespace {
 
-// A NetworkForwardPipe that forwards to a C function: parity tests plug the reference's CPU pipe in here
-// (tests only -- the product backend is HipForwardPipe).
-// out: prob[N], own[N], pass, wdl[3], stm, score, q_err, score_err   (N = board_size^2, raw network outputs)
-using ForwardFn = int (*)(int board_size, float komi, int side_to_move, int offset, const float* planes, float* out);
+// A NetworkForwardPipe that forwards to a C function: parity tests plug a CPU pipe in here (tests only -- the
+// product backend is HipForwardPipe).  Two shapes are accepted:
+//   kind 0: fn(board_size, komi, side_to_move, offset, planes, out)        e.g. the oracle tap ref_forward
+//   kind 1: fn(user, board_size, komi, offset, planes, out)                e.g. the oracle port so_forward
+// out: prob[N], own[N], pass, wdl[3], stm, score, q_err, score_err, offset   (N = board_size^2, raw outputs)
+using ForwardFn0 = int (*)(int, float, int, int, const float*, float*);
+using ForwardFn1 = int (*)(const void*, int, float, int, const float*, float*);
 
 class CallbackPipe : public sayuri_host::NetworkForwardPipe {
 public:
-    explicit CallbackPipe(ForwardFn fn) : fn_(fn) {}
+    CallbackPipe(void* fn, int kind, const void* user) : fn_(fn), kind_(kind), user_(user) {}
     void Initialize(std::shared_ptr<sayuri_host::DNNWeights>) override {}
     OutputResult Forward(const InputData& in) override {
         const int n = in.board_size * in.board_size;
-        float out[2 * sayuri_go::kMaxPoints + 8];
-        fn_(in.board_size, in.komi, in.side_to_move, static_cast<int>(in.offset), in.planes.data(), out);
+        float out[2 * sayuri_go::kMaxPoints + 16];
+        const int offset = static_cast<int>(in.offset);
+        if (kind_ == 0) reinterpret_cast<ForwardFn0>(fn_)(in.board_size, in.komi, in.side_to_move, offset, in.planes.data(), out);
+        else reinterpret_cast<ForwardFn1>(fn_)(user_, in.board_size, in.komi, offset, in.planes.data(), out);
         OutputResult r;
         r.board_size = in.board_size;
         r.komi = in.komi;
@@ -50,7 +56,9 @@ public:
     bool Valid() const override { return fn_ != nullptr; }
 
 private:
-    ForwardFn fn_;
+    void* fn_;
+    int kind_;
+    const void* user_;
 };
 
 int MoveToIndex(const GameState& g, int v) {
@@ -95,12 +103,12 @@ void Export(const GameState& g, const ComputationResult& r, int* ints, float* fl
 extern "C" {
 
 // options: "key=value key=value ..." (names of the reference's option map, engine_options.h)
-void* sayuri_engine_net_new_callback(void* forward_fn, int weights_version, const char* options) {
+void* sayuri_engine_net_new_callback(void* forward_fn, int kind, const void* user, int weights_version, const char* options) {
     EngineOptions opt;
     opt.Parse(options ? options : "");
     auto* net = new Network();
     std::shared_ptr<NetworkForwardPipe> pipe;
-    if (forward_fn) pipe = std::make_shared<CallbackPipe>(reinterpret_cast<ForwardFn>(forward_fn));
+    if (forward_fn) pipe = std::make_shared<CallbackPipe>(forward_fn, kind, user);
     net->Initialize(pipe, weights_version, opt.network);
     return net;
 }
@@ -149,6 +157,42 @@ int sayuri_engine_search_think(void* s, void* game) {
     return MoveToIndex(*static_cast<GameState*>(game), static_cast<Search*>(s)->ThinkBestMove());
 }
 void sayuri_engine_search_update_territory_helper(void* s) { static_cast<Search*>(s)->UpdateTerritoryHelper(); }
+// Self-play on a forward pipe (raw = sayuri_pipe_raw(handle); NULL = the dummy random-output backend).
+// stats[10] = games_started, games_done, moves, playouts, nn_queries, cache_lookups, cache_hits, records,
+// chunks_saved, 0.  Returns 0, or -1 with the message in sayuri_engine_last_error().
+static thread_local std::string g_engine_err;
+const char* sayuri_engine_last_error() { return g_engine_err.c_str(); }
+int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
+                        int move_cap, std::uint64_t* stats, double* elapsed) {
+    try {
+        EngineOptions opt;
+        opt.Parse(options ? options : "");
+        std::shared_ptr<NetworkForwardPipe> pipe;
+        if (raw_pipe) pipe = std::shared_ptr<NetworkForwardPipe>(static_cast<NetworkForwardPipe*>(raw_pipe), [](NetworkForwardPipe*) {});
+        SelfplayPipe sp(pipe, weights_version, opt, name_suffix ? name_suffix : "");
+        sp.engine().move_cap = move_cap;
+        const SelfplayStats st = sp.Run(seconds);
+        const std::uint64_t v[10] = {st.games_started, st.games_done, st.moves, st.playouts, st.nn_queries,
+                                     st.cache_lookups, st.cache_hits, st.records, st.chunks_saved, 0};
+        std::memcpy(stats, v, sizeof(v));
+        *elapsed = st.elapsed;
+        return 0;
+    } catch (const std::exception& e) {
+        g_engine_err = e.what();
+        return -1;
+    }
+}
+
+// The network evaluation facade on a forward pipe (for GPU parity tests of search moves).
+void* sayuri_engine_net_new_pipe(void* raw_pipe, int weights_version, const char* options) {
+    EngineOptions opt;
+    opt.Parse(options ? options : "");
+    auto* net = new Network();
+    std::shared_ptr<NetworkForwardPipe> pipe(static_cast<NetworkForwardPipe*>(raw_pipe), [](NetworkForwardPipe*) {});
+    net->Initialize(pipe, weights_version, opt.network);
+    return net;
+}
+
 long sayuri_engine_search_gather(void* s, char* buf, long cap) {
     std::vector<TrainingData> chunk;
     static_cast<Search*>(s)->GatherTrainingBuffer(chunk);

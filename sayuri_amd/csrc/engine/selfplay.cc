@@ -1,0 +1,441 @@
+#include "selfplay.h"
+
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <ctime>
+#include <fstream>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+
+namespace sayuri_engine {
+
+using sayuri_go::kAreaScoring;
+using sayuri_go::kBlack;
+using sayuri_go::kPassMove;
+using sayuri_go::kTerritoryScoring;
+using sayuri_go::kWhite;
+
+namespace {
+bool IsZeroKomi(float v) { return std::abs(v) < 1e-4f; }
+
+std::vector<std::string> SplitColon(std::string s) {
+    for (char& c : s)
+        if (c == ':') c = ' ';
+    std::istringstream in(s);
+    std::vector<std::string> out;
+    for (std::string w; in >> w;) out.push_back(w);
+    return out;
+}
+
+bool DirExists(const std::string& d) {
+    struct stat st;
+    return stat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+void MakeDir(const std::string& d) {
+    if (!DirExists(d)) mkdir(d.c_str(), 0755);
+}
+std::string NowString() {
+    char buf[64];
+    const std::time_t t = std::time(nullptr);
+    std::strftime(buf, sizeof(buf), "%Y-%m-%d-%H:%M:%S", std::localtime(&t));
+    return buf;
+}
+} // namespace
+
+float AdjustKomiToHalf(float komi) {
+    // round to the nearest half point, keeping the sign
+    if (IsZeroKomi(komi)) return 0;
+    const bool negative = komi < 0.0f;
+    if (negative) komi = -komi;
+    const int whole = static_cast<int>(komi);
+    float frac = komi - whole;
+    frac = frac < 0.25f ? 0.f : frac < 0.75f ? 0.5f : 1.f;
+    komi = frac + whole;
+    if (negative && !IsZeroKomi(komi)) komi = -komi;
+    return komi;
+}
+
+// ---------------------------------------------------------------------------------------------
+SelfplayEngine::SelfplayEngine(std::shared_ptr<NetworkForwardPipe> pipe, int weights_version, const EngineOptions& opt)
+    : opt_(opt) {
+    network_.Initialize(std::move(pipe), weights_version, opt_.network);
+    const int games = std::max(1, opt_.selfplay.parallel_games);
+    std::uint64_t seed = opt_.selfplay.seed;
+    if (seed == 0) seed = static_cast<std::uint64_t>(std::chrono::steady_clock::now().time_since_epoch().count());
+    for (int g = 0; g < games; ++g) {
+        auto slot = std::make_unique<Slot>();
+        slot->state.Reset(opt_.selfplay.default_boardsize, opt_.selfplay.default_komi, opt_.selfplay.scoring_rule);
+        slot->search = std::make_unique<Search>(slot->state, network_, opt_.search);
+        // two independent streams per game, all derived from one seed
+        slot->search->Seed(seed + 2 * static_cast<std::uint64_t>(g) + 1, seed + 2 * static_cast<std::uint64_t>(g) + 2);
+        slots_.push_back(std::move(slot));
+    }
+    ParseQueries();
+}
+
+SelfplayEngine::Slot& SelfplayEngine::At(int g) {
+    if (g < 0 || g >= GetParallelGames()) throw std::runtime_error("The game index is out of array.");
+    return *slots_[static_cast<size_t>(g)];
+}
+
+std::uint64_t SelfplayEngine::playouts() const {
+    std::uint64_t n = 0;
+    for (const auto& s : slots_) n += s->search->total_playouts();
+    return n;
+}
+
+void SelfplayEngine::ParseQueries() {
+    float total = 0.f;
+    for (const auto& q : opt_.selfplay.selfplay_queries) {
+        const auto w = SplitColon(q);
+        if (w.empty()) break;
+        if (w[0] == "bkp" && w.size() == 4) { // board : komi : probability
+            BoardQuery b{std::stoi(w[1]), std::stof(w[2]), std::stof(w[3])};
+            board_queries_.push_back(b);
+            total += b.prob;
+        } else if (w[0] == "bhp" && w.size() == 4) { // board : max handicap : probability
+            HandicapQuery h{std::stoi(w[1]), std::stoi(w[2]), std::stof(w[3])};
+            if (h.handicaps >= 2) handicap_queries_.push_back(h);
+        } else if (w[0] == "srs") { // scoring rule set
+            for (size_t i = 1; i < w.size(); ++i) scoring_set_.push_back(w[i] == "territory" ? kTerritoryScoring : kAreaScoring);
+        }
+    }
+    if (board_queries_.empty()) {
+        board_queries_.push_back({opt_.selfplay.default_boardsize, opt_.selfplay.default_komi, 1.f});
+    } else {
+        for (auto& q : board_queries_) q.prob /= total;
+    }
+    if (scoring_set_.empty()) scoring_set_.push_back(kAreaScoring);
+    const bool has_territory = std::find(scoring_set_.begin(), scoring_set_.end(), kTerritoryScoring) != scoring_set_.end();
+    const bool has_area = std::find(scoring_set_.begin(), scoring_set_.end(), kAreaScoring) != scoring_set_.end();
+    if (has_territory && !has_area) scoring_set_.push_back(kTerritoryScoring); // as the reference does (engine.cc:163-168)
+    std::sort(scoring_set_.begin(), scoring_set_.end());
+    scoring_set_.erase(std::unique(scoring_set_.begin(), scoring_set_.end()), scoring_set_.end());
+}
+
+void SelfplayEngine::PrepareGame(int g) {
+    Slot& s = At(g);
+    Rng& rng = s.search->caller_rng();
+    s.state.ClearBoard();
+    s.state.SetRule(kAreaScoring);
+    s.comments.clear();
+
+    constexpr std::uint32_t kRange = 1000000;
+    const std::uint32_t pick = rng.Below(kRange);
+    float acc = 0.f;
+    size_t chosen = 0;
+    for (size_t i = 0; i < board_queries_.size(); ++i) {
+        acc += board_queries_[i].prob;
+        if (pick <= kRange * acc) {
+            chosen = i;
+            break;
+        }
+    }
+    auto rules = scoring_set_;
+    std::shuffle(rules.begin(), rules.end(), rng);
+    s.state.Reset(board_queries_[chosen].board_size, board_queries_[chosen].komi, rules.front());
+    const int h = GetHandicaps(g);
+    if (h > 0) SetHandicapGame(g, h);
+    else SetNormalGame(g);
+}
+
+int SelfplayEngine::GetHandicaps(int g) {
+    Slot& s = At(g);
+    Rng& rng = s.search->caller_rng();
+    for (const auto& q : handicap_queries_) {
+        if (s.state.GetBoardSize() == q.board_size && rng.Chance(q.prob))
+            return static_cast<int>(rng.Next() % static_cast<std::uint64_t>(q.handicaps - 1)) + 2;
+    }
+    return 0;
+}
+
+void SelfplayEngine::SetNormalGame(int g) {
+    if (At(g).search->caller_rng().Chance(opt_.selfplay.random_opening_prob)) SetRandomOpeningGame(g);
+    SetUnfairKomi(g);
+}
+
+void SelfplayEngine::SetHandicapGame(int g, int handicaps) {
+    Slot& s = At(g);
+    Rng& rng = s.search->caller_rng();
+    // handicap stones go where the policy would put them
+    for (int i = 0; i < handicaps - 1; ++i) {
+        s.state.SetToMove(kBlack);
+        const int move = network_.GetVertexWithPolicy(s.state, 0.8f, false, rng);
+        s.state.AppendMove(move, kBlack);
+    }
+    s.state.SetHandicap(handicaps);
+    SetFairKomi(g);
+    if (rng.Chance(opt_.selfplay.random_opening_prob)) SetRandomOpeningGame(g);
+    if (!rng.Chance(opt_.selfplay.handicap_fair_komi_prob)) SetUnfairKomi(g);
+}
+
+void SelfplayEngine::SetRandomOpeningGame(int g) {
+    Slot& s = At(g);
+    Rng& rng = s.search->caller_rng();
+    const int bs = s.state.GetBoardSize();
+    const int random_moves = static_cast<int>(opt_.search.random_moves_factor * s.state.GetNumIntersections());
+    std::normal_distribution<float> dist(0.f, static_cast<float>(bs) / 4);
+    const int remaining = std::max(static_cast<int>(dist(rng)) + random_moves - s.state.GetMoveNumber(), 0);
+    const float lambda = 0.69314718056f / bs;
+    int times = 0;
+    for (int i = 0; i < remaining; ++i) {
+        if (s.state.GetPasses() >= 2) break;
+        const float temp = std::max(opt_.selfplay.random_opening_temp * std::exp(-(lambda * times)), 0.8f);
+        s.state.PlayMove(network_.GetVertexWithPolicy(s.state, temp, false, rng));
+        s.comments.emplace_back();
+        times += 1;
+    }
+    SetFairKomi(g);
+}
+
+void SelfplayEngine::SetUnfairKomi(int g) {
+    Slot& s = At(g);
+    Rng& rng = s.search->caller_rng();
+    float stddev = opt_.selfplay.komi_stddev;
+    if (rng.Chance(opt_.selfplay.komi_big_stddev_prob)) stddev = opt_.selfplay.komi_big_stddev;
+    std::normal_distribution<float> dist(0.f, stddev);
+    const float bonus = dist(rng);
+    s.state.SetKomi(AdjustKomiToHalf(s.state.GetKomi() + bonus));
+}
+
+void SelfplayEngine::SetFairKomi(int g) {
+    Slot& s = At(g);
+    const auto result = s.search->Computation(opt_.search.playouts, Search::kNoExploring);
+    float lead = result.root_score_lead;
+    if (s.state.GetToMove() == kWhite) lead = 0.0f - lead;
+    s.state.SetKomi(AdjustKomiToHalf(s.state.GetKomi() + lead));
+}
+
+bool SelfplayEngine::Step(int g) {
+    Slot& s = At(g);
+    if (s.state.IsGameOver()) return false;
+    int move = s.search->GetSelfPlayMove();
+    if (move_cap > 0 && s.state.GetMoveNumber() >= move_cap) move = kPassMove;
+    s.state.PlayMove(move);
+    s.comments.resize(static_cast<size_t>(s.state.GetMoveNumber()) + 1);
+    s.comments[static_cast<size_t>(s.state.GetMoveNumber())] = s.search->last_comment();
+    moves_.fetch_add(1, std::memory_order_relaxed);
+    return !s.state.IsGameOver();
+}
+
+void SelfplayEngine::Selfplay(int g) {
+    while (Step(g)) {
+    }
+    At(g).search->UpdateTerritoryHelper();
+}
+
+void SelfplayEngine::GatherTrainingData(std::vector<TrainingData>& chunk, int g) { At(g).search->GatherTrainingBuffer(chunk); }
+
+std::string SelfplayEngine::GatherSgfString(int g) {
+    Slot& s = At(g);
+    GameState& st = s.state;
+    std::ostringstream out;
+    const std::string bot = "sayuri-amd 0.1";
+    out << "(;GM[1]FF[4]SZ[" << st.GetBoardSize() << "]KM[" << st.GetKomi() << "]RU["
+        << (st.GetScoringRule() == kAreaScoring ? "chinese" : "japanese") << "]PB[" << bot << "]PW[" << bot << "]DT[" << NowString() << ']';
+    if (st.GetHandicap() != 0) out << "HA[" << st.GetHandicap() << ']';
+    for (int c = 0; c < 2; ++c) {
+        const auto setup = st.GetAppendMoves(c);
+        if (setup.empty()) continue;
+        out << (c == kBlack ? "AB" : "AW");
+        for (int v : setup) out << '[' << st.VertexToSgf(v) << ']';
+    }
+    out << "C[" << (st.GetScoringRule() == kAreaScoring ? "chinese" : "japanese") << ']';
+    const float score = st.GetFinalScore(kBlack);
+    const bool pass_end = st.GetPasses() >= 2;
+    if (pass_end) st.SetWinner(score > 1e-4 ? sayuri_go::kBlackWon : score < -1e-4 ? sayuri_go::kWhiteWon : sayuri_go::kDrawGame);
+    if (st.GetWinner() != sayuri_go::kUndecided) {
+        out << "RE[";
+        if (st.GetWinner() == sayuri_go::kBlackWon) {
+            out << "B+";
+            if (pass_end) out << score;
+        } else if (st.GetWinner() == sayuri_go::kWhiteWon) {
+            out << "W+";
+            if (pass_end) out << -score;
+        } else {
+            out << "0";
+        }
+        if (!pass_end && st.GetWinner() != sayuri_go::kDrawGame) out << "Resign";
+        out << ']';
+    }
+    for (int i = 1; i <= st.GetMoveNumber(); ++i) {
+        const auto mv = st.MoveAt(i);
+        out << ';' << (mv.second == kBlack ? 'B' : 'W') << '[' << st.VertexToSgf(mv.first) << ']';
+        if (static_cast<size_t>(i) < s.comments.size() && !s.comments[static_cast<size_t>(i)].empty()) out << "C[" << s.comments[static_cast<size_t>(i)] << ']';
+    }
+    out << ')';
+    return out.str();
+}
+
+// ---------------------------------------------------------------------------------------------
+SelfplayPipe::SelfplayPipe(std::shared_ptr<NetworkForwardPipe> pipe, int weights_version, const EngineOptions& opt,
+                           const std::string& name_suffix)
+    : opt_(opt), engine_(std::move(pipe), weights_version, opt) {
+    max_games_ = std::max(opt_.selfplay.num_games, engine_.GetParallelGames());
+    const std::string& target = opt_.selfplay.target_directory;
+    if (!target.empty()) {
+        // a name not used by an earlier run in this directory (pipe.cc:44-80), plus the caller's suffix (rank id)
+        for (;;) {
+            std::ostringstream ss;
+            const std::time_t now = std::time(nullptr);
+            ss << std::hex << std::uppercase << std::hash<std::string>()(std::to_string(now) + "/" + std::to_string(opt_.selfplay.seed));
+            hash_ = ss.str() + name_suffix;
+            tdata_dir_ = target + "/tdata/" + hash_;
+            vdata_dir_ = target + "/vdata/" + hash_;
+            if (!DirExists(tdata_dir_) && !DirExists(vdata_dir_)) break;
+            std::this_thread::sleep_for(std::chrono::seconds(1));
+        }
+        sgf_dir_ = target + "/sgf";
+        queries_dir_ = target + "/net_queries";
+        if (!DirExists(target)) throw std::runtime_error("ABORT: Target directory do not exist.");
+        MakeDir(target + "/tdata");
+        MakeDir(tdata_dir_);
+        MakeDir(target + "/vdata");
+        MakeDir(vdata_dir_);
+        MakeDir(sgf_dir_);
+        MakeDir(queries_dir_);
+    }
+}
+
+namespace {
+bool WriteGzip(const std::string& name, const std::string& text) {
+    gzFile f = gzopen((name + ".gz").c_str(), "wb9");
+    if (!f) return false;
+    const int n = text.empty() ? 0 : gzwrite(f, text.data(), static_cast<unsigned>(text.size()));
+    gzclose(f);
+    return text.empty() || n > 0;
+}
+} // namespace
+
+bool SelfplayPipe::SaveChunk(int id, float vdata_prob, std::vector<TrainingData>& chunk, Rng& rng) {
+    std::ostringstream tdata, vdata;
+    vdata_prob = std::max(std::min(vdata_prob, 1.0f), 0.0f);
+    for (auto& d : chunk) {
+        if (rng.Chance(1.0f - vdata_prob)) d.StreamOut(tdata);
+        else d.StreamOut(vdata);
+        if (!d.discard) records_.fetch_add(1, std::memory_order_relaxed);
+    }
+    bool ok = WriteGzip(tdata_dir_ + "/game_" + std::to_string(id) + ".txt", tdata.str());
+    ok &= WriteGzip(vdata_dir_ + "/game_" + std::to_string(id) + ".txt", vdata.str());
+    chunk.clear();
+    return ok;
+}
+
+void SelfplayPipe::SaveSgf(const std::string& sgf) {
+    std::ofstream f(sgf_dir_ + "/" + hash_ + ".sgf", std::ios_base::app);
+    if (f.is_open()) f << sgf << std::endl;
+}
+
+void SelfplayPipe::SaveNetQueries(int games, const std::string& text) {
+    std::ofstream f(queries_dir_ + "/" + hash_ + ".txt", std::ios_base::app);
+    if (f.is_open()) f << games << " " << text << std::endl;
+}
+
+void SelfplayPipe::WriterLoop() {
+    // chunks leave in random order, one game per file; a pool of `games` finished games is kept while the
+    // workers run so that consecutive files do not come from consecutive games (pipe.cc:181-232)
+    constexpr float kValidationRatio = 0.1f;
+    const int games = engine_.GetParallelGames();
+    Rng rng(opt_.selfplay.seed ^ 0x5eedf00dULL);
+    std::vector<std::shared_ptr<DataSgf>> pool;
+    bool keep = true;
+    while (keep) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        keep = writer_running_.load(std::memory_order_relaxed);
+        std::deque<std::pair<int, std::string>> queries;
+        {
+            std::lock_guard<std::mutex> lock(data_mu_);
+            while (!data_queue_.empty()) {
+                pool.push_back(data_queue_.front());
+                data_queue_.pop_front();
+                keep = true;
+            }
+            queries.swap(queries_queue_);
+        }
+        const size_t hold = writer_running_.load(std::memory_order_relaxed) ? static_cast<size_t>(games) : 1;
+        while (pool.size() >= hold && !pool.empty()) {
+            std::shuffle(pool.begin(), pool.end(), rng);
+            auto item = pool.back();
+            pool.pop_back();
+            if (!opt_.selfplay.target_directory.empty()) {
+                if (SaveChunk(static_cast<int>(chunks_.load()), kValidationRatio, item->first, rng)) chunks_.fetch_add(1);
+                SaveSgf(item->second);
+            } else {
+                for (auto& d : item->first)
+                    if (!d.discard) records_.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+        if (!opt_.selfplay.target_directory.empty())
+            for (auto& q : queries) SaveNetQueries(q.first, q.second);
+    }
+}
+
+SelfplayStats SelfplayPipe::Run(double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    writer_running_.store(true);
+    std::thread writer([this]() { WriterLoop(); });
+    std::vector<std::thread> workers;
+    std::atomic<std::uint64_t> started{0};
+    const int games = engine_.GetParallelGames();
+    for (int g = 0; g < games; ++g) {
+        workers.emplace_back([this, g, &started]() {
+            while (!stop_.load(std::memory_order_relaxed) && accumulation_games_.fetch_add(1) < max_games_) {
+                started.fetch_add(1);
+                auto item = std::make_shared<DataSgf>();
+                engine_.PrepareGame(g);
+                // the game loop, abandoned between moves when the clock has run out
+                Search& search = engine_.search(g);
+                bool abandoned = false;
+                while (engine_.Step(g)) {
+                    if (stop_.load(std::memory_order_relaxed)) {
+                        abandoned = true;
+                        break;
+                    }
+                }
+                if (abandoned) {
+                    search.ClearTrainingBuffer();
+                    break;
+                }
+                search.UpdateTerritoryHelper();
+                engine_.GatherTrainingData(item->first, g);
+                item->second = engine_.GatherSgfString(g);
+                const int played = played_games_.fetch_add(1) + 1;
+                std::lock_guard<std::mutex> lock(data_mu_);
+                data_queue_.push_back(item);
+                queries_queue_.emplace_back(played, std::string("hip ") + std::to_string(engine_.network().GetNumQueries()));
+            }
+        });
+    }
+    if (seconds > 0) {
+        // wake up often enough to stop close to the deadline
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+            if (played_games_.load() >= max_games_) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+        stop_.store(true);
+    }
+    for (auto& w : workers) w.join();
+    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    writer_running_.store(false);
+    writer.join();
+
+    SelfplayStats st;
+    st.games_started = started.load();
+    st.games_done = static_cast<std::uint64_t>(played_games_.load());
+    st.moves = engine_.moves_played();
+    st.playouts = engine_.playouts();
+    st.nn_queries = engine_.network().GetNumQueries();
+    st.cache_lookups = engine_.network().cache().lookups();
+    st.cache_hits = engine_.network().cache().hits();
+    st.records = records_.load();
+    st.chunks_saved = chunks_.load();
+    st.elapsed = elapsed;
+    return st;
+}
+
+} // namespace sayuri_engine

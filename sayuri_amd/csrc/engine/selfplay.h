@@ -1,0 +1,106 @@
+// Self-play: game set-up (board / komi / handicap / random-opening queries), the game loop, SGF and
+// training-chunk output, and the worker pool that keeps many games in flight against one evaluation queue.
+//
+// Behaviour follows the reference's self-play mode (src/selfplay/engine.{h,cc}, src/selfplay/pipe.{h,cc},
+// src/game/sgf.cc:513-588, src/neural/training_data.cc): same query grammar ("bkp:19:7.5:0.2", "bhp:9:2:0.1",
+// "srs:area:territory"), same set-up randomisation, same 53-line records, same tdata/ vdata/ sgf/ net_queries/
+// directory layout (chunks gzip'ed with zlib).  Each game owns its two random streams, so a seed fixes a game.
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine_options.h"
+#include "search.h"
+
+namespace sayuri_engine {
+
+struct SelfplayStats {
+    std::uint64_t games_started{0}, games_done{0}, moves{0}, playouts{0};
+    std::uint64_t nn_queries{0}, cache_lookups{0}, cache_hits{0}, records{0}, chunks_saved{0};
+    double elapsed{0};
+};
+
+class SelfplayEngine { // engine.h:12-69
+public:
+    SelfplayEngine(std::shared_ptr<NetworkForwardPipe> pipe, int weights_version, const EngineOptions& opt);
+    void PrepareGame(int g);                                       // engine.cc:193-232
+    bool Step(int g);                                              // one self-play move; false once the game is over
+    void Selfplay(int g);                                          // engine.cc:234-241
+    void GatherTrainingData(std::vector<TrainingData>& chunk, int g);
+    std::string GatherSgfString(int g);                            // engine.cc:181-186 + sgf.cc:513-588
+    int GetParallelGames() const { return static_cast<int>(slots_.size()); }
+    Network& network() { return network_; }
+    GameState& state(int g) { return slots_[static_cast<size_t>(g)]->state; }
+    Search& search(int g) { return *slots_[static_cast<size_t>(g)]->search; }
+    std::uint64_t moves_played() const { return moves_.load(std::memory_order_relaxed); }
+    std::uint64_t playouts() const;
+    int move_cap{0}; // extension: 0 = none; otherwise both sides pass once a game reaches this many moves
+
+private:
+    struct BoardQuery { int board_size; float komi; float prob; };
+    struct HandicapQuery { int board_size; int handicaps; float prob; };
+    struct Slot {
+        GameState state;
+        std::unique_ptr<Search> search;
+        std::vector<std::string> comments; // SGF comment per move number
+    };
+    void ParseQueries();
+    void SetNormalGame(int g);
+    void SetHandicapGame(int g, int handicaps);
+    void SetRandomOpeningGame(int g);
+    void SetUnfairKomi(int g);
+    void SetFairKomi(int g);
+    int GetHandicaps(int g);
+    Slot& At(int g);
+
+    EngineOptions opt_;
+    Network network_;
+    std::vector<std::unique_ptr<Slot>> slots_;
+    std::vector<BoardQuery> board_queries_;
+    std::vector<HandicapQuery> handicap_queries_;
+    std::vector<int> scoring_set_;
+    std::atomic<std::uint64_t> moves_{0};
+};
+
+// The worker pool + data writer (pipe.cc:13-341).  One worker per concurrent game; each blocks in the
+// evaluation queue of the forward pipe while its leaf is in a batch.
+class SelfplayPipe {
+public:
+    SelfplayPipe(std::shared_ptr<NetworkForwardPipe> pipe, int weights_version, const EngineOptions& opt,
+                 const std::string& name_suffix = "");
+    // Plays until `num_games` games are complete, or (seconds > 0) until the clock runs out: games still in
+    // progress are then abandoned and not written.
+    SelfplayStats Run(double seconds = 0);
+    const std::string& filename_hash() const { return hash_; }
+    SelfplayEngine& engine() { return engine_; }
+
+private:
+    using DataSgf = std::pair<std::vector<TrainingData>, std::string>;
+    void WriterLoop();
+    bool SaveChunk(int id, float vdata_prob, std::vector<TrainingData>& chunk, Rng& rng);
+    void SaveSgf(const std::string& sgf);
+    void SaveNetQueries(int games, const std::string& text);
+
+    EngineOptions opt_;
+    SelfplayEngine engine_;
+    std::string hash_, tdata_dir_, vdata_dir_, sgf_dir_, queries_dir_;
+    std::mutex data_mu_;
+    std::deque<std::shared_ptr<DataSgf>> data_queue_;
+    std::deque<std::pair<int, std::string>> queries_queue_;
+    std::atomic<bool> writer_running_{false};
+    std::atomic<int> accumulation_games_{0}, played_games_{0};
+    std::atomic<bool> stop_{false};
+    std::atomic<std::uint64_t> records_{0}, chunks_{0};
+    int max_games_{0};
+};
+
+float AdjustKomiToHalf(float komi); // utils/komi.cc AdjustKomi<float>
+
+} // namespace sayuri_engine

@@ -172,6 +172,17 @@ int sayuri_pipe_eval(void* hp, int mode, int gpu, int n, const float* planes, co
 
 #include <thread>
 
+// The pipe behind a handle as the abstract plugin interface (for the engine, which only knows
+// NetworkForwardPipe), and the version of the weights it was built from.
+extern "C" void* sayuri_pipe_raw(void* hp) {
+    auto* h = static_cast<PipeHandle*>(hp);
+    return h ? static_cast<NetworkForwardPipe*>(h->pipe.get()) : nullptr;
+}
+extern "C" int sayuri_pipe_weights_version(void* hp) {
+    auto* h = static_cast<PipeHandle*>(hp);
+    return h && h->weights ? h->weights->version : -1;
+}
+
 extern "C" int sayuri_pipe_eval(void* hp, int mode, int gpu, int n, const float* planes, const int* board_sizes,
                                 const float* komi, const int* offsets, float* out) {
     auto* h = static_cast<PipeHandle*>(hp);
