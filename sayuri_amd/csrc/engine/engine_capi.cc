@@ -156,6 +156,12 @@ int sayuri_engine_search_selfplay_move(void* s, void* game, int tag) {
 int sayuri_engine_search_think(void* s, void* game) {
     return MoveToIndex(*static_cast<GameState*>(game), static_cast<Search*>(s)->ThinkBestMove());
 }
+// indices of the buffered training samples that came from single-candidate searches (see search.h); returns the count
+int sayuri_engine_search_single_candidate(void* s, int* out, int cap) {
+    const auto& v = static_cast<Search*>(s)->single_candidate_records();
+    for (size_t i = 0; i < v.size() && static_cast<int>(i) < cap; ++i) out[i] = v[i];
+    return static_cast<int>(v.size());
+}
 void sayuri_engine_search_update_territory_helper(void* s) { static_cast<Search*>(s)->UpdateTerritoryHelper(); }
 // Self-play on a forward pipe (raw = sayuri_pipe_raw(handle); NULL = the dummy random-output backend).
 // stats[10] = games_started, games_done, moves, playouts, nn_queries, cache_lookups, cache_hits, records,

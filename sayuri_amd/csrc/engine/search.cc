@@ -250,7 +250,13 @@ ComputationResult Search::Computation(int playouts, int tag) {
 
     PrepareRootNode(result, tag);
 
-    bool running = !AchieveCap(playouts, tag) && HaveAlternateMoves();
+    bool running = !AchieveCap(playouts, tag);
+    last_single_candidate_ = false;
+    if (running && !HaveAlternateMoves()) {
+        running = false;
+        single_candidate_searches_ += 1;
+        last_single_candidate_ = true;
+    }
     while (running) {
         GameState fork = root_state_;
         PlayoutResult pr;
@@ -557,7 +563,10 @@ int Search::GetSelfPlayMove(int tag) {
     std::snprintf(buf, sizeof(buf), "%d, %d, %.2f, %.2f, %.2f, %c", result.playouts, result.visits, root_eval, root_score,
                   result.policy_kld, discard ? 'F' : 'T');
     last_comment_ = buf;
-    if (!(tag & kNoBuffer)) GatherData(root_state_, result, discard);
+    if (!(tag & kNoBuffer)) {
+        if (last_single_candidate_) single_candidate_records_.push_back(static_cast<int>(training_buffer_.size()));
+        GatherData(root_state_, result, discard);
+    }
     return move;
 }
 
@@ -678,6 +687,7 @@ void Search::GatherTrainingBuffer(std::vector<TrainingData>& chunk) {
     }
     for (auto& buf : training_buffer_) chunk.push_back(buf);
     training_buffer_.clear();
+    single_candidate_records_.clear();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -82,11 +82,16 @@ public:
     const Node* root() const { return root_.get(); }
     const std::string& last_comment() const { return last_comment_; }
     size_t total_playouts() const { return total_playouts_; }
+    // searches that ended at once because the root had a single candidate (the reference stops those from a
+    // polling thread, after a timing-dependent handful of playouts: search.cc:352-386, 1423-1441)
+    int single_candidate_searches() const { return single_candidate_searches_; }
+    // indices (within the current training buffer, counting discarded samples) of the samples such searches produced
+    const std::vector<int>& single_candidate_records() const { return single_candidate_records_; }
 
 private:
     struct PlayoutResult {
         bool valid{false};
-        NodeEvals evals;
+        NodeEvals evals{};
     };
     void PlaySimulation(GameState& state, Node* node, int depth, PlayoutResult& result); // search.cc:60-137
     void GameOverEvals(GameState& state, PlayoutResult& result);                        // search.h:33-60
@@ -117,6 +122,9 @@ private:
     int prev_kld_visits_{0};
     int playouts_{0};
     size_t total_playouts_{0};
+    int single_candidate_searches_{0};
+    bool last_single_candidate_{false};
+    std::vector<int> single_candidate_records_;
     std::string last_comment_;
 };
 

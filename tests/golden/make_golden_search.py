@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/search_games.npz -- fixed-seed self-play games of the REFERENCE search.
+
+Dev container only: drives the reference's Network / Search / TrainingData through
+oracle/_ref/libsayuri_ref.so (taps in oracle/ref_search_driver.cc) with its random generators pinned
+(ref_seed).  Recorded per game: the moves and the 53-line training records the reference wrote.
+tests/test_search_cpu.py replays the same seeds through the product engine.
+
+    python tests/golden/make_golden_search.py
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from sayuri_amd import weights as W  # noqa: E402
+from sayuri_amd.engine import GoApi  # noqa: E402
+from search_replay import DUMMY_GAMES, NN_GAMES, REF_SO, RefSearchApi, ref_selfplay_game  # noqa: E402
+
+
+def main():
+    api = RefSearchApi()
+    go_api = GoApi(api.lib, "ref_game_")
+    out = {}
+    for i, (seed, board, komi, scoring, opts) in enumerate(DUMMY_GAMES):
+        moves, text = ref_selfplay_game(api, go_api, seed, board, komi, scoring, opts)
+        out[f"dummy{i}_moves"] = np.array(moves, np.int16)
+        out[f"dummy{i}_records"] = np.frombuffer(zlib.compress(text, 9), np.uint8)
+        print(f"dummy game {i}: board {board}, {len(moves)} moves, {len(text)} bytes of records", file=sys.stderr)
+    wpath = "/tmp/sayuri_golden_6b96_seed21.bin"
+    W.write_weights(wpath, W.spec_6b96(), seed=21)
+    assert api.lib.ref_init(wpath.encode(), 1) == 0
+    for i, (seed, board, komi, scoring, opts, nmoves) in enumerate(NN_GAMES):
+        moves, text = ref_selfplay_game(api, go_api, seed, board, komi, scoring, opts, weights=wpath.encode(), max_moves=nmoves)
+        out[f"nn{i}_moves"] = np.array(moves, np.int16)
+        out[f"nn{i}_records"] = np.frombuffer(zlib.compress(text, 9), np.uint8)
+        print(f"nn game {i}: board {board}, {len(moves)} moves, {len(text)} bytes of records", file=sys.stderr)
+    path = os.path.join(HERE, "search_games.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

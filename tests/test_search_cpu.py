@@ -1,0 +1,170 @@
+"""Tree search / self-play parity, CPU only.
+
+* golden, dummy backend: with no weights the network facade returns random outputs drawn from the search's own
+  seeded streams (reference network.cc:144-165), so a whole self-play game -- every move, every training record --
+  is a pure function of the seed.  tests/golden/search_games.npz holds such games played by the REFERENCE search
+  (generator: tests/golden/make_golden_search.py); the product engine must play the SAME MOVES and emit records
+  equal field by field (integers / bit planes exactly, floats to 3e-5: the reference binary is a -ffast-math build).
+  Covers PUCT, Dirichlet noise, first-pass bonus, Gumbel + completed-Q targets, territory scoring with rule
+  switching in playouts, fast-search / resign bookkeeping, tree reuse, symmetry pruning, capture-all-dead.
+* golden, real network: the same with the synthetic 6b96 net; here the product engine is fed by the oracle port of
+  the CPU pipe (oracle/libsayuri_oracle.so, tests only) while the golden games used the reference's own pipe.
+* live (dev container): the reference taps and the engine side by side on fresh seeds, plus the facade
+  (symmetry, cache, post-processing) against Network::GetOutput.
+"""
+import ctypes
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from search_replay import DUMMY_GAMES, NN_GAMES, REF_SO, RefSearchApi, options, records_close, ref_selfplay_game
+from sayuri_amd import search as S
+from sayuri_amd import weights as W
+from sayuri_amd.engine import Game, GoApi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+have_ref = os.path.exists(REF_SO)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "search_games.npz"))
+
+
+def engine_selfplay_game(net, seed, board, komi, scoring, opts, max_moves=100000):
+    game = Game(board, komi, scoring)
+    search = S.Search(game, net, options(opts), seeds=(seed, seed + 77))
+    moves = []
+    while not game.info()[10] and len(moves) < max_moves:
+        mv = search.selfplay_move()
+        moves.append(mv)
+        assert game.play(mv)
+    search.update_territory_helper()
+    racy = search.single_candidate_records()
+    text = search.gather_training_text()
+    search.close()
+    return moves, text, racy
+
+
+@pytest.mark.parametrize("i", range(len(DUMMY_GAMES)))
+def test_golden_dummy_backend_games(golden, i):
+    seed, board, komi, scoring, opts = DUMMY_GAMES[i]
+    net = S.Network(options=options(opts))
+    moves, text, racy = engine_selfplay_game(net, seed, board, komi, scoring, opts)
+    want = golden[f"dummy{i}_moves"].tolist()
+    assert moves == want, f"first different move at {next(k for k, (a, b) in enumerate(zip(moves, want)) if a != b)}"
+    assert records_close(zlib.decompress(golden[f"dummy{i}_records"].tobytes()), text, racy_records=racy) is None
+
+
+@pytest.fixture(scope="module")
+def port_net(tmp_weights_dir):
+    from _oracle import PortNet
+    path = os.path.join(tmp_weights_dir, "search_6b96.bin")
+    if not os.path.exists(path):
+        W.write_weights(path, W.spec_6b96(), seed=21)
+    return PortNet(path, True)
+
+
+@pytest.mark.parametrize("i", range(len(NN_GAMES)))
+def test_golden_network_games(golden, port_net, i):
+    seed, board, komi, scoring, opts, nmoves = NN_GAMES[i]
+    fn = ctypes.cast(port_net.lib().so_forward, ctypes.c_void_p)
+    net = S.Network(callback=fn, callback_kind=1, callback_user=port_net._h, options=options(opts))
+    moves, text, racy = engine_selfplay_game(net, seed, board, komi, scoring, opts, max_moves=nmoves)
+    assert moves == golden[f"nn{i}_moves"].tolist()
+    assert records_close(zlib.decompress(golden[f"nn{i}_records"].tobytes()), text, rel=2e-4, abs_=2e-5, racy_records=racy) is None
+
+
+def test_selfplay_pipe_dummy_backend(tmp_path):
+    opts = dict(playouts=100, parallel_games=4, num_games=8, seed=7, dirichlet_noise=1, first_pass_bonus=1, random_moves_factor=0.1,
+                komi_stddev=2.5, komi_big_stddev_prob=0.1, komi_big_stddev=12, handicap_fair_komi_prob=0.5, random_opening_prob=0.3,
+                selfplay_query=["bkp:9:7:0.7", "bkp:7:9:0.3", "bhp:9:2:0.5", "srs:area:territory"], target_directory=str(tmp_path))
+    st = S.selfplay(None, opts, name_suffix="-r0")
+    assert st["games_done"] == 8 and st["chunks_saved"] == 8 and st["records"] > 100
+    import glob
+    import gzip
+    chunks = sorted(glob.glob(str(tmp_path / "tdata" / "*-r0" / "game_*.txt.gz")))
+    assert len(chunks) == 8
+    lines = gzip.open(chunks[0]).read().decode().split("\n")
+    assert (len(lines) - 1) % 53 == 0 and lines[0] == "2" and lines[1] == "0"
+    sgf = open(glob.glob(str(tmp_path / "sgf" / "*.sgf"))[0]).read()
+    assert sgf.count("(;GM[1]FF[4]") == 8 and "RE[" in sgf
+    # one game per worker: a seed fixes every game (with more games than workers, which worker picks up the next
+    # game depends on timing, as in the reference)
+    once = dict(opts, target_directory="", num_games=4)
+    a, b = S.selfplay(None, once), S.selfplay(None, once)
+    assert (a["moves"], a["playouts"], a["records"]) == (b["moves"], b["playouts"], b["records"]) and a["games_done"] == 4
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/train/torch"), reason="reference trainer only in the dev container")
+def test_training_chunks_parse_with_reference_reader(tmp_path):
+    """The reference's own Python chunk parser (train/torch/data.py) must accept what the writer emits."""
+    import glob
+    import gzip
+    import sys
+    S.selfplay(None, dict(playouts=60, parallel_games=2, num_games=2, seed=3, selfplay_query=["bkp:9:7:1"], target_directory=str(tmp_path)))
+    sys.path.insert(0, "/root/reference/train/torch")
+    try:
+        import data as refdata
+    finally:
+        sys.path.pop(0)
+    import io
+    text = gzip.open(sorted(glob.glob(str(tmp_path / "tdata" / "*" / "*.gz")))[0]).read().decode()
+    stream, count = io.StringIO(text), 0
+    while True:
+        d = refdata.Data()
+        if not d.load_from_stream(stream):
+            break
+        d.parse()
+        count += 1
+        assert d.board_size == 9 and d.planes.shape == (37, 81) and abs(float(np.sum(d.prob)) - 1.0) < 1e-3
+        assert len(d.ownership) == 81 and d.result in (-1, 0, 1) and d.to_move in (0, 1)
+    assert count == text.count("\n") // 53 and count > 10
+
+
+# ---------------------------------------------------------------------------------------------
+pytestmark_live = pytest.mark.skipif(not have_ref, reason="oracle/_ref is only built in the dev container")
+
+
+@pytestmark_live
+@pytest.mark.parametrize("seed,board,komi,scoring,opts", [
+    (101, 9, 7.0, 0, dict(playouts=150, dirichlet_noise=1, first_pass_bonus=1, random_moves_factor=0.15)),
+    (102, 11, 6.5, 1, dict(playouts=120, gumbel=1, gumbel_playouts_threshold=30, first_pass_bonus=1)),
+    (103, 9, 7.5, 0, dict(playouts=130, reuse_tree=1, fastsearch_playouts=40, fastsearch_playouts_prob=0.3, random_fastsearch_prob=0.5)),
+])
+def test_live_dummy_games_against_reference(seed, board, komi, scoring, opts):
+    api = RefSearchApi()
+    want_moves, want_text = ref_selfplay_game(api, GoApi(api.lib, "ref_game_"), seed, board, komi, scoring, opts)
+    moves, text, racy = engine_selfplay_game(S.Network(options=options(opts)), seed, board, komi, scoring, opts)
+    assert moves == want_moves
+    assert records_close(want_text, text, racy_records=racy) is None
+
+
+@pytestmark_live
+def test_live_facade_against_reference(tmp_weights_dir):
+    """Network::GetOutput: direct symmetries, averaged ensemble, temperature -- both sides on the reference CPU pipe."""
+    path = os.path.join(tmp_weights_dir, "facade_6b96.bin")
+    if not os.path.exists(path):
+        W.write_weights(path, W.spec_6b96(), seed=21)
+    api = RefSearchApi()
+    api.set_options(options({}))
+    assert api.lib.ref_init(path.encode(), 1) == 0
+    rnet = api.lib.ref_net_new(path.encode())
+    mnet = S.Network(callback=ctypes.cast(api.lib.ref_forward, ctypes.c_void_p), callback_kind=0, options=options({}))
+    go_api = GoApi(api.lib, "ref_game_")
+    rng = np.random.default_rng(5)
+    for board, komi in ((9, 7.0), (13, 6.5)):
+        a, b = Game(board, komi, 0, api_=go_api), Game(board, komi, 0)
+        for _ in range(12):
+            legal = np.flatnonzero(a.maps()[1][:a.n])
+            mv = int(rng.choice(legal))
+            assert a.play(mv) and b.play(mv)
+        n = a.n
+        for ensemble, symm, temp in ((0, 0, 1.0), (0, 5, 1.0), (0, 3, 0.7), (2, 0, 1.0), (0, 7, 1.5)):
+            want = np.zeros(2 * n + 9, np.float32)
+            api.lib.ref_net_output(rnet, a._h, ensemble, symm, temp, 0, want.ctypes.data)
+            got = mnet.output(b, ensemble, symm, temp)
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (board, ensemble, symm, temp, np.abs(got - want).max())
+    api.lib.ref_net_free(rnet)
