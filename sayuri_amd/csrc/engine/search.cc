@@ -248,6 +248,9 @@ ComputationResult Search::Computation(int playouts, int tag) {
         return result;
     }
 
+    // fold the move log into its shared prefix: every fork of the root below (one per playout, one per root
+    // child in the superko filter) then copies a pointer instead of the frames
+    root_state_.Freeze();
     PrepareRootNode(result, tag);
 
     bool running = !AchieveCap(playouts, tag);
@@ -266,6 +269,7 @@ ComputationResult Search::Computation(int playouts, int tag) {
             total_playouts_ += 1;
         }
         if (AchieveCap(playouts, tag)) running = false;
+        else if (abort_ && abort_->load(std::memory_order_relaxed)) running = false;
         else if (active_->kldgain_interval > 0 && StoppedByKldGain(result, tag)) running = false;
     }
     UpdateComputationResult(result);

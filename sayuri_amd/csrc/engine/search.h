@@ -11,6 +11,7 @@
 // split is kept as two explicit streams so that a fixed-seed search reproduces the reference's moves.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <ostream>
@@ -78,6 +79,8 @@ public:
     void GatherTrainingBuffer(std::vector<TrainingData>& chunk); // search.cc:1180-1306
     void ClearTrainingBuffer() { training_buffer_.clear(); }
     void ReleaseTree() { root_.reset(); }
+    // When set and raised, a running Computation stops after the current playout (used to end a timed self-play run).
+    void SetAbortFlag(const std::atomic<bool>* flag) { abort_ = flag; }
     SearchParams* GetParams(bool no_exploring = false) { return no_exploring ? passive_ : active_; }
     const Node* root() const { return root_.get(); }
     const std::string& last_comment() const { return last_comment_; }
@@ -126,6 +129,7 @@ private:
     bool last_single_candidate_{false};
     std::vector<int> single_candidate_records_;
     std::string last_comment_;
+    const std::atomic<bool>* abort_{nullptr};
 };
 
 bool ShouldResign(GameState& state, ComputationResult& result, const SearchParams* param); // search.cc:749-793

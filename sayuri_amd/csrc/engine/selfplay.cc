@@ -1,11 +1,16 @@
 #include "selfplay.h"
 
+#include <malloc.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <ctime>
 #include <fstream>
 #include <random>
@@ -376,14 +381,49 @@ void SelfplayPipe::WriterLoop() {
 }
 
 SelfplayStats SelfplayPipe::Run(double seconds) {
+    // Hundreds of game threads build and drop a search tree per move.  Keep freed heap inside the process instead of
+    // trimming / unmapping it: every munmap or brk shrink takes the address-space lock exclusively and stalls the page
+    // faults of all other game threads.
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
     const auto t0 = std::chrono::steady_clock::now();
     writer_running_.store(true);
     std::thread writer([this]() { WriterLoop(); });
     std::vector<std::thread> workers;
     std::atomic<std::uint64_t> started{0};
     const int games = engine_.GetParallelGames();
+    // The CPUs this process may use; game thread g is pinned to the g-th of them (round robin).  Unpinned, the 256
+    // threads the pump wakes when a batch completes are queued next to the pump's CPU (wake-affine placement) and run
+    // there one after another, which multiplies the time until the next batch is full.
+    std::vector<int> cpus;
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0)
+            for (int c = 0; c < CPU_SETSIZE; ++c)
+                if (CPU_ISSET(c, &set)) cpus.push_back(c);
+    }
+    for (int g = 0; g < games; ++g) engine_.search(g).SetAbortFlag(&stop_);
     for (int g = 0; g < games; ++g) {
-        workers.emplace_back([this, g, &started]() {
+        workers.emplace_back([this, g, &started, &cpus]() {
+            if (cpus.size() > 1) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                CPU_SET(cpus[static_cast<size_t>(g) % cpus.size()], &one);
+                pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+            }
+            {
+                // Grow this thread's malloc arena once to about the size of a move's search tree (a node plus its edge
+                // list is ~7 KB, one per playout) and pre-fault it.  Otherwise the arena grows in page-sized mprotect
+                // steps while the first trees are built -- thousands of address-space write locks per thread, all of
+                // them contending with every other game thread's page faults.
+                const size_t bytes = static_cast<size_t>(std::max(opt_.search.playouts, 64)) * 8192 + (1u << 20);
+                void* warm = std::malloc(bytes);
+                if (warm) {
+                    std::memset(warm, 0, bytes);
+                    std::free(warm);
+                }
+            }
             while (!stop_.load(std::memory_order_relaxed) && accumulation_games_.fetch_add(1) < max_games_) {
                 started.fetch_add(1);
                 auto item = std::make_shared<DataSgf>();
@@ -411,30 +451,36 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
             }
         });
     }
+    auto snapshot = [&](SelfplayStats& st) {
+        st.games_started = started.load();
+        st.games_done = static_cast<std::uint64_t>(played_games_.load());
+        st.moves = engine_.moves_played();
+        st.playouts = engine_.playouts();
+        st.nn_queries = engine_.network().GetNumQueries();
+        st.cache_lookups = engine_.network().cache().lookups();
+        st.cache_hits = engine_.network().cache().hits();
+        st.elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    SelfplayStats st;
+    bool timed_out = false;
     if (seconds > 0) {
         // wake up often enough to stop close to the deadline
         while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
             if (played_games_.load() >= max_games_) break;
-            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+        if (played_games_.load() < max_games_) {
+            snapshot(st); // the window ends here: what the workers do while winding down is not counted
+            timed_out = true;
         }
         stop_.store(true);
     }
     for (auto& w : workers) w.join();
-    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!timed_out) snapshot(st);
     writer_running_.store(false);
     writer.join();
-
-    SelfplayStats st;
-    st.games_started = started.load();
-    st.games_done = static_cast<std::uint64_t>(played_games_.load());
-    st.moves = engine_.moves_played();
-    st.playouts = engine_.playouts();
-    st.nn_queries = engine_.network().GetNumQueries();
-    st.cache_lookups = engine_.network().cache().lookups();
-    st.cache_hits = engine_.network().cache().hits();
     st.records = records_.load();
     st.chunks_saved = chunks_.load();
-    st.elapsed = elapsed;
     return st;
 }
 

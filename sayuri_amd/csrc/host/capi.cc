@@ -136,9 +136,9 @@ void sayuri_pipe_destroy(void* hp) {
     delete h;
 }
 
-void sayuri_pipe_pump_times(void* hp, double* out4, long* batches, long* evals) {
+void sayuri_pipe_pump_times(void* hp, double* out6, long* batches, long* evals) {
     auto* h = static_cast<PipeHandle*>(hp);
-    h->pipe->pump_times(out4);
+    h->pipe->pump_times(out6);
     *batches = static_cast<long>(h->pipe->num_batches());
     *evals = static_cast<long>(h->pipe->num_evals());
 }

@@ -215,6 +215,8 @@ void HipForwardPipe::DestroyGraphs() {
             std::lock_guard<std::mutex> lk(g->mu);
         }
         g->cv.notify_all();
+        g->epoch.fetch_add(1, std::memory_order_release);
+        FutexWakeAll(&g->epoch);  // callers parked for a free staging set see running_ == false
     }
     for (auto& g : graphs_)
         if (g->pump.joinable()) g->pump.join();
@@ -327,39 +329,75 @@ void HipForwardPipe::FinishBatch(Graph* g, Staging* s, int n) {
     s->n_inflight = 0;
     s->ready.store(0, std::memory_order_relaxed);
     s->reserved.store(0, std::memory_order_release);  // re-open for callers
+    g->epoch.fetch_add(1, std::memory_order_release);
+    FutexWakeAll(&g->epoch);
 }
 
-// One persistent pump per GPU, two batches deep.  While batch A runs on the GPU the callers fill
-// staging set B; as soon as B holds batch_size requests it is ENQUEUED behind A (H2D, graph, D2H are
-// all stream-ordered), and only then does the pump block on A, hand out A's results and re-open A.
-// A set that is not full is sent after gpu_waittime_ms, and once that happened the pump stops
-// waiting until a set comes up empty again (the adaptive 0 <-> base wait of
+// One persistent pump per GPU over a ring of staging sets.  Callers fill the set `fill` points at; when it holds
+// batch_size requests (or its wait expired) the pump closes it and points callers at the next set of the ring.
+// Closed sets are ENQUEUED on the GPU in order, at most two at a time (H2D, graph, D2H are stream-ordered, so
+// the second runs back to back with the first); the pump hands out a batch's results when its event fires and
+// re-opens the set.  With more leaves in flight than two batches the remaining sets hold full batches that are
+// ready the moment the GPU frees a slot.  A set that is not full is sent after gpu_waittime_ms, and once that
+// happened the pump stops waiting until the fill set runs dry again (the adaptive 0 <-> base wait of
 // batch_forward_pipe.cc:99-193).
 void HipForwardPipe::PumpLoop(Graph* g) {
     using clock = std::chrono::steady_clock;
+    constexpr int K = Graph::kSets;
     auto count = [](const Staging& s) { return s.reserved.load(std::memory_order_acquire) & ~Staging::kClosed; };
     auto closed = [](const Staging& s) { return (s.reserved.load(std::memory_order_acquire) & Staging::kClosed) != 0; };
     const unsigned want = static_cast<unsigned>(std::min(cfg_.batch_size, max_batch_));
-    int cur = 0;           // set currently filling
-    int inflight[2];       // FIFO of sets on the GPU
-    int n_in = 0;
-    bool eager = false;
-    clock::time_point first_seen{};
+    int cur = 0;              // set currently filling
+    int pending[K], n_pending = 0, pending_n[K];  // closed sets (and their sizes) waiting for a GPU slot, FIFO
+    int inflight[2], n_in = 0;                    // FIFO of sets on the GPU
     bool timing = false;
+    clock::time_point first_seen{};
+    clock::time_point gpu_busy_since{};  // when the batch at the head of the GPU queue started executing (estimate)
+    double gpu_batch_us = 1000.0;        // running mean of a batch's time on the GPU
+    clock::time_point gpu_idle_since{};
+    bool ever_busy = false;
 
-    // close set `i`, point callers at the other one, wait for plane copies, enqueue
-    auto launch = [&](int i) {
-        Staging& s = g->st[i];
+    auto wake_callers = [&] {
+        const auto t0 = clock::now();
+        g->epoch.fetch_add(1, std::memory_order_release);
+        FutexWakeAll(&g->epoch);
+        pump_ns_[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0).count();
+    };
+    // close the fill set and point callers at the next one of the ring
+    auto close_and_rotate = [&] {
+        Staging& s = g->st[cur];
         const unsigned prev = s.reserved.fetch_or(Staging::kClosed, std::memory_order_acq_rel);
         const int n = static_cast<int>(std::min<unsigned>(prev & ~Staging::kClosed, static_cast<unsigned>(max_batch_)));
-        g->fill.store(i ^ 1, std::memory_order_release);
         if (n == 0) {
             s.reserved.store(0, std::memory_order_release);
             return;
         }
+        if (static_cast<unsigned>(n) < want) pump_ns_[5] += 1000;  // counts partial batches (reported /1000)
+        pending[n_pending] = cur;
+        pending_n[n_pending++] = n;
+        cur = (cur + 1) % K;
+        g->fill.store(cur, std::memory_order_release);
+        wake_callers();
+    };
+    // wait for the callers' plane copies of the oldest pending set, then enqueue it
+    auto submit_pending = [&] {
+        const int i = pending[0], n = pending_n[0];
+        for (int k = 1; k < n_pending; ++k) {
+            pending[k - 1] = pending[k];
+            pending_n[k - 1] = pending_n[k];
+        }
+        --n_pending;
+        Staging& s = g->st[i];
+        const auto tc0 = clock::now();
         while (s.ready.load(std::memory_order_acquire) < static_cast<unsigned>(n)) std::this_thread::yield();
+        pump_ns_[7] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - tc0).count();
         try {
             SubmitBatch(g, &s, n);
+            if (n_in == 0) {
+                gpu_busy_since = clock::now();
+                if (ever_busy) pump_ns_[6] += std::chrono::duration_cast<std::chrono::nanoseconds>(gpu_busy_since - gpu_idle_since).count();
+                ever_busy = true;
+            }
             inflight[n_in++] = i;
         } catch (const std::exception&) {
             for (int k = 0; k < n; ++k) {
@@ -368,41 +406,63 @@ void HipForwardPipe::PumpLoop(Graph* g) {
             }
             s.ready.store(0, std::memory_order_relaxed);
             s.reserved.store(0, std::memory_order_release);
+            wake_callers();
         }
     };
     auto finish_oldest = [&] {
         Staging& s = g->st[inflight[0]];
         FinishBatch(g, &s, s.n_inflight);
+        const auto now = clock::now();
+        const double us = std::chrono::duration<double, std::micro>(now - gpu_busy_since).count();
+        gpu_batch_us = 0.8 * gpu_batch_us + 0.2 * us;
+        gpu_busy_since = now;  // the next queued batch (if any) has the GPU from here
         inflight[0] = inflight[1];
         --n_in;
+        if (n_in == 0) gpu_idle_since = now;
     };
 
     while (true) {
+        if (!running_.load() && n_in == 0 && n_pending == 0) {
+            bool idle = true;
+            for (const Staging& s : g->st) idle &= count(s) == 0;
+            if (idle) return;
+        }
+        // keep the GPU fed: closed sets go out while it has a free slot
+        if (n_pending > 0 && n_in < 2) {
+            submit_pending();
+            continue;
+        }
         Staging& s = g->st[cur];
-        const unsigned c = closed(s) ? 0u : count(s);
-        if (!running_.load() && n_in == 0 && count(g->st[0]) == 0 && count(g->st[1]) == 0) return;
-
-        if (closed(s)) {  // both sets are on the GPU: retire the older one, it becomes the fill set
-            finish_oldest();
+        if (closed(s)) {  // the ring is full: wait for the oldest batch, its set is the one callers are parked on
+            if (n_in > 0) finish_oldest();
             timing = false;
             continue;
         }
-        if (c >= want || (c > 0 && (eager || cfg_.gpu_waittime_ms <= 0 || !running_.load()))) {
-            if (c >= want) eager = false;  // traffic fills whole batches again
-            launch(cur);
-            cur ^= 1;
+        const unsigned c = count(s);
+        if (c >= want || (c > 0 && (cfg_.gpu_waittime_ms <= 0 || !running_.load()))) {
+            close_and_rotate();
             timing = false;
             continue;
         }
-        if (c > 0) {  // partial batch: give it gpu_waittime_ms, then send it and turn eager
+        if (c > 0 && n_in == 0) {
+            // partial batch and an idle GPU: give stragglers gpu_waittime_ms, then send what is there
             if (!timing) { timing = true; first_seen = clock::now(); }
             if (clock::now() - first_seen >= std::chrono::milliseconds(cfg_.gpu_waittime_ms)) {
-                eager = true;
+                close_and_rotate();
+                timing = false;
+                continue;
+            }
+        } else if (c > 0 && n_in == 1) {
+            // one batch is running and nothing is queued behind it: let the partial set keep filling, but enqueue it
+            // shortly before that batch is expected to finish, so its upload hides under the running batch's tail
+            timing = false;
+            const double run_us = std::chrono::duration<double, std::micro>(clock::now() - gpu_busy_since).count();
+            if (run_us >= 0.85 * gpu_batch_us) {
+                close_and_rotate();
                 continue;
             }
         } else {
             timing = false;
-            eager = false;  // the fill set ran dry
         }
         // nothing to send yet: retire a finished batch if there is one, else nap
         if (n_in > 0) {
@@ -433,21 +493,24 @@ void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atom
     Graph* g = graphs_[next_graph_.fetch_add(1, std::memory_order_relaxed) % graphs_.size()].get();
     const unsigned cap = static_cast<unsigned>(max_batch_);
     const unsigned want = static_cast<unsigned>(std::min(cfg_.batch_size, max_batch_));
-    for (int spins = 0;; ++spins) {
+    for (;;) {
+        const int epoch = g->epoch.load(std::memory_order_acquire);
         Staging& s = g->st[g->fill.load(std::memory_order_acquire)];
-        const unsigned r = s.reserved.fetch_add(1, std::memory_order_acq_rel);
-        if (!(r & Staging::kClosed) && r < cap) {
-            const int slot = static_cast<int>(r);
-            StageInput(&s, slot, input, false);  // the one copy of the planes, by the calling thread
-            s.reqs[slot] = Request{&input, out, done};
-            s.ready.fetch_add(1, std::memory_order_release);
-            if (r == 0 || r + 1 >= want) g->cv.notify_one();
-            return;
+        const unsigned seen = s.reserved.load(std::memory_order_acquire);
+        if (!(seen & Staging::kClosed) && seen < cap) {
+            const unsigned r = s.reserved.fetch_add(1, std::memory_order_acq_rel);
+            if (!(r & Staging::kClosed) && r < cap) {
+                const int slot = static_cast<int>(r);
+                StageInput(&s, slot, input, false);  // the one copy of the planes, by the calling thread
+                s.reqs[slot] = Request{&input, out, done};
+                s.ready.fetch_add(1, std::memory_order_release);
+                if (r == 0 || r + 1 >= want) g->cv.notify_one();
+                return;
+            }
         }
-        // set closed or full: the pump is about to rotate; back off briefly and retry
-        if (spins < 16) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        // both sets are taken (one on the GPU, one full or being rotated): sleep until the pump re-opens one
         if (!running_.load()) throw std::runtime_error("HipForwardPipe is shutting down");
+        FutexWait(&g->epoch, epoch);
     }
 }
 

@@ -77,9 +77,11 @@ public:
     size_t num_batches() const { return batches_.load(std::memory_order_relaxed); }
     size_t num_evals() const { return evals_.load(std::memory_order_relaxed); }
     // pump time split since construction, microseconds: [0] inside sayuri_hip_forward, [1] filling
-    // outputs + signalling, [2] waiting for a batch to form, [3] waiting for plane copies
-    void pump_times(double out[4]) const {
-        for (int i = 0; i < 4; ++i) out[i] = static_cast<double>(pump_ns_[i].load(std::memory_order_relaxed)) * 1e-3;
+    // outputs + signalling, [2] waiting for a batch to form, [3] waiting for plane copies, [4] waking callers parked
+    // for a staging set, [5] batches sent with fewer than batch_size requests (a count, not a time)
+    // [6] time the GPU queue was empty while the pipe was in use, [7] waiting for callers to finish their plane copies
+    void pump_times(double out[8]) const {
+        for (int i = 0; i < 8; ++i) out[i] = static_cast<double>(pump_ns_[i].load(std::memory_order_relaxed)) * 1e-3;
     }
 
 private:
@@ -105,8 +107,13 @@ private:
     struct Graph {  // one per GPU (NNGraph in the reference)
         int device{-1};
         sayuri_hip_ctx* ctx{nullptr};
-        Staging st[2];               // double buffer: one fills while the other is on the GPU
+        static constexpr int kSets = 4;  // ring of staging sets: one fills, up to two are on the GPU, the rest are
+                                         // full and queued -- with more leaves in flight than two batches the next
+                                         // batch is always ready when the GPU finishes one
+        Staging st[kSets];
         std::atomic<int> fill{0};    // index of the staging set new requests go to
+        std::atomic<int> epoch{0};   // bumped whenever a set re-opens or the fill index moves: callers that found
+                                     // both sets taken sleep on it (futex) instead of polling
         std::thread pump;
         std::mutex dev_mu;  // owner of ctx (pump batch or a direct BatchForward)
         std::mutex mu;      // pump sleep / wake-up only
@@ -128,7 +135,7 @@ private:
     std::atomic<bool> running_{false};
     std::atomic<unsigned> next_graph_{0};
     std::atomic<size_t> batches_{0}, evals_{0};
-    mutable std::atomic<long long> pump_ns_[4] = {};
+    mutable std::atomic<long long> pump_ns_[8] = {};
 };
 
 SAYURI_HOST_END

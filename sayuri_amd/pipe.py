@@ -109,11 +109,12 @@ class HipForwardPipe:
 
     def pump_times(self):
         """-> dict of pump-thread time (us) since construction + batch / eval counters."""
-        t = (ctypes.c_double * 4)()
+        t = (ctypes.c_double * 8)()
         b, e = ctypes.c_long(0), ctypes.c_long(0)
         _lib.host().sayuri_pipe_pump_times(self._h, t, ctypes.byref(b), ctypes.byref(e))
         return {"forward_us": t[0], "fill_us": t[1], "wait_batch_us": t[2], "wait_copies_us": t[3],
-                "batches": b.value, "evals": e.value}
+                "wake_parked_us": t[4], "partial_batches": int(round(t[5])), "gpu_queue_empty_us": t[6],
+                "wait_plane_copies_us": t[7], "batches": b.value, "evals": e.value}
 
     def ctx(self, gpu: int = 0) -> int:
         c = _lib.host().sayuri_pipe_ctx(self._h, gpu)

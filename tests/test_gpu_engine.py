@@ -1,0 +1,102 @@
+"""Search and self-play on the MI355X forward pipe.
+
+* fixed-seed search, fp32 engine: the golden games of tests/golden/search_games.npz were played by the REFERENCE
+  search on the reference's CPU pipe; the product engine on HipForwardPipe (fp32, abs <= 1e-4 to that pipe) must
+  choose the same moves and emit the same training records (floats within the fp32 tolerance of the network).
+* fp16 engine: same positions, the root visit distribution must stay close and the best move equal.
+* self-play loop on the GPU: many concurrent games feeding one batched queue; records and SGF come out well-formed.
+"""
+import glob
+import gzip
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from search_replay import NN_GAMES, options, records_close
+from sayuri_amd import search as S
+from sayuri_amd import weights as W
+from sayuri_amd.engine import Game
+from sayuri_amd.pipe import HipForwardPipe
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def w6b96(tmp_weights_dir):
+    path = os.path.join(tmp_weights_dir, "engine_6b96.bin")
+    if not os.path.exists(path):
+        W.write_weights(path, W.spec_6b96(), seed=21)
+    return path
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "search_games.npz"))
+
+
+def play(net, seed, board, komi, scoring, opts, nmoves):
+    game = Game(board, komi, scoring)
+    search = S.Search(game, net, options(opts), seeds=(seed, seed + 77))
+    moves = []
+    while not game.info()[10] and len(moves) < nmoves:
+        mv = search.selfplay_move()
+        moves.append(mv)
+        assert game.play(mv)
+    search.update_territory_helper()
+    racy = search.single_candidate_records()
+    return moves, search.gather_training_text(), racy
+
+
+@pytest.mark.parametrize("i", range(len(NN_GAMES)))
+def test_fixed_seed_search_reproduces_reference_moves_fp32(golden, w6b96, i):
+    seed, board, komi, scoring, opts, nmoves = NN_GAMES[i]
+    pipe = HipForwardPipe(w6b96, board_size=board, batch_size=8, fp16=False, waittime_ms=0)
+    net = S.Network(pipe=pipe, options=options(opts))
+    moves, text, racy = play(net, seed, board, komi, scoring, opts, nmoves)
+    assert moves == golden[f"nn{i}_moves"].tolist()
+    # network outputs agree to 1e-4 abs (fp32); the records' policy / value targets inherit that
+    assert records_close(zlib.decompress(golden[f"nn{i}_records"].tobytes()), text, rel=2e-3, abs_=2e-4, racy_records=racy) is None
+    assert net.queries() > 0
+    pipe.Destroy()
+
+
+def test_fp16_search_close_to_fp32(w6b96):
+    results = {}
+    for fp16 in (False, True):
+        pipe = HipForwardPipe(w6b96, board_size=9, batch_size=8, fp16=fp16, waittime_ms=0)
+        net = S.Network(pipe=pipe, options=options({}))
+        game = Game(9, 7.0, 0)
+        for mv in (40, 30, 50, 22):
+            assert game.play(mv)
+        search = S.Search(game, net, options(dict(playouts=200)), seeds=(5, 6))
+        results[fp16] = search.computation(200, S.TAG_UNREUSED)
+        search.close()
+        pipe.Destroy()
+    a, b = results[False], results[True]
+    assert a["visits"] == b["visits"] == 201
+    assert a["best_move"] == b["best_move"]
+    # visit distributions: total variation distance
+    tv = 0.5 * np.abs(a["root_visits"] / 200.0 - b["root_visits"] / 200.0).sum()
+    assert tv < 0.15, tv
+    assert abs(a["root_eval"] - b["root_eval"]) < 0.02
+
+
+def test_selfplay_on_the_gpu_queue(w6b96, tmp_path):
+    pipe = HipForwardPipe(w6b96, board_size=9, batch_size=32, fp16=True, waittime_ms=2)
+    opts = dict(playouts=48, parallel_games=64, num_games=64, seed=11, dirichlet_noise=1, first_pass_bonus=1, random_moves_factor=0.1,
+                komi_stddev=2.5, selfplay_query=["bkp:9:7:0.8", "bkp:7:9:0.2"], early_symm_cache=1, target_directory=str(tmp_path))
+    st = S.selfplay(pipe, opts, move_cap=40, name_suffix="-r0")
+    pt = pipe.pump_times()
+    assert st["games_done"] == 64 and st["chunks_saved"] == 64
+    assert st["nn_queries"] == pt["evals"] > 10000
+    assert pt["evals"] / pt["batches"] > 8, "games are not being batched together"
+    assert st["cache_hits"] > 0
+    chunks = glob.glob(str(tmp_path / "tdata" / "*-r0" / "*.gz"))
+    assert len(chunks) == 64
+    lines = gzip.open(chunks[0]).read().decode().split("\n")
+    assert (len(lines) - 1) % 53 == 0
+    assert open(glob.glob(str(tmp_path / "sgf" / "*.sgf"))[0]).read().count("(;GM[1]") == 64
+    pipe.Destroy()

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Self-play throughput on one GPU: BASELINE.json configs[2] (19x19, 20b x 256 net, 400 visits, 512 concurrent games).
+
+    python tools/selfplay_bench.py [--seconds 120] [--games 512] [--playouts 400] [--net 20b256|6b96] [--board 19]
+                                   [--num-games N] [--move-cap M] [--fp32]
+
+With --seconds the run is a time window (games in progress at the end are dropped); with --num-games it plays
+that many complete games.  Prints one JSON line with the counters and the derived rates.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=0.0)
+    ap.add_argument("--games", type=int, default=512, help="concurrent games")
+    ap.add_argument("--num-games", type=int, default=0, help="complete games to play (default: one per worker)")
+    ap.add_argument("--playouts", type=int, default=400)
+    ap.add_argument("--net", default="20b256")
+    ap.add_argument("--board", type=int, default=19)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--move-cap", type=int, default=0)
+    ap.add_argument("--waittime", type=int, default=2)
+    ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    from sayuri_amd import search as S
+    from sayuri_amd import weights as W
+    from sayuri_amd.pipe import HipForwardPipe
+
+    spec = {"20b256": W.spec_20b256, "6b96": W.spec_6b96, "40b384": W.spec_40b384}[args.net]()
+    wpath = f"/tmp/sayuri_selfplay_{args.net}_{os.getuid()}.bin"
+    if not os.path.exists(wpath):
+        W.write_weights(wpath, spec, seed=22)
+    pipe = HipForwardPipe(wpath, board_size=args.board, batch_size=args.batch, fp16=not args.fp32, waittime_ms=args.waittime)
+    opts = dict(playouts=args.playouts, parallel_games=args.games, num_games=max(args.num_games, args.games), seed=args.seed,
+                dirichlet_noise=1, dirichlet_epsilon=0.25, dirichlet_init=0.03, dirichlet_factor=361, first_pass_bonus=1,
+                random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
+                resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
+                selfplay_query=[f"bkp:{args.board}:7:1"], target_directory=args.out)
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    t0 = time.time()
+    st = S.selfplay(pipe, opts, seconds=args.seconds, move_cap=args.move_cap)
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    pt = pipe.pump_times()
+    el = st["elapsed"]
+    out = dict(st)
+    out.update(net=args.net, board=args.board, concurrent_games=args.games, playouts_per_move=args.playouts,
+               nn_evals_per_sec=round(st["nn_queries"] / el, 1), playouts_per_sec=round(st["playouts"] / el, 1),
+               moves_per_sec=round(st["moves"] / el, 2), games_per_hour=round(st["games_done"] / el * 3600, 1),
+               cache_hit_rate=round(st["cache_hits"] / max(st["cache_lookups"], 1), 4),
+               mean_batch=round(pt["evals"] / max(pt["batches"], 1), 1), partial_batches=pt["partial_batches"], batches=pt["batches"],
+               pump_us_per_batch={k: round(pt[k] / max(pt["batches"], 1)) for k in ("forward_us", "fill_us", "wait_batch_us", "wait_copies_us", "wake_parked_us", "gpu_queue_empty_us", "wait_plane_copies_us")},
+               host_cpu_cores_busy=round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / el, 1),
+               host_sys_cores=round((ru1.ru_stime - ru0.ru_stime) / el, 1), host_cpus=os.cpu_count(),
+               ctx_switches_per_sec=round(((ru1.ru_nvcsw - ru0.ru_nvcsw) + (ru1.ru_nivcsw - ru0.ru_nivcsw)) / el),
+               wall=round(time.time() - t0, 1))
+    print(json.dumps(out))
+    pipe.Destroy()
+
+
+if __name__ == "__main__":
+    main()
