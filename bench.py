@@ -106,6 +106,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile", action="store_true", help="also print the per-kernel-class table to stderr")
+    ap.add_argument("--selfplay-seconds", type=float, default=40.0,
+                    help="length of the self-play window (configs[2]: 512 concurrent 19x19 games, 400 visits); 0 = skip")
+    ap.add_argument("--selfplay-games", type=int, default=512, help="concurrent self-play games per GPU")
+    ap.add_argument("--selfplay-visits", type=int, default=400)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,6 +187,33 @@ def main():
         elapsed = stats["elapsed_max"]
         assert stats["nn_queries"] == world * n * args.steps
 
+    # ---- second segment: the self-play loop on the same pipe (encoder + search + cache + batched queue + PCIe), one
+    # engine per rank, games sharded by rank, no data-path collective
+    selfplay = None
+    if args.selfplay_seconds > 0:
+        from sayuri_amd import search as S
+        from sayuri_amd.shard import gather_stats
+        sp_opts = dict(playouts=args.selfplay_visits, parallel_games=args.selfplay_games, num_games=1000000, seed=1000 + rank,
+                       dirichlet_noise=1, dirichlet_epsilon=0.25, dirichlet_init=0.03, dirichlet_factor=361, first_pass_bonus=1,
+                       random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
+                       resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
+                       selfplay_query=["bkp:19:7:1"])
+        if dist is not None:
+            dist.barrier()
+        st = S.selfplay(pipe, sp_opts, seconds=args.selfplay_seconds, name_suffix=f"-r{rank}")
+        pt = pipe.pump_times()
+        tot = gather_stats({"games_done": st["games_done"], "nn_queries": st["nn_queries"], "nn_batches": pt["batches"],
+                            "cache_hits": st["cache_hits"], "moves": st["moves"], "playouts": st["playouts"], "records": st["records"],
+                            "elapsed": st["elapsed"]})
+        el = tot["elapsed_max"]
+        selfplay = {"workload": "configs[2]: 19x19, 20b x 256 net, %d visits/move, %d concurrent games per GPU, Dirichlet noise, "
+                                "NN cache 400 MiB; time window (games in progress are not counted as done)" % (args.selfplay_visits, args.selfplay_games),
+                    "seconds": round(el, 2), "nn_evals_per_sec": round(tot["nn_queries"] / el, 1),
+                    "playouts_per_sec": round(tot["playouts"] / el, 1), "moves_per_sec": round(tot["moves"] / el, 2),
+                    "games_done": int(tot["games_done"]), "games_per_hour_in_window": round(tot["games_done"] / el * 3600, 1),
+                    "mean_batch": round(tot["nn_queries"] / max(tot["nn_batches"], 1), 1),
+                    "frac_of_microbench_evals": None}
+
     result = None
     if rank == 0:
         flops_eval = algorithmic_flops_per_eval(spec)
@@ -211,6 +242,9 @@ def main():
                          "avg_launch_us": round(stat.total_ms / max(stat.launches, 1) * 1e3, 2),
                          "flops_per_launch": stat.flops / max(stat.launches, 1)},
         }
+        if selfplay is not None:
+            selfplay["frac_of_microbench_evals"] = round(selfplay["nn_evals_per_sec"] / value, 4)
+            result["selfplay"] = selfplay
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wpath, planes, args.cpu_seconds)
         if args.profile:

@@ -1,0 +1,96 @@
+/* sayuri_engine.h -- C entry points of the host library (libsayuri_host.so): the weight loader, the
+ * NetworkForwardPipe built on the HIP library, the Go engine (board / game state / input encoder), the
+ * evaluation facade, the tree search and the self-play loop.
+ *
+ * Everything here sits ABOVE the device boundary of include/sayuri_hip.h and is what a non-C++ front end binds
+ * (the Python face under sayuri_amd/ does, with ctypes).  A C++ program embeds the classes directly
+ * (sayuri_amd/csrc/host/hip_forward_pipe.h, sayuri_amd/csrc/engine/{game_state,encoder,network,search,selfplay}.h).
+ *
+ * Conventions: handles are opaque pointers; functions returning int give 0 on success and -1 on failure with the
+ * message in sayuri_host_last_error() / sayuri_engine_last_error(); moves are intersection indices (0..N-1 row
+ * major, N = pass, -1 = resign); colours are 0 black, 1 white, 2 empty; options are "key=value key=value" text
+ * with the names of the reference's option map (src/config.cc:21-133).
+ */
+#ifndef SAYURI_ENGINE_H
+#define SAYURI_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- weights (reference DNNLoader, src/neural/loader.cc:26-121,628-831) ------------------------------------ */
+const char* sayuri_host_last_error(void);
+void* sayuri_weights_load(const char* path);
+void sayuri_weights_free(void* weights);
+int sayuri_weights_info(void* weights, int* info12);
+int sayuri_weights_block_info(void* weights, int block, int* binfo5);
+long sayuri_weights_tensor(void* weights, const char* name, float* dst, long cap);
+
+/* ---- forward pipe (reference NetworkForwardPipe / BatchForwardPipe, src/neural/network_basic.h:132-161,
+ *      src/neural/batch_forward_pipe.cc:7-193) ---------------------------------------------------------------- */
+void* sayuri_pipe_create(const char* weights_path, int board, int batch, int fp16, int device, int waittime_ms);
+void sayuri_pipe_destroy(void* pipe);
+int sayuri_pipe_num_workers(void* pipe);
+void* sayuri_pipe_ctx(void* pipe, int gpu);                 /* the sayuri_hip_ctx of one GPU */
+int sayuri_pipe_reconstruct(void* pipe, int board, int batch);
+void* sayuri_pipe_raw(void* pipe);                          /* as NetworkForwardPipe*, for the engine entry points */
+int sayuri_pipe_weights_version(void* pipe);
+int sayuri_pipe_eval(void* pipe, int mode, int gpu, int n, const float* planes, const int* board_sizes,
+                     const float* komi, const int* offsets, float* out);
+int sayuri_pipe_netbench(void* pipe, int threads, double seconds, int board, double* evals_per_sec, long* total);
+void sayuri_pipe_pump_times(void* pipe, double* out8, long* batches, long* evals);
+
+/* ---- Go engine (reference GameState / Board / Encoder, src/game/game_state.h, src/game/board.h,
+ *      src/neural/encoder.h:24-61) -------------------------------------------------------------------------- */
+void* sayuri_go_new(int board, float komi, int scoring);
+void* sayuri_go_clone(void* game);
+void sayuri_go_free(void* game);
+int sayuri_go_play(void* game, int move, int color);        /* color < 0: side to move; returns 1 if legal */
+int sayuri_go_append(void* game, int move, int color);      /* set-up stone */
+int sayuri_go_undo(void* game);
+int sayuri_go_fixed_handicap(void* game, int stones);
+void sayuri_go_set_komi(void* game, float komi);
+void sayuri_go_set_rule(void* game, int scoring);
+void sayuri_go_set_to_move(void* game, int color);
+void sayuri_go_set_territory_helper_from_ownership(void* game);
+void sayuri_go_freeze(void* game);
+void sayuri_go_info(void* game, uint64_t* info16);
+void sayuri_go_scalars(void* game, float* out6);
+void sayuri_go_maps(void* game, uint8_t* out /* [9][N+1] */);
+int sayuri_go_planes(void* game, int symmetry, int weights_version, float* planes /* [43|38][N] */);
+void sayuri_go_rng_stream(uint64_t seed, int n, uint32_t range, double prob, uint64_t* out /* [3n] */);
+
+/* ---- evaluation facade and tree search (reference Network, src/neural/network.h:17-98; Search,
+ *      src/mcts/search.h:155-296) --------------------------------------------------------------------------- */
+const char* sayuri_engine_last_error(void);
+void* sayuri_engine_net_new_pipe(void* raw_pipe, int weights_version, const char* options);
+/* tests: a C forward function instead of a pipe (kind 0: fn(bs, komi, stm, offset, planes, out); kind 1:
+ * fn(user, bs, komi, offset, planes, out)); fn == NULL selects the dummy random-output backend */
+void* sayuri_engine_net_new_callback(void* forward_fn, int kind, const void* user, int weights_version, const char* options);
+void sayuri_engine_net_free(void* net);
+unsigned long sayuri_engine_net_queries(void* net);
+void sayuri_engine_net_output(void* net, void* game, int ensemble, int symmetry, float temperature, int use_cache,
+                              uint64_t seed, float* out /* [2N+9] */);
+void* sayuri_engine_search_new(void* game, void* net, const char* options);
+void sayuri_engine_search_free(void* search);
+void sayuri_engine_search_seed(void* search, uint64_t caller_seed, uint64_t playout_seed);
+void sayuri_engine_search_computation(void* search, void* game, int playouts, int tag, int* ints16, float* floats8,
+                                      int* visits, float* estimated_q, float* target_policy, float* ownership);
+int sayuri_engine_search_selfplay_move(void* search, void* game, int tag);
+int sayuri_engine_search_think(void* search, void* game);
+void sayuri_engine_search_update_territory_helper(void* search);
+int sayuri_engine_search_single_candidate(void* search, int* record_indices, int cap);
+long sayuri_engine_search_gather(void* search, char* text, long cap); /* the game's 53-line training records */
+
+/* ---- self-play (reference SelfPlayPipe + Engine, src/selfplay/pipe.cc, src/selfplay/engine.cc) -------------- */
+/* raw_pipe == NULL: dummy backend.  seconds > 0: time window; otherwise plays num_games complete games.
+ * stats[10]: games_started, games_done, moves, playouts, nn_queries, cache_lookups, cache_hits, records, chunks, 0 */
+int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
+                        int move_cap, uint64_t* stats, double* elapsed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAYURI_ENGINE_H */

@@ -10,7 +10,7 @@ from typing import Dict, Tuple
 import torch
 import torch.distributed as dist
 
-STAT_KEYS = ("games_done", "nn_queries", "nn_batches", "cache_hits", "elapsed")
+STAT_KEYS = ("games_done", "nn_queries", "nn_batches", "cache_hits", "moves", "playouts", "records", "elapsed")
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:

@@ -44,3 +44,36 @@ def test_sharded_stats_gather_gloo_world2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_selfplay_sharded_by_rank_gloo_world2(tmp_path):
+    """Self-play shards by games: every rank runs its own engine (here on the dummy backend) and writes its own
+    chunk directory; the only exchange is the stats gather.  Two gloo ranks on CPU."""
+    out = tmp_path / "data"
+    out.mkdir()
+    script = tmp_path / "sp.py"
+    script.write_text(
+        "import os, sys, glob\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from sayuri_amd import search as S\n"
+        "from sayuri_amd.shard import shard_range, gather_stats\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "lo, hi = shard_range(6, r, w)\n"
+        f"opts = dict(playouts=80, parallel_games=hi - lo, num_games=hi - lo, seed=100 + r, selfplay_query=['bkp:9:7:1'], target_directory={str(out)!r})\n"
+        "st = S.selfplay(None, opts, name_suffix=f'-r{r}')\n"
+        "tot = gather_stats({'games_done': st['games_done'], 'nn_queries': st['nn_queries'], 'moves': st['moves'], 'records': st['records'], 'elapsed': st['elapsed']})\n"
+        "dist.barrier()\n"
+        "if r == 0:\n"
+        "    assert tot['games_done'] == 6 and tot['moves'] > 100 and tot['records'] > 100, tot\n"
+        f"    dirs = sorted(os.path.basename(d) for d in glob.glob({str(out)!r} + '/tdata/*'))\n"
+        "    assert len(dirs) == 2 and dirs[0].endswith('-r0') or dirs[0].endswith('-r1'), dirs\n"
+        f"    assert len(glob.glob({str(out)!r} + '/tdata/*/game_*.txt.gz')) == 6\n"
+        "    print('OK')\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

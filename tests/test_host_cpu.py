@@ -87,6 +87,16 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, sym), sym
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/sayuri_engine.h lists the host library's C entry points: declared == exported."""
+    import subprocess
+    header = open(os.path.join(ROOT, "include", "sayuri_engine.h")).read()
+    declared = set(re.findall(r"\b(sayuri_[a-z_]+)\s*\(", header))
+    nm = subprocess.run(["nm", "-D", "--defined-only", _build.HOST_SO], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if " T sayuri_" in line}
+    assert declared == exported, declared ^ exported
+
+
 @pytest.mark.skipif(_lib.hip().sayuri_hip_device_count() > 0, reason="a GPU is present")
 def test_fails_loudly_without_gpu(tmp_weights_dir):
     from sayuri_amd.pipe import HipForwardPipe
