@@ -235,7 +235,7 @@ def main():
                        "whole_net_tflops": round(value * flops_eval / 1e12, 2),
                        "whole_net_mfma_frac": round(value * flops_eval / 1e12 / (peak * world), 4),
                        "device_ms_per_step": round(ms.value / args.steps, 4)},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (conv3x3_tower, 256->256 3x3)",
+            "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<8,3> (conv3x3_tower, 256->256 3x3)",
                          "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4) if ach else None, "traffic": None,
                          "launches_timed": int(stat.launches),
