@@ -424,6 +424,7 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                     std::free(warm);
                 }
             }
+            try {
             while (!stop_.load(std::memory_order_relaxed) && accumulation_games_.fetch_add(1) < max_games_) {
                 started.fetch_add(1);
                 auto item = std::make_shared<DataSgf>();
@@ -448,6 +449,12 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                 std::lock_guard<std::mutex> lock(data_mu_);
                 data_queue_.push_back(item);
                 queries_queue_.emplace_back(played, std::string("hip ") + std::to_string(engine_.network().GetNumQueries()));
+            }
+            } catch (const std::exception& e) {
+                // a failing backend ends the run: remember the first message, stop the other workers
+                std::lock_guard<std::mutex> lock(data_mu_);
+                if (error_.empty()) error_ = e.what();
+                stop_.store(true);
             }
         });
     }
@@ -479,6 +486,7 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
     if (!timed_out) snapshot(st);
     writer_running_.store(false);
     writer.join();
+    if (!error_.empty()) throw std::runtime_error("self-play worker failed: " + error_);
     st.records = records_.load();
     st.chunks_saved = chunks_.load();
     return st;

@@ -99,6 +99,7 @@ private:
     std::atomic<bool> stop_{false};
     std::atomic<std::uint64_t> records_{0}, chunks_{0};
     int max_games_{0};
+    std::string error_;
 };
 
 float AdjustKomiToHalf(float komi); // utils/komi.cc AdjustKomi<float>

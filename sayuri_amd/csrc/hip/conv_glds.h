@@ -46,13 +46,19 @@ template <int OFF> __device__ __forceinline__ void ds_read16(f16x8& dst, uint32_
 // Wait until at most N younger LDS reads are outstanding.  The fragments named here count as
 // (re)defined by the wait, so no consumer can be scheduled above it.
 template <int N, int NB> __device__ __forceinline__ void wait_frags(f16x8& a, f16x8 (&b)[NB]) {
-    static_assert(NB >= 1 && NB <= 4, "unsupported fragment count");
+    static_assert(NB >= 1 && NB <= 6, "unsupported fragment count");
     if constexpr (NB == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b[0]) : "n"(N));
     else if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b[0]), "+v"(b[1]) : "n"(N));
     else if constexpr (NB == 3)
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N));
-    else
+    else if constexpr (NB == 4)
         asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+    else if constexpr (NB == 5)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]) : "n"(N));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%7)"
+                     : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5])
+                     : "n"(N));
 }
 
 // compile-time loop: f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N-1>{})
@@ -63,11 +69,13 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int WMT_, int WNT_> struct GldsCfg {
-    static constexpr int WMT = WMT_, WNT = WNT_, WAVM = 2, WAVN = 4, NWAVE = 8;
+// WAVN = wave columns of the workgroup (2 wave rows always): 4 -> eight waves, two per SIMD; 2 -> four waves, one
+// per SIMD, each with a twice as wide register tile (fewer LDS fragment reads per MFMA, 512 registers per lane).
+template <int WMT_, int WNT_, int WAVN_ = 4> struct GldsCfg {
+    static constexpr int WMT = WMT_, WNT = WNT_, WAVM = 2, WAVN = WAVN_, NWAVE = WAVM * WAVN;
     static constexpr int KO_T = WAVM * WMT * 16;
     static constexpr int PT = WAVN * WNT * 16;
-    static constexpr int NT = 512;
+    static constexpr int NT = 64 * NWAVE;
     static constexpr int NPOS_CAP = ((PT + PT / 4 + 128 + 63) / 64) * 64;  // halo positions, multiple of 64
     static constexpr int A_INSTR = KO_T * 64 / 1024;                      // 1 KiB DMA instructions per tap tile
     static constexpr int AI = A_INSTR / NWAVE;                            // per wave per tap
@@ -81,7 +89,7 @@ template <int WMT_, int WNT_> struct GldsCfg {
     static constexpr int STAGE_BYTES = (PT / 2) * STAGE_RS;
     static constexpr int RING_BYTES = 2 * A_BYTES + 2 * B_BYTES;
     static_assert(A_INSTR % NWAVE == 0, "KO_T must be a multiple of 128");
-    static_assert(BI <= 3, "halo DMA is spread over the three taps of a row");
+    static_assert(BI <= 6, "halo DMA is spread over the six DMA slots of a group");
     static_assert(STAGE_BYTES <= RING_BYTES, "the epilogue staging tile re-uses the DMA rings");
     static constexpr int ROWID_OFF = RING_BYTES;                          // int rowid[PT] behind the rings
     static constexpr size_t lds_bytes() { return RING_BYTES + PT * 4; }
@@ -164,27 +172,28 @@ __global__ __launch_bounds__(256) void tile_setup_kernel(BatchGeom g, int* __res
 // Cooperative second half of the epilogue: whole rows out of the fp32 staging tile.
 // EpiRows holds, per lane, the output row ids and residual rows of one phase; they are fetched for
 // BOTH phases before the first staging pass, so one memory latency covers the whole epilogue.
-template <int KO_T, int PT> struct EpiRows {
+template <int KO_T, int PT, int NW = 8> struct EpiRows {
     static constexpr int HALF = PT / 2;
-    static constexpr int LPR = KO_T / 8;         // lanes per row (8 channels = 16 B of fp16 each)
-    static constexpr int RPI = 64 / LPR;         // rows per wave instruction
-    static constexpr int NR = HALF / (8 * RPI);  // rows per lane per phase
-    static_assert(HALF % (8 * RPI) == 0, "rows must split evenly over the waves");
+    static constexpr int LPR = KO_T / 8;          // lanes per row (8 channels = 16 B of fp16 each)
+    static constexpr int RPI = 64 / LPR;          // rows per wave instruction
+    static constexpr int NR = HALF / (NW * RPI);  // rows per lane per phase
+    static constexpr int STEP = NW * RPI;         // row distance between a lane's consecutive rows
+    static_assert(HALF % (NW * RPI) == 0, "rows must split evenly over the waves");
     int grow[NR];
     f16x8 rr[NR];
 };
 
-template <int KO_T, int PT>
-__device__ __forceinline__ void epi_fetch(EpiRows<KO_T, PT>& e, const GldsParams& gp, const int* rowid, int phase,
+template <int KO_T, int PT, int NW>
+__device__ __forceinline__ void epi_fetch(EpiRows<KO_T, PT, NW>& e, const GldsParams& gp, const int* rowid, int phase,
                                           int kt, int wave, int lane) {
-    using E = EpiRows<KO_T, PT>;
+    using E = EpiRows<KO_T, PT, NW>;
     const ConvParams& p = gp.c;
     const f16* __restrict__ gres = (const f16*)p.res;
     const int ko = kt * KO_T + (lane % E::LPR) * 8;
     const bool ko_ok = ko < p.cout_s;  // cout_s is a multiple of 32, so 8-channel groups never straddle it
     const int r0 = wave * E::RPI + lane / E::LPR;
 #pragma unroll
-    for (int k = 0; k < E::NR; ++k) e.grow[k] = ko_ok ? rowid[phase * E::HALF + r0 + k * 8 * E::RPI] : -1;
+    for (int k = 0; k < E::NR; ++k) e.grow[k] = ko_ok ? rowid[phase * E::HALF + r0 + k * E::STEP] : -1;
     if (gres) {
 #pragma unroll
         for (int k = 0; k < E::NR; ++k)
@@ -193,10 +202,10 @@ __device__ __forceinline__ void epi_fetch(EpiRows<KO_T, PT>& e, const GldsParams
     }
 }
 
-template <int ACT, int KO_T, int PT>
-__device__ __forceinline__ void epi_store(const EpiRows<KO_T, PT>& e, const GldsParams& gp, const unsigned char* stage,
+template <int ACT, int KO_T, int PT, int NW>
+__device__ __forceinline__ void epi_store(const EpiRows<KO_T, PT, NW>& e, const GldsParams& gp, const unsigned char* stage,
                                           int kt, int wave, int lane) {
-    using E = EpiRows<KO_T, PT>;
+    using E = EpiRows<KO_T, PT, NW>;
     constexpr int RS = KO_T * 4 + 16;
     const ConvParams& p = gp.c;
     f16* __restrict__ gout = (f16*)p.out;
@@ -205,7 +214,7 @@ __device__ __forceinline__ void epi_store(const EpiRows<KO_T, PT>& e, const Glds
     const int r0 = wave * E::RPI + lane / E::LPR;
 #pragma unroll
     for (int k = 0; k < E::NR; ++k) {
-        const unsigned char* src = stage + (r0 + k * 8 * E::RPI) * RS + col * 4;
+        const unsigned char* src = stage + (r0 + k * E::STEP) * RS + col * 4;
         const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 16);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (p.res) {
@@ -221,10 +230,10 @@ __device__ __forceinline__ void epi_store(const EpiRows<KO_T, PT>& e, const Glds
 
 // ABL: timing-only ablation mask (never used by the engine proper): 1 = no weight DMA after the
 // first group, 2 = no halo DMA after the first chunk, 8 = no epilogue.
-template <int WMT, int WNT, int ABL = 0>
-__global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
-    using Cfg = GldsCfg<WMT, WNT>;
-    constexpr int KO_T = Cfg::KO_T, PT = Cfg::PT, WAVN = Cfg::WAVN;
+template <int WMT, int WNT, int ABL = 0, int WAVN_ = 4>
+__global__ __launch_bounds__(128 * WAVN_) void conv_glds_kernel(const GldsParams gp) {
+    using Cfg = GldsCfg<WMT, WNT, WAVN_>;
+    constexpr int KO_T = Cfg::KO_T, PT = Cfg::PT, WAVN = Cfg::WAVN, NWAVE = Cfg::NWAVE;
     constexpr int AI = Cfg::AI, BI = Cfg::BI, NPOS = Cfg::NPOS;
     const ConvParams& p = gp.c;
 
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
     int bdst[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-        const int q = wave + 8 * i, kgq = q & 3, blk = q >> 2;
+        const int q = wave + NWAVE * i, kgq = q & 3, blk = q >> 2;
         const int src = gp.tab_src[(size_t)tile * NPOS + blk * 64 + lane];
         bsrc[i] = src >= 0 ? gin + ((size_t)src * p.cin_s + kgq * 8) * 2 : (const unsigned char*)gp.zeros;
         bdst[i] = (kgq * NPOS + blk * 64) * 16;
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
     int adst[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int q = wave + 8 * i;
+        const int q = wave + NWAVE * i;
         const int kgq = q / (KO_T / 64), part = q % (KO_T / 64);
         aoff[i] = (((size_t)kgq * p.ko_pad + (size_t)kt * KO_T + part * 64 + lane) * 8) * 2;
         adst[i] = (kgq * KO_T + part * 64) * 16;
@@ -347,9 +356,11 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
                 // DMA of the next group, front-loaded: block 0: tap 0 + halo piece 0, block WMT/2:
                 // tap 1, block WMT: tap 2 + halo piece 1, block 3*WMT/2: halo piece 2.
                 constexpr int SP = (ABL & 32) ? (WMT / 4 > 0 ? WMT / 4 : 1) : WMT / 2;  // DMA slot spacing
-                if constexpr (q % SP == 0 && q / SP < 4) {
+                constexpr int NSLOT = BI > 3 ? 6 : 4;
+                if constexpr (q % SP == 0 && q / SP < NSLOT) {
                     constexpr int slot = q / SP;
-                    constexpr int bpiece = slot == 0 ? 0 : slot == 2 ? 1 : slot == 3 ? 2 : -1;
+                    // halo pieces: three or fewer go out at slots 0, 2, 3; more than three one per slot
+                    constexpr int bpiece = BI > 3 ? slot : (slot == 0 ? 0 : slot == 2 ? 1 : slot == 3 ? 2 : -1);
                     constexpr int atap = slot < 3 ? slot : -1;
                     if constexpr (!(ABL & 2) && bpiece >= 0 && bpiece < BI) {
                         if (row == 0 && more_b) issue_b1(chunk + 1, bpiece);
@@ -361,8 +372,8 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
                 if constexpr ((ABL & 64) && q == NQ / 2) {
                     // warm L2 / Infinity Cache with this tile's residual rows while the MFMAs run:
                     // group G touches rows G*8+wave .. (PT rows total => PT/8 groups)
-                    if (p.res && G < PT / 8) {
-                        const int grow = rowid[G * 8 + wave];
+                    if (p.res && G < PT / NWAVE) {
+                        const int grow = rowid[G * NWAVE + wave];
                         if (grow >= 0) {
                             const char* src = (const char*)p.res + ((size_t)grow * p.cout_s + kt * KO_T) * 2 + (lane % (KO_T / 8)) * 16;
                             uint4 dummy;
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
         __builtin_amdgcn_s_barrier();
     };
     lds_barrier();  // rowid visible, rings no longer read
-    EpiRows<KO_T, PT> rows0, rows1;
+    EpiRows<KO_T, PT, NWAVE> rows0, rows1;
     epi_fetch(rows0, gp, rowid, 0, kt, wave, lane);
     epi_fetch(rows1, gp, rowid, 1, kt, wave, lane);
 #pragma unroll
@@ -425,14 +436,14 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
         if constexpr (ABL & 16) {
             if (dbg) dbg[(28 + phase) * 4 + 0] = __builtin_amdgcn_s_memtime();
         }
-        if ((wave_n >> 1) == phase) {
+        if ((wave_n / (WAVN / 2)) == phase) {
 #pragma unroll
             for (int i = 0; i < WMT; ++i) {
                 const int kol = wave_m * WMT * 16 + i * 16 + 4 * (lane >> 4);  // channel inside the tile
                 const f32x4 bias = *(const f32x4*)(p.bias + kt * KO_T + kol);
 #pragma unroll
                 for (int j = 0; j < WNT; ++j) {
-                    const int rl = ((wave_n & 1) * WNT + j) * 16 + (lane & 15);
+                    const int rl = ((wave_n % (WAVN / 2)) * WNT + j) * 16 + (lane & 15);
                     *(f32x4*)(stage + rl * RS + kol * 4) = acc[i][j] + bias;
                 }
             }
@@ -441,16 +452,16 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const GldsParams gp) {
         if constexpr (ABL & 16) {
             if (dbg) dbg[(28 + phase) * 4 + 1] = __builtin_amdgcn_s_memtime();
         }
-        const EpiRows<KO_T, PT>& rows = phase ? rows1 : rows0;
+        const EpiRows<KO_T, PT, NWAVE>& rows = phase ? rows1 : rows0;
         switch (p.act) {
-        case kMish: epi_store<kMish, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
-        case kIdentity: epi_store<kIdentity, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
-        case kReLU: epi_store<kReLU, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
-        case kSwish: epi_store<kSwish, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
-        case kELU: epi_store<kELU, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
-        case kSELU: epi_store<kSELU, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
-        case kGELU: epi_store<kGELU, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
-        default: epi_store<kHardSwish, KO_T, PT>(rows, gp, stage, kt, wave, lane); break;
+        case kMish: epi_store<kMish, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
+        case kIdentity: epi_store<kIdentity, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
+        case kReLU: epi_store<kReLU, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
+        case kSwish: epi_store<kSwish, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
+        case kELU: epi_store<kELU, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
+        case kSELU: epi_store<kSELU, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
+        case kGELU: epi_store<kGELU, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
+        default: epi_store<kHardSwish, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
         }
         if constexpr (ABL & 16) {
             if (dbg) dbg[(28 + phase) * 4 + 2] = __builtin_amdgcn_s_memtime();

@@ -50,7 +50,9 @@ template <typename T, int WMT_, int WNT_> struct ConvCfg {
     static constexpr int KO_T = WAVM * WMT * 16;
     static constexpr int PT = WAVN * WNT * 16;
     static constexpr int NT = 64 * WAVM * WAVN;
-    static constexpr int NPOS_CAP = PT + PT / 4 + 128;
+    // halo positions a pixel tile may need: a tile over several small boards pays a one-cell frame per board
+    // (worst mixes of 9/13/19 boards measured: 304 @ PT 128, 400 @ 192, 480 @ 256)
+    static constexpr int NPOS_CAP = PT + PT / 2 + 160;
     static size_t lds_bytes(int npos) {
         return kHdrBytes + ((npos * 4 + 15) & ~15) + 2 * (size_t)KO_T * kChunk * sizeof(T) +
                2 * (size_t)npos * kChunk * sizeof(T);

@@ -83,20 +83,22 @@ struct GldsEntry {
     void (*setup)(BatchGeom, int*, int2*);
     size_t lds;
     int npos_cap, npos, pt;
+    int threads;  // workgroup size: 512 (two waves per SIMD) or 256 (one wave per SIMD, twice as wide register tiles)
 };
 static std::vector<GldsEntry>& glds_entries() {
     static std::vector<GldsEntry> e;
     return e;
 }
-template <int WMT, int WNT> static void register_glds() {
-    typedef GldsCfg<WMT, WNT> Cfg;
-    glds_entries().push_back({WMT, WNT, &conv_glds_kernel<WMT, WNT>, &tile_setup_kernel<Cfg::PT, Cfg::NPOS>,
-                              Cfg::lds_bytes(), Cfg::NPOS_CAP, Cfg::NPOS, Cfg::PT});
+template <int WMT, int WNT, int WAVN = 4> static void register_glds() {
+    typedef GldsCfg<WMT, WNT, WAVN> Cfg;
+    glds_entries().push_back({WMT, WNT, &conv_glds_kernel<WMT, WNT, 0, WAVN>, &tile_setup_kernel<Cfg::PT, Cfg::NPOS>,
+                              Cfg::lds_bytes(), Cfg::NPOS_CAP, Cfg::NPOS, Cfg::PT, Cfg::NT});
 }
 static void register_all_glds() {
     if (!glds_entries().empty()) return;
     register_glds<8, 3>(); register_glds<8, 2>(); register_glds<8, 1>();
     register_glds<4, 3>(); register_glds<4, 2>(); register_glds<4, 1>();
+    register_glds<8, 6, 2>();  // four-wave variant of the <8,3> tile (same 256 x 192 workgroup tile and tile tables)
     if (const char* abl = getenv("SAYURI_ABL")) {  // timing-only ablations of the <8,3> kernel
         GldsEntry& e = glds_entries()[0];
         switch (atoi(abl)) {
@@ -121,12 +123,13 @@ static void enable_big_lds_glds() {
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
 }
 // SAYURI_CONV=v0 | glds[:wnt]   (tuning / A-B switch; default = glds, auto tile)
-struct ConvOverride { bool v0 = false; int wnt = 0; };
+struct ConvOverride { bool v0 = false; int wnt = 0; bool four_wave = false; };
 static ConvOverride conv_override() {
     ConvOverride o;
     const char* e = getenv("SAYURI_CONV");
     if (!e) return o;
     if (!strncmp(e, "v0", 2)) { o.v0 = true; return o; }
+    if (!strncmp(e, "glds4", 5)) { o.four_wave = true; return o; }
     if (!strncmp(e, "glds", 4)) (void)sscanf(e, "glds:%d", &o.wnt);
     return o;
 }
@@ -200,8 +203,9 @@ static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_
     double best_cost = 1e30;
     for (const auto& e : glds_entries()) {
         if (e.wmt != wmt) continue;
+        if ((e.threads == 256) != ov.four_wave && !(ov.four_wave && wmt != 8)) continue;
         if (ov.wnt && e.wnt != ov.wnt) continue;
-        const int PT = 64 * e.wnt;
+        const int PT = e.pt;
         int npos, nsub;
         geom.tile_bounds(PT, &npos, &nsub);
         if (npos > e.npos_cap || nsub > kMaxSub || e.lds > kMaxLds) continue;
@@ -786,8 +790,9 @@ private:
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
             const auto fn = gc->e->fn;
             const size_t lds = gc->e->lds;
+            const int threads = gc->e->threads;
             const int grid = gc->ntiles * (L.ko_pad / (gc->e->wmt * 32));
-            return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, gp); });
+            return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, stream_, gp); });
         }
         const int kot = L.wmt * 32, kot_tiles = L.ko_pad / kot;
         TileChoice tc;
@@ -1228,7 +1233,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
             p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;
             p.num_pix_tiles = g_ntiles;
             gp.zeros = dz;
-            hipLaunchKernelGGL(ge->fn, dim3(g_ntiles * (ko_pad / (ge->wmt * 32))), dim3(512), ge->lds, 0, gp);
+            hipLaunchKernelGGL(ge->fn, dim3(g_ntiles * (ko_pad / (ge->wmt * 32))), dim3(ge->threads), ge->lds, 0, gp);
             HIP_OK(hipGetLastError());
             HIP_OK(hipDeviceSynchronize());
         }

@@ -91,6 +91,28 @@ def test_mixed_board_batch_matches_native_evaluation(tmp_weights_dir):
         pipe.Destroy()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 7])
+@pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
+def test_full_mixed_batches_fit_a_tile_configuration(seed, fp16, tmp_weights_dir):
+    """256 samples of randomly mixed 9/13/19 boards (what a mixed-size self-play queue produces): pixel tiles that
+    straddle several small boards need up to 1.6x their pixel count in halo positions -- every layer, including the
+    1x1 head convolutions of the generic kernel, must still find a tile configuration (seed 1 used to fail with
+    "no conv tile configuration fits this batch geometry").  Spot-checked against the oracle."""
+    g = Golden("net_6b96", tmp_weights_dir)
+    oracle = PortNet(g.weights_path)
+    rng = np.random.default_rng(seed)
+    bsz = [int(b) for b in rng.choice([9, 13, 19], size=256)]
+    planes = W.synthetic_planes(len(bsz), bsz, seed=seed)
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=256, fp16=fp16)
+    try:
+        outs = pipe.BatchForward(planes, bsz)
+        for i in (0, 17, 101, 255):
+            exp = oracle.forward(planes[i], bsz[i])
+            assert np.abs(outs[i] - exp).max() <= (FP16_ATOL if fp16 else FP32_ATOL), (i, bsz[i])
+    finally:
+        pipe.Destroy()
+
+
 def test_batch256_properties_20b256(tmp_weights_dir):
     """Full bench size (batch 256, 19x19, 20b256, fp16): size-independent properties --
     a sample's result does not depend on its slot or on its neighbours, duplicated inputs give

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--out", default="")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--boards", default="", help="comma list of board sizes drawn uniformly per game (mixed-size batches), e.g. 9,13,19")
     args = ap.parse_args()
 
     from sayuri_amd import search as S
@@ -48,7 +49,8 @@ def main():
                 dirichlet_noise=1, dirichlet_epsilon=0.25, dirichlet_init=0.03, dirichlet_factor=361, first_pass_bonus=1,
                 random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
                 resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
-                selfplay_query=[f"bkp:{args.board}:7:1"], target_directory=args.out)
+                selfplay_query=([f"bkp:{b}:7:1" for b in args.boards.split(",")] if args.boards else [f"bkp:{args.board}:7:1"]),
+                target_directory=args.out)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.time()
