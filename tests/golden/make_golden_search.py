@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from sayuri_amd import weights as W  # noqa: E402
 from sayuri_amd.engine import GoApi  # noqa: E402
-from search_replay import DUMMY_GAMES, NN_GAMES, REF_SO, RefSearchApi, ref_selfplay_game  # noqa: E402
+from search_replay import DUMMY_GAMES, NN_GAMES, REF_SO, THINK_GAMES, RefSearchApi, ref_selfplay_game, ref_think_game  # noqa: E402
 
 
 def main():
@@ -36,6 +36,10 @@ def main():
         out[f"dummy{i}_moves"] = np.array(moves, np.int16)
         out[f"dummy{i}_records"] = np.frombuffer(zlib.compress(text, 9), np.uint8)
         print(f"dummy game {i}: board {board}, {len(moves)} moves, {len(text)} bytes of records", file=sys.stderr)
+    for i, (seed, board, komi, scoring, opts) in enumerate(THINK_GAMES):
+        moves = ref_think_game(api, go_api, seed, board, komi, scoring, opts)
+        out[f"think{i}_moves"] = np.array(moves, np.int16)
+        print(f"think game {i}: board {board}, {len(moves)} moves, last {moves[-1]}", file=sys.stderr)
     wpath = "/tmp/sayuri_golden_6b96_seed21.bin"
     W.write_weights(wpath, W.spec_6b96(), seed=21)
     assert api.lib.ref_init(wpath.encode(), 1) == 0

@@ -47,6 +47,15 @@ NN_GAMES = [
 ]
 
 
+# Fixed-seed games played with ThinkBestMove (the genmove path: resign / friendly-pass / capture-all-dead policy) on the
+# dummy backend: (seed, board, komi, scoring, options)
+THINK_GAMES = [
+    (21, 9, 7.0, 0, dict(playouts=120, friendly_pass=1, capture_all_dead=1, resign_threshold=0.3)),
+    (22, 9, 7.0, 0, dict(playouts=100, reuse_tree=1, friendly_pass=1, resign_threshold=0.25, random_moves_factor=0.1)),
+    (23, 7, 9.0, 1, dict(playouts=150, resign_threshold=0.0)),
+]
+
+
 def options(extra: dict) -> dict:
     o = dict(DEFAULTS)
     o.update(extra)
@@ -70,6 +79,8 @@ class RefSearchApi:
         lib.ref_search_computation.argtypes = [vp, vp, ci, ci] + [vp] * 6
         lib.ref_search_selfplay_move.restype = ci
         lib.ref_search_selfplay_move.argtypes = [vp, vp, ci]
+        lib.ref_search_think.restype = ci
+        lib.ref_search_think.argtypes = [vp, vp]
         lib.ref_search_gather.restype = ctypes.c_long
         lib.ref_search_gather.argtypes = [vp, vp, ctypes.c_long]
         lib.ref_search_update_territory_helper.argtypes = [vp]
@@ -112,6 +123,24 @@ def ref_selfplay_game(api: RefSearchApi, go_api, seed, board, komi, scoring, opt
     api.lib.ref_search_free(search)
     api.lib.ref_net_free(net)
     return moves, buf.raw[:n]
+
+
+def ref_think_game(api: RefSearchApi, go_api, seed, board, komi, scoring, opts, max_moves=1000):
+    """One fixed-seed game of the REFERENCE's ThinkBestMove against itself; returns the moves (-1 = resign)."""
+    from sayuri_amd.engine import Game
+    api.set_options(options(opts))
+    net = api.lib.ref_net_new(b"")
+    game = Game(board, komi, scoring, api_=go_api)
+    search = api.lib.ref_search_new(game._h, net)
+    api.lib.ref_seed(seed, seed + 77)
+    moves = []
+    while not game.info()[10] and len(moves) < max_moves:
+        mv = api.lib.ref_search_think(search, game._h)
+        moves.append(mv)
+        assert game.play(mv)
+    api.lib.ref_search_free(search)
+    api.lib.ref_net_free(net)
+    return moves
 
 
 def records_close(a: bytes, b: bytes, rel=3e-5, abs_=2e-6, racy_records=()):

@@ -19,7 +19,8 @@ import zlib
 import numpy as np
 import pytest
 
-from search_replay import DUMMY_GAMES, NN_GAMES, REF_SO, RefSearchApi, options, records_close, ref_selfplay_game
+from search_replay import (DUMMY_GAMES, NN_GAMES, REF_SO, THINK_GAMES, RefSearchApi, options, records_close, ref_selfplay_game,
+                           ref_think_game)
 from sayuri_amd import search as S
 from sayuri_amd import weights as W
 from sayuri_amd.engine import Game, GoApi
@@ -56,6 +57,25 @@ def test_golden_dummy_backend_games(golden, i):
     want = golden[f"dummy{i}_moves"].tolist()
     assert moves == want, f"first different move at {next(k for k, (a, b) in enumerate(zip(moves, want)) if a != b)}"
     assert records_close(zlib.decompress(golden[f"dummy{i}_records"].tobytes()), text, racy_records=racy) is None
+
+
+def engine_think_game(seed, board, komi, scoring, opts, max_moves=1000):
+    game = Game(board, komi, scoring)
+    search = S.Search(game, S.Network(options=options(opts)), options(opts), seeds=(seed, seed + 77))
+    moves = []
+    while not game.info()[10] and len(moves) < max_moves:
+        mv = search.think()
+        moves.append(mv)
+        assert game.play(mv)
+    search.close()
+    return moves
+
+
+@pytest.mark.parametrize("i", range(len(THINK_GAMES)))
+def test_golden_think_games(golden, i):
+    """ThinkBestMove against itself (genmove path: resign threshold blending, friendly pass, capture-all-dead, tree
+    reuse): the same moves as the reference, including the resignation that ends game 1."""
+    assert engine_think_game(*THINK_GAMES[i]) == golden[f"think{i}_moves"].tolist()
 
 
 @pytest.fixture(scope="module")
