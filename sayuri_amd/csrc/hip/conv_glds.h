@@ -327,9 +327,9 @@ __global__ __launch_bounds__(128 * WAVN_) void conv_glds_kernel(const GldsParams
             unsigned long long t0 = 0, t1 = 0, t2 = 0;
             if constexpr (ABL & 16) t0 = __builtin_amdgcn_s_memtime();
             // A(G) and B(chunk) were issued during the previous group and nothing after them.
-            wait_vmcnt<0>();
+            if constexpr (!(ABL & 256)) wait_vmcnt<0>();
             if constexpr (ABL & 16) t1 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABL & 128)) __builtin_amdgcn_s_barrier();
             if constexpr (ABL & 16) t2 = __builtin_amdgcn_s_memtime();
             const bool more_a = G + 1 < ngroups;
             const int dy = row - 1;

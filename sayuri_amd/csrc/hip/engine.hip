@@ -113,6 +113,8 @@ static void register_all_glds() {
         case 96: e.fn = &conv_glds_kernel<8, 3, 96>; break;
         case 48: e.fn = &conv_glds_kernel<8, 3, 48>; break;
         case 80: e.fn = &conv_glds_kernel<8, 3, 80>; break;
+        case 128: e.fn = &conv_glds_kernel<8, 3, 128>; break;  // timing only: no group barrier (wrong results)
+        case 384: e.fn = &conv_glds_kernel<8, 3, 384>; break;  // timing only: no group barrier, no DMA wait
         default: break;
         }
     }
@@ -784,6 +786,7 @@ private:
             p.g = dgeom();
             p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
             p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = gc->ntiles;
+            { static const char* na = getenv("SAYURI_ACT_OVERRIDE"); if (na) p.act = atoi(na); }  // timing experiments only
             gp.zeros = d_zeros_;
             const double px = geom_.total;
             const double flops = 2.0 * px * L.cin * L.cout * 9;
