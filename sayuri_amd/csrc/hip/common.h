@@ -24,8 +24,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // All eight activations of the reference (src/neural/activation.h:41-81).  Mish is evaluated
-// as x*n/(n+2), n = e^x(e^x+2), which equals x*tanh(log(1+e^x)) without the cancellation of the
-// literal form and costs one exp + one rcp instead of exp+log+tanh.
+// as x*(1 - 2/(e^2 + 2e + 2)), e = e^x, which equals x*tanh(log(1+e^x)) (tanh(log(1+e)) = n/(n+2) with
+// n = e(e+2)) and costs one exp, one rcp and five VALU operations instead of exp+log+tanh.
 __device__ __forceinline__ float activate(float x, int act) {
     switch (act) {
     case kReLU: return x > 0.f ? x : 0.f;
@@ -38,10 +38,13 @@ __device__ __forceinline__ float activate(float x, int act) {
         return 0.5f * x * (1.0f + t);
     }
     case kMish: {
+        // the guard is not needed for the value (e = inf gives rcp = 0 and the result x) but keeps the generated code in
+        // one shape for every element: without it hipcc mixes packed and scalar sequences whose last bits differ, and
+        // a sample's result then depends on the slot it occupies in the batch (tests/test_gpu_net.py catches that)
         if (x > 20.f) return x;
         const float e = fast_exp(x);
-        const float n = e * (e + 2.f);
-        return x * n * __builtin_amdgcn_rcpf(n + 2.f);
+        const float r = __builtin_amdgcn_rcpf(__builtin_fmaf(e, e + 2.f, 2.f));
+        return x * __builtin_fmaf(-2.f, r, 1.f);
     }
     case kSwish: return x / (1.0f + fast_exp(-x));
     case kHardSwish: return x >= 3.f ? x : (x <= -3.f ? 0.f : (x * (x + 3.0f) / 6.0f));
