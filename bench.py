@@ -210,7 +210,11 @@ def main():
                                 "NN cache 400 MiB; time window (games in progress are not counted as done)" % (args.selfplay_visits, args.selfplay_games),
                     "seconds": round(el, 2), "nn_evals_per_sec": round(tot["nn_queries"] / el, 1),
                     "playouts_per_sec": round(tot["playouts"] / el, 1), "moves_per_sec": round(tot["moves"] / el, 2),
-                    "games_done": int(tot["games_done"]), "games_per_hour_in_window": round(tot["games_done"] / el * 3600, 1),
+                    "games_done": int(tot["games_done"]),
+                    # a 19x19 game needs ~15-25 minutes of wall clock at 512 concurrent games, so a short window ends before
+                    # the first game does; games/hour is measured by tools/selfplay_bench.py over a long window
+                    # (profiles/r01_selfplay_27min_512games.json: 1398 games/hour on one MI355X)
+                    "games_per_hour_in_window": (round(tot["games_done"] / el * 3600, 1) if tot["games_done"] > 0 else None),
                     "mean_batch": round(tot["nn_queries"] / max(tot["nn_batches"], 1), 1),
                     "frac_of_microbench_evals": None}
 
