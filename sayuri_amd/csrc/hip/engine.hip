@@ -274,6 +274,12 @@ public:
     int init() {
         HIP_OK(hipSetDevice(device_));
         HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking));
+        for (int t = 0; t < 2; ++t) {
+            HIP_OK(hipEventCreateWithFlags(&h2d_done_[t], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&fwd_done_[t], hipEventDisableTiming));
+        }
         HIP_OK(hipEventCreate(&ev0_));
         HIP_OK(hipEventCreate(&ev1_));
         enable_big_lds<T>();
@@ -309,18 +315,30 @@ public:
     // asynchronous: H2D, graph, D2H enqueued on the stream, an event marks the end
     int submit(int n, const float* planes, const int* board_sizes, float* prob, float* pass, float* misc, float* own,
                int* ticket) override {
-        if (enqueue_inputs(n, planes, board_sizes)) return -1;
-        have_batch_ = true;
-        if (forward()) return -1;
-        const size_t B2 = (size_t)board_ * board_;
-        HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, stream_));
+        // Three streams: uploads, the forward graph, downloads.  The planes of batch k+1 cross PCIe while batch k
+        // computes, and the results of batch k while batch k+1 computes; each of the two tickets owns its own device
+        // input / geometry / output buffers.
         const int t = next_ticket_;
         next_ticket_ ^= 1;
+        HIP_OK(hipSetDevice(device_));
+        if (finalize()) return -1;
+        select_slot(t);
+        HIP_OK(hipStreamWaitEvent(h2d_stream_, fwd_done_[t], 0));  // the forward that last read this slot's inputs
+        if (enqueue_inputs(n, planes, board_sizes, h2d_stream_)) return -1;
+        HIP_OK(hipEventRecord(h2d_done_[t], h2d_stream_));
+        HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
+        if (tick_ev_[t]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t], 0));  // the download that last read this slot's outputs
+        have_batch_ = true;
+        if (forward()) return -1;
+        HIP_OK(hipEventRecord(fwd_done_[t], stream_));
+        HIP_OK(hipStreamWaitEvent(d2h_stream_, fwd_done_[t], 0));
+        const size_t B2 = (size_t)board_ * board_;
+        HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, d2h_stream_));
+        HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, d2h_stream_));
+        HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, d2h_stream_));
+        HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, d2h_stream_));
         if (!tick_ev_[t]) HIP_OK(hipEventCreateWithFlags(&tick_ev_[t], hipEventDisableTiming));
-        HIP_OK(hipEventRecord(tick_ev_[t], stream_));
+        HIP_OK(hipEventRecord(tick_ev_[t], d2h_stream_));
         *ticket = t;
         return 0;
     }
@@ -339,7 +357,13 @@ public:
     }
 
     int upload(int n, const float* planes, const int* board_sizes) override {
-        if (enqueue_inputs(n, planes, board_sizes)) return -1;
+        HIP_OK(hipSetDevice(device_));
+        if (finalize()) return -1;
+        HIP_OK(hipStreamSynchronize(h2d_stream_));
+        HIP_OK(hipStreamSynchronize(d2h_stream_));
+        HIP_OK(hipStreamSynchronize(stream_));
+        select_slot(0);
+        if (enqueue_inputs(n, planes, board_sizes, stream_)) return -1;
         HIP_OK(hipStreamSynchronize(stream_));
         have_batch_ = true;
         return 0;
@@ -347,7 +371,7 @@ public:
 
     // geometry + planes H2D on the stream (no sync).  The geometry arrays are staged in a
     // 2-deep pinned ring so a second batch can be enqueued while the first is still copying.
-    int enqueue_inputs(int n, const float* planes, const int* board_sizes) {
+    int enqueue_inputs(int n, const float* planes, const int* board_sizes, hipStream_t copy_stream) {
         HIP_OK(hipSetDevice(device_));
         if (n <= 0 || n > max_batch_) return fail("batch size out of range");
         if (finalize()) return -1;
@@ -372,10 +396,10 @@ public:
         geom_slot_ ^= 1;
         std::memcpy(hg, geom_.off.data(), sizeof(int) * (n + 1));
         std::memcpy(hg + max_batch_ + 1, geom_.bsz.data(), sizeof(int) * n);
-        HIP_OK(hipMemcpyAsync(d_off_, hg, sizeof(int) * (n + 1), hipMemcpyHostToDevice, stream_));
-        HIP_OK(hipMemcpyAsync(d_bsz_, hg + max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, stream_));
+        HIP_OK(hipMemcpyAsync(d_off_, hg, sizeof(int) * (n + 1), hipMemcpyHostToDevice, copy_stream));
+        HIP_OK(hipMemcpyAsync(d_bsz_, hg + max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
         HIP_OK(hipMemcpyAsync(d_planes_, planes, sizeof(float) * (size_t)n * desc_.input_channels * board_ * board_,
-                              hipMemcpyHostToDevice, stream_));
+                              hipMemcpyHostToDevice, copy_stream));
         return 0;
     }
 
@@ -638,17 +662,20 @@ private:
         for (int i = 0; i < kNumBufs; ++i)
             if (dev_alloc(&bufs_[i], act_elems)) return -1;
         const size_t B2 = (size_t)board_ * board_;
-        if (dev_alloc(&d_planes_, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
-        if (dev_alloc(&d_off_, max_batch_ + 1) || dev_alloc(&d_bsz_, max_batch_)) return -1;
+        for (IoSlot& io : io_) {
+            if (dev_alloc(&io.planes, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
+            if (dev_alloc(&io.off, max_batch_ + 1) || dev_alloc(&io.bsz, max_batch_)) return -1;
+            if (dev_alloc(&io.prob, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
+            if (dev_alloc(&io.pass, (size_t)max_batch_ * desc_.pass_probability_outputs)) return -1;
+            if (dev_alloc(&io.misc, (size_t)max_batch_ * desc_.value_misc_outputs)) return -1;
+            if (dev_alloc(&io.own, (size_t)max_batch_ * B2)) return -1;
+        }
         if (dev_alloc(&d_zeros_, 64)) return -1;
         HIP_OK(hipHostMalloc((void**)&h_geom_, sizeof(int) * 2 * (2 * max_batch_ + 1), hipHostMallocDefault));
         if (dev_alloc(&d_gate_, (size_t)max_batch_ * 2 * round_up(desc_.residual_channels, 32))) return -1;
         if (dev_alloc(&d_separt_, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
-        if (dev_alloc(&d_prob_, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
-        if (dev_alloc(&d_pass_, (size_t)max_batch_ * desc_.pass_probability_outputs)) return -1;
-        if (dev_alloc(&d_misc_, (size_t)max_batch_ * desc_.value_misc_outputs)) return -1;
-        if (dev_alloc(&d_own_, (size_t)max_batch_ * B2)) return -1;
         finalized_ = true;
+        select_slot(0);
         return 0;
     }
 
@@ -665,9 +692,13 @@ private:
         pool_.clear();
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
+        for (hipEvent_t& e : h2d_done_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        for (hipEvent_t& e : fwd_done_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (stream_) (void)hipStreamDestroy(stream_);
+        if (h2d_stream_) (void)hipStreamDestroy(h2d_stream_);
+        if (d2h_stream_) (void)hipStreamDestroy(d2h_stream_);
         ev0_ = ev1_ = nullptr;
-        stream_ = nullptr;
+        stream_ = h2d_stream_ = d2h_stream_ = nullptr;
     }
 
     // -------------------------------------------------------------- launch plumbing
@@ -974,8 +1005,20 @@ private:
     std::map<int, ConvLayerDev> convs_;
     std::map<int, FcLayerDev> fcs_;
     bool finalized_ = false, have_batch_ = false, profiling_ = false;
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr, h2d_stream_ = nullptr, d2h_stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    hipEvent_t h2d_done_[2] = {nullptr, nullptr}, fwd_done_[2] = {nullptr, nullptr};
+    // device-side batch i/o, one set per ticket; the d_* members below alias the slot the current forward uses
+    struct IoSlot {
+        float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;
+        int *off = nullptr, *bsz = nullptr;
+    };
+    IoSlot io_[2];
+    void select_slot(int t) {
+        const IoSlot& io = io_[t];
+        d_planes_ = io.planes; d_off_ = io.off; d_bsz_ = io.bsz;
+        d_prob_ = io.prob; d_pass_ = io.pass; d_misc_ = io.misc; d_own_ = io.own;
+    }
     std::vector<void*> allocs_;
     size_t dev_bytes_ = 0;
     T* bufs_[kNumBufs] = {};
