@@ -213,7 +213,7 @@ def main():
                     "games_done": int(tot["games_done"]),
                     # a 19x19 game needs ~15-25 minutes of wall clock at 512 concurrent games, so a short window ends before
                     # the first game does; games/hour is measured by tools/selfplay_bench.py over a long window
-                    # (profiles/r01_selfplay_27min_512games.json: 1398 games/hour on one MI355X)
+                    # (profiles/r01_selfplay_27min_512games_3stream.json: 1518 games/hour on one MI355X)
                     "games_per_hour_in_window": (round(tot["games_done"] / el * 3600, 1) if tot["games_done"] > 0 else None),
                     "mean_batch": round(tot["nn_queries"] / max(tot["nn_batches"], 1), 1),
                     "frac_of_microbench_evals": None}

@@ -264,6 +264,7 @@ public:
 
 template <typename T> class Engine : public EngineBase {
 public:
+    struct TileTabs { int* src = nullptr; int2* pix = nullptr; bool fresh = false; };
     Engine(int device, const sayuri_hip_netdesc& d, int max_batch, int board)
         : device_(device), desc_(d), max_batch_(max_batch), board_(board) {
         blocks_.assign(d.blocks, d.blocks + d.residual_blocks);
@@ -274,6 +275,14 @@ public:
     int init() {
         HIP_OK(hipSetDevice(device_));
         HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        // Both tickets run their forward graphs on ONE compute stream.  A second compute stream (SAYURI_COMPUTE_STREAMS=2:
+        // the next batch's kernels fill the CUs the current batch leaves idle -- second tile wave, small SE / head kernels,
+        // launch gaps) is supported -- each ticket has its own activations and tile tables -- but measured slower:
+        // 48.0 k vs 54.0 k evals/s through the queue, two graphs evict each other's weights and activations from L2.
+        compute_[0] = stream_;
+        compute_[1] = stream_;
+        const char* cs_env = getenv("SAYURI_COMPUTE_STREAMS");
+        if (cs_env && atoi(cs_env) == 2) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
         HIP_OK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
         HIP_OK(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking));
         for (int t = 0; t < 2; ++t) {
@@ -361,7 +370,8 @@ public:
         if (finalize()) return -1;
         HIP_OK(hipStreamSynchronize(h2d_stream_));
         HIP_OK(hipStreamSynchronize(d2h_stream_));
-        HIP_OK(hipStreamSynchronize(stream_));
+        for (hipStream_t cs : compute_)
+            if (cs) HIP_OK(hipStreamSynchronize(cs));
         select_slot(0);
         if (enqueue_inputs(n, planes, board_sizes, stream_)) return -1;
         HIP_OK(hipStreamSynchronize(stream_));
@@ -390,7 +400,11 @@ public:
         if (geom_.bsz != prev_bsz_) {  // tile choices and index tables depend on the geometry only
             tile_cache_.clear();
             glds_cache_.clear();
-            for (auto& kv : tabs_) kv.second.fresh = false;
+        }
+        IoSlot& slot = io_[cur_slot_];
+        if (slot.tabs_bsz != geom_.bsz) {  // this slot's tables were built for another geometry
+            for (auto& kv : slot.tabs) kv.second.fresh = false;
+            slot.tabs_bsz = geom_.bsz;
         }
         int* hg = h_geom_ + (size_t)geom_slot_ * (2 * max_batch_ + 1);
         geom_slot_ ^= 1;
@@ -659,8 +673,9 @@ private:
         // workspaces
         slot_pix_ = board_ * board_;
         const size_t act_elems = (size_t)max_batch_ * slot_pix_ * cs_max_;
-        for (int i = 0; i < kNumBufs; ++i)
-            if (dev_alloc(&bufs_[i], act_elems)) return -1;
+        for (IoSlot& io : io_)
+            for (int i = 0; i < kNumBufs; ++i)
+                if (dev_alloc(&io.bufs[i], act_elems)) return -1;
         const size_t B2 = (size_t)board_ * board_;
         for (IoSlot& io : io_) {
             if (dev_alloc(&io.planes, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
@@ -672,8 +687,10 @@ private:
         }
         if (dev_alloc(&d_zeros_, 64)) return -1;
         HIP_OK(hipHostMalloc((void**)&h_geom_, sizeof(int) * 2 * (2 * max_batch_ + 1), hipHostMallocDefault));
-        if (dev_alloc(&d_gate_, (size_t)max_batch_ * 2 * round_up(desc_.residual_channels, 32))) return -1;
-        if (dev_alloc(&d_separt_, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
+        for (IoSlot& io : io_) {
+            if (dev_alloc(&io.gate, (size_t)max_batch_ * 2 * round_up(desc_.residual_channels, 32))) return -1;
+            if (dev_alloc(&io.separt, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
+        }
         finalized_ = true;
         select_slot(0);
         return 0;
@@ -694,6 +711,9 @@ private:
         if (ev1_) (void)hipEventDestroy(ev1_);
         for (hipEvent_t& e : h2d_done_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         for (hipEvent_t& e : fwd_done_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        stream_ = compute_[0];
+        if (compute_[1] && compute_[1] != compute_[0]) (void)hipStreamDestroy(compute_[1]);
+        compute_[1] = nullptr;
         if (stream_) (void)hipStreamDestroy(stream_);
         if (h2d_stream_) (void)hipStreamDestroy(h2d_stream_);
         if (d2h_stream_) (void)hipStreamDestroy(d2h_stream_);
@@ -771,10 +791,9 @@ private:
     }
 
     struct GldsChoice { const GldsEntry* e; int ntiles; };
-    struct TileTabs { int* src = nullptr; int2* pix = nullptr; bool fresh = false; };
     // index tables of the current batch geometry for pixel-tile size 64*wnt (built on first use)
     int tile_tabs(const GldsEntry& e, const TileTabs** out) {
-        TileTabs& t = tabs_[e.wnt];
+        TileTabs& t = io_[cur_slot_].tabs[e.wnt];
         if (!t.src) {
             const size_t max_tiles = ((size_t)max_batch_ * slot_pix_ + e.pt - 1) / e.pt;
             if (dev_alloc(&t.src, max_tiles * e.npos) || dev_alloc(&t.pix, max_tiles * e.pt)) return -1;
@@ -1012,12 +1031,22 @@ private:
     struct IoSlot {
         float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;
         int *off = nullptr, *bsz = nullptr;
+        T* bufs[kNumBufs] = {};
+        float *gate = nullptr, *separt = nullptr;
+        std::map<int, TileTabs> tabs;   // index tables of the geometry this slot last ran (keyed by tile variant)
+        std::vector<int> tabs_bsz;
     };
     IoSlot io_[2];
+    hipStream_t compute_[2] = {nullptr, nullptr};
+    int cur_slot_ = 0;
     void select_slot(int t) {
-        const IoSlot& io = io_[t];
+        IoSlot& io = io_[t];
+        cur_slot_ = t;
         d_planes_ = io.planes; d_off_ = io.off; d_bsz_ = io.bsz;
         d_prob_ = io.prob; d_pass_ = io.pass; d_misc_ = io.misc; d_own_ = io.own;
+        for (int i = 0; i < kNumBufs; ++i) bufs_[i] = io.bufs[i];
+        d_gate_ = io.gate; d_separt_ = io.separt;
+        if (compute_[t]) stream_ = compute_[t];
     }
     std::vector<void*> allocs_;
     size_t dev_bytes_ = 0;
@@ -1034,7 +1063,6 @@ private:
     HostGeom geom_;
     std::vector<int> prev_bsz_;
     std::map<int, GldsChoice> glds_cache_;
-    std::map<int, TileTabs> tabs_;
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;
     // light per-launch timing of one kernel class inside time_runs()
