@@ -266,7 +266,7 @@ ComputationResult Search::Computation(int playouts, int tag) {
         PlaySimulation(fork, root_.get(), 0, pr);
         if (pr.valid) {
             playouts_ += 1;
-            total_playouts_ += 1;
+            total_playouts_.fetch_add(1, std::memory_order_relaxed);
         }
         if (AchieveCap(playouts, tag)) running = false;
         else if (abort_ && abort_->load(std::memory_order_relaxed)) running = false;

@@ -84,7 +84,7 @@ public:
     SearchParams* GetParams(bool no_exploring = false) { return no_exploring ? passive_ : active_; }
     const Node* root() const { return root_.get(); }
     const std::string& last_comment() const { return last_comment_; }
-    size_t total_playouts() const { return total_playouts_; }
+    size_t total_playouts() const { return total_playouts_.load(std::memory_order_relaxed); }
     // searches that ended at once because the root had a single candidate (the reference stops those from a
     // polling thread, after a timing-dependent handful of playouts: search.cc:352-386, 1423-1441)
     int single_candidate_searches() const { return single_candidate_searches_; }
@@ -124,7 +124,7 @@ private:
     std::vector<double> prev_kld_policy_;
     int prev_kld_visits_{0};
     int playouts_{0};
-    size_t total_playouts_{0};
+    std::atomic<size_t> total_playouts_{0};  // read by the self-play statistics while the game thread searches
     int single_candidate_searches_{0};
     bool last_single_candidate_{false};
     std::vector<int> single_candidate_records_;

@@ -47,7 +47,9 @@ void MakeDir(const std::string& d) {
 std::string NowString() {
     char buf[64];
     const std::time_t t = std::time(nullptr);
-    std::strftime(buf, sizeof(buf), "%Y-%m-%d-%H:%M:%S", std::localtime(&t));
+    std::tm tm_buf;
+    localtime_r(&t, &tm_buf);  // std::localtime shares one static buffer between the game threads
+    std::strftime(buf, sizeof(buf), "%Y-%m-%d-%H:%M:%S", &tm_buf);
     return buf;
 }
 } // namespace
