@@ -201,6 +201,9 @@ void HipForwardPipe::BuildGraphs() {
             s.own = pinned(static_cast<size_t>(max_batch_) * B2);
             s.bsz.assign(max_batch_, board_size_);
             s.reqs.resize(max_batch_);
+            s.fin_reqs.resize(max_batch_);
+            s.fin_list.resize(max_batch_);
+            s.fin_pos.resize(max_batch_);
         }
         graphs_.push_back(std::move(g));
     }
@@ -316,17 +319,43 @@ void HipForwardPipe::FinishBatch(Graph* g, Staging* s, int n) {
         rc = sayuri_hip_wait(g->ctx, s->ticket);
     }
     const auto t1 = std::chrono::steady_clock::now();
+    // the previous batch of this set was handed out at least one batch time ago
+    while (s->wakes_done.load(std::memory_order_acquire) < s->fin_count) std::this_thread::yield();
+    int count = 0;
     for (int i = 0; i < n; ++i) {
-        if (rc == 0) FillOutput(s, i, *s->reqs[i].input, true, s->reqs[i].output);
-        s->reqs[i].done->store(rc == 0 ? 1 : -1, std::memory_order_release);
-        FutexWakeAll(s->reqs[i].done);
+        const Request& r = s->reqs[i];
+        s->fin_reqs[i] = r;
+        if (r.self_serve) {
+            s->fin_pos[i] = count;
+            s->fin_list[count++] = i;
+        } else {  // asynchronous Submit(): filled and signalled here
+            if (rc == 0) FillOutput(s, i, *r.input, true, r.output);
+            r.done->store(rc == 0 ? 1 : -1, std::memory_order_release);
+            FutexWakeAll(r.done);
+        }
     }
-    const auto t2 = std::chrono::steady_clock::now();
-    pump_ns_[3] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
-    pump_ns_[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
     batches_.fetch_add(1, std::memory_order_relaxed);
     evals_.fetch_add(static_cast<size_t>(n), std::memory_order_relaxed);
     s->n_inflight = 0;
+    s->fin_count = count;
+    s->wakes_done.store(0, std::memory_order_relaxed);
+    s->consumed.store(0, std::memory_order_relaxed);
+    s->fin_status.store(rc == 0 ? 1 : -1, std::memory_order_relaxed);
+    if (count > 0) {  // root of the wake tree
+        std::atomic<int>* root = s->fin_reqs[s->fin_list[0]].done;
+        root->store(1, std::memory_order_release);
+        FutexWakeAll(root);
+    }
+    // The set takes new requests at once: its inputs are on the GPU already, the snapshot above keeps the hand-out
+    // independent of new reservations, and the pinned OUTPUT buffers are not written again before the set's next
+    // batch is submitted -- SubmitBatch waits for `consumed` there (callers need microseconds, that is a batch away).
+    Reopen(g, s);
+    const auto t2 = std::chrono::steady_clock::now();
+    pump_ns_[3] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    pump_ns_[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+}
+
+void HipForwardPipe::Reopen(Graph* g, Staging* s) {
     s->ready.store(0, std::memory_order_relaxed);
     s->reserved.store(0, std::memory_order_release);  // re-open for callers
     g->epoch.fetch_add(1, std::memory_order_release);
@@ -390,6 +419,8 @@ void HipForwardPipe::PumpLoop(Graph* g) {
         Staging& s = g->st[i];
         const auto tc0 = clock::now();
         while (s.ready.load(std::memory_order_acquire) < static_cast<unsigned>(n)) std::this_thread::yield();
+        // every blocking caller of this set's previous batch has copied its result out of the pinned outputs
+        while (s.consumed.load(std::memory_order_acquire) < s.fin_count) std::this_thread::yield();
         pump_ns_[7] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - tc0).count();
         try {
             SubmitBatch(g, &s, n);
@@ -400,13 +431,12 @@ void HipForwardPipe::PumpLoop(Graph* g) {
             }
             inflight[n_in++] = i;
         } catch (const std::exception&) {
+            // nothing was evaluated: every caller gets the failure directly (no tree: nothing to copy out)
             for (int k = 0; k < n; ++k) {
                 s.reqs[k].done->store(-1, std::memory_order_release);
                 FutexWakeAll(s.reqs[k].done);
             }
-            s.ready.store(0, std::memory_order_relaxed);
-            s.reserved.store(0, std::memory_order_release);
-            wake_callers();
+            Reopen(g, &s);
         }
     };
     auto finish_oldest = [&] {
@@ -485,7 +515,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
     }
 }
 
-void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atomic<int>* done) {
+HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputResult* out, std::atomic<int>* done, bool self_serve) {
     if (graphs_.empty()) throw std::runtime_error("HipForwardPipe is not constructed");
     if (input.board_size < 2 || input.board_size > board_size_)
         throw std::runtime_error("InputData board size does not fit the NN board");
@@ -502,10 +532,10 @@ void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atom
             if (!(r & Staging::kClosed) && r < cap) {
                 const int slot = static_cast<int>(r);
                 StageInput(&s, slot, input, false);  // the one copy of the planes, by the calling thread
-                s.reqs[slot] = Request{&input, out, done};
+                s.reqs[slot] = Request{&input, out, done, self_serve};
                 s.ready.fetch_add(1, std::memory_order_release);
                 if (r == 0 || r + 1 >= want) g->cv.notify_one();
-                return;
+                return Ticket{g, &s, slot};
             }
         }
         // both sets are taken (one on the GPU, one full or being rotated): sleep until the pump re-opens one
@@ -514,13 +544,30 @@ void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atom
     }
 }
 
+void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atomic<int>* done) {
+    Reserve(input, out, done, false);
+}
+
 OutputResult HipForwardPipe::Forward(const InputData& input) {
     OutputResult out;
     std::atomic<int> done{0};
-    Submit(input, &out, &done);
+    const Ticket t = Reserve(input, nullptr, &done, true);
     int st;
     while ((st = done.load(std::memory_order_acquire)) == 0) FutexWait(&done, 0);
     if (st < 0) throw std::runtime_error("HIP forward pipe failed while evaluating a batch");
+    // woken through the batch's tree: pass the wake-up on to this node's children first, then take the result
+    Staging& s = *t.s;
+    const int count = s.fin_count, pos = s.fin_pos[t.slot];
+    for (int c = Staging::kFanout * pos + 1; c <= Staging::kFanout * pos + Staging::kFanout && c < count; ++c) {
+        std::atomic<int>* child = s.fin_reqs[s.fin_list[c]].done;
+        child->store(1, std::memory_order_release);
+        FutexWakeAll(child);
+    }
+    s.wakes_done.fetch_add(1, std::memory_order_release);
+    const int status = s.fin_status.load(std::memory_order_relaxed);
+    if (status > 0) FillOutput(&s, t.slot, input, true, &out);
+    s.consumed.fetch_add(1, std::memory_order_release);
+    if (status < 0) throw std::runtime_error("HIP forward pipe failed while evaluating a batch");
     return out;
 }
 
