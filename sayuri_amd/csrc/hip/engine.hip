@@ -23,6 +23,7 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "conv_glds.h"
+#include "conv_wino.h"
 #include "small_ops.h"
 
 namespace sayuri {
@@ -219,6 +220,86 @@ static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_
     return best;
 }
 
+// ------------------------------------------------------------------ fused Winograd (conv_wino.h)
+// SAYURI_CONV=wino routes every fp16 3x3 layer whose batch geometry fits the kernel's raw-position budget through
+// conv_wino_kernel; anything else keeps the implicit-GEMM kernels.
+static bool wino_enabled() {  // read when an engine finalises its weights / per test_conv call
+    const char* e = getenv("SAYURI_CONV");
+    return e && !strncmp(e, "wino", 4);
+}
+struct WinoGeom { int blocks = 0, total_tiles = 0; bool fits = false; };
+static WinoGeom wino_geom(const HostGeom& geom) {
+    WinoGeom wg;
+    std::vector<int> toff(geom.n + 1, 0);
+    for (int i = 0; i < geom.n; ++i) {
+        const int tw = wino_tiles_per_side(geom.bsz[i]);
+        toff[i + 1] = toff[i] + tw * tw;
+    }
+    wg.total_tiles = toff[geom.n];
+    wg.blocks = (wg.total_tiles + WinoCfg::NTL - 1) / WinoCfg::NTL;
+    int s = 0, max_pos = 0, max_sub = 0;
+    for (int t0 = 0; t0 < wg.total_tiles; t0 += WinoCfg::NTL) {  // mirrors wino_setup_kernel
+        const int t1 = std::min(t0 + WinoCfg::NTL, wg.total_tiles);
+        while (s + 1 < geom.n && toff[s + 1] <= t0) ++s;
+        int pos = 0, sub = 0;
+        for (int m = s; m < geom.n && toff[m] < t1; ++m) {
+            const int tw = wino_tiles_per_side(geom.bsz[m]);
+            const int a = std::max(t0, toff[m]) - toff[m], b = std::min(t1, toff[m + 1]) - toff[m];
+            const int rows = 2 * ((b - 1) / tw - a / tw + 1) + 2;
+            pos += rows * (2 * tw + 2);
+            ++sub;
+        }
+        max_pos = std::max(max_pos, pos);
+        max_sub = std::max(max_sub, sub);
+    }
+    // a dummy tile of the last block reads the 4x4 patch at position 0 of the first subregion: always inside NPOS
+    wg.fits = wg.total_tiles > 0 && max_pos <= WinoCfg::NPOS && max_sub <= kMaxSub;
+    return wg;
+}
+// U = G g G^T per (output channel, input channel), in the fragment order conv_wino_kernel loads:
+// [kt][chunk][xi][nu][m][lane][8] with ko = kt*64 + m*16 + (lane & 15), c = chunk*32 + (lane >> 4)*8 + e.
+static std::vector<f16> wino_image(const float* w, int cin, int cout, int cin_s, int ko_pad) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nch = cin_s / 32, kts = ko_pad / WinoCfg::KO_T;
+    std::vector<f16> img((size_t)ko_pad * cin_s * 16, (f16)0.f);
+    for (int ko = 0; ko < cout; ++ko)
+        for (int c = 0; c < cin; ++c) {
+            const float* g = w + ((size_t)ko * cin + c) * 9;
+            double tmp[4][3];
+            for (int x = 0; x < 4; ++x)
+                for (int sct = 0; sct < 3; ++sct)
+                    tmp[x][sct] = G[x][0] * g[0 * 3 + sct] + G[x][1] * g[1 * 3 + sct] + G[x][2] * g[2 * 3 + sct];
+            const int kt = ko / WinoCfg::KO_T, m = (ko % WinoCfg::KO_T) / 16, row = ko % 16;
+            const int chunk = c / 32, kgq = (c % 32) / 8, e = c % 8;
+            const int lane = kgq * 16 + row;
+            for (int x = 0; x < 4; ++x)
+                for (int nu = 0; nu < 4; ++nu) {
+                    const double u = tmp[x][0] * G[nu][0] + tmp[x][1] * G[nu][1] + tmp[x][2] * G[nu][2];
+                    const size_t frag = ((((size_t)kt * nch + chunk) * 4 + x) * 4 + nu) * 4 + m;
+                    img[frag * 512 + (size_t)lane * 8 + e] = (f16)(float)u;
+                }
+        }
+    (void)kts;
+    return img;
+}
+typedef void (*WinoFn)(const WinoParams);
+// the kernel is instantiated per input width (cin_s / 32 chunks, K loop fully unrolled)
+static WinoFn wino_kernel_for(int nchunks) {
+    switch (nchunks) {
+    case 2: return &conv_wino_kernel<2>;
+    case 3: return &conv_wino_kernel<3>;
+    case 4: return &conv_wino_kernel<4>;
+    case 6: return &conv_wino_kernel<6>;
+    case 8: return &conv_wino_kernel<8>;
+    case 12: return &conv_wino_kernel<12>;
+    default: return nullptr;
+    }
+}
+static void enable_big_lds_wino() {
+    for (int nch : {2, 3, 4, 6, 8, 12})
+        (void)hipFuncSetAttribute((const void*)wino_kernel_for(nch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+}
+
 struct Stat {
     int launches = 0;
     float ms = 0.f;
@@ -234,6 +315,8 @@ struct ConvLayerDev {
     void* w = nullptr;      // MFMA image, or [k*k][cs] fp32 for depthwise
     float* bias = nullptr;  // [ko_pad] / [cs]
     float* w32 = nullptr;   // plain fp32 copy [cout][cin] for the tiny head convs
+    void* wino = nullptr;   // Winograd image (conv_wino.h) of an fp16 3x3 layer, when that kernel is enabled
+    int wino_ko_pad = 0;
 };
 struct FcLayerDev {
     int in = 0, out = 0;
@@ -265,6 +348,7 @@ public:
 template <typename T> class Engine : public EngineBase {
 public:
     struct TileTabs { int* src = nullptr; int2* pix = nullptr; bool fresh = false; };
+    struct WinoTabs { int *tile_off = nullptr, *src = nullptr, *tile = nullptr, *out = nullptr; bool fresh = false; };
     Engine(int device, const sayuri_hip_netdesc& d, int max_batch, int board)
         : device_(device), desc_(d), max_batch_(max_batch), board_(board) {
         blocks_.assign(d.blocks, d.blocks + d.residual_blocks);
@@ -292,7 +376,7 @@ public:
         HIP_OK(hipEventCreate(&ev0_));
         HIP_OK(hipEventCreate(&ev1_));
         enable_big_lds<T>();
-        if (sizeof(T) == 2) enable_big_lds_glds();
+        if (sizeof(T) == 2) { enable_big_lds_glds(); enable_big_lds_wino(); }
         return describe_layers();
     }
 
@@ -400,10 +484,12 @@ public:
         if (geom_.bsz != prev_bsz_) {  // tile choices and index tables depend on the geometry only
             tile_cache_.clear();
             glds_cache_.clear();
+            wino_geom_valid_ = false;
         }
         IoSlot& slot = io_[cur_slot_];
         if (slot.tabs_bsz != geom_.bsz) {  // this slot's tables were built for another geometry
             for (auto& kv : slot.tabs) kv.second.fresh = false;
+            slot.wino.fresh = false;
             slot.tabs_bsz = geom_.bsz;
         }
         int* hg = h_geom_ + (size_t)geom_slot_ * (2 * max_batch_ + 1);
@@ -487,6 +573,29 @@ public:
         const int rc = forward();
         profiling_ = false;
         if (rc) return -1;
+        if (d_wdbg_) {  // SAYURI_WINO_DBG: s_memtime timeline of the last tower conv (first 64 workgroups)
+            std::vector<unsigned long long> h(64 * 4 * 16);
+            HIP_OK(hipMemcpy(h.data(), d_wdbg_, h.size() * 8, hipMemcpyDeviceToHost));
+            double sum[16] = {};
+            for (int wg = 0; wg < 64; ++wg) {
+                const unsigned long long* d = &h[(size_t)wg * 4 * 16];
+                for (int k = 1; k <= 12; ++k) sum[k] += (double)(d[k] - d[0]);
+            }
+            fprintf(stderr, "[wino timeline, mean over 64 wgs, wave 0, cycles since start]\n");
+            const char* nm[13] = {"", "tables+first issue", "first barrier", "chunk1", "chunk2", "chunk3", "chunk4", "chunk5",
+                                  "chunk6", "sum of weight waits", "loop end", "Z staged", "end"};
+            for (int k = 1; k <= 12; ++k) fprintf(stderr, "  %-20s %9.0f\n", nm[k], sum[k] / 64);
+            {
+                double a = 0, b = 0, c = 0;
+                for (int wg = 0; wg < 64; ++wg) {
+                    const unsigned long long* d = &h[(size_t)wg * 4 * 16];
+                    a += (double)(d[13] - d[5]); b += (double)(d[14] - d[13]); c += (double)(d[15] - d[14]);
+                }
+                fprintf(stderr, "  chunk3->4: compute %.0f, vmcnt wait %.0f, barrier %.0f\n", a / 64, b / 64, c / 64);
+            }
+            const unsigned long long* d0 = &h[0];
+            fprintf(stderr, "  wg0 waves end: %llu %llu %llu %llu\n", d0[12] - d0[0], d0[16 + 12] - d0[0], d0[32 + 12] - d0[0], d0[48 + 12] - d0[0]);
+        }
         if (d_dbg_) {  // SAYURI_ABL=16: print the s_memtime timeline of the last tower conv
             std::vector<unsigned long long> h(2 * 8 * 32 * 4);
             HIP_OK(hipMemcpy(h.data(), d_dbg_, h.size() * 8, hipMemcpyDeviceToHost));
@@ -656,6 +765,14 @@ private:
                 T* w = nullptr;
                 if (dev_upload(&w, img) || dev_upload(&L.bias, b)) return -1;
                 L.w = w;
+                if (sizeof(T) == 2 && L.k == 3 && wino_enabled() && wino_kernel_for(L.cin_s / 32)) {
+                    L.wino_ko_pad = round_up(L.cout_s, WinoCfg::KO_T);
+                    if ((int)b.size() < L.wino_ko_pad) return fail("winograd: bias image shorter than the channel tiles");
+                    const std::vector<f16> wimg = wino_image(L.hw.data(), L.cin, L.cout, L.cin_s, L.wino_ko_pad);
+                    f16* dw = nullptr;
+                    if (dev_upload(&dw, wimg)) return -1;
+                    L.wino = dw;
+                }
             }
             std::vector<float>().swap(L.hw);
             std::vector<float>().swap(L.hb);
@@ -675,7 +792,10 @@ private:
         const size_t act_elems = (size_t)max_batch_ * slot_pix_ * cs_max_;
         for (IoSlot& io : io_)
             for (int i = 0; i < kNumBufs; ++i)
-                if (dev_alloc(&io.bufs[i], act_elems)) return -1;
+                // every activation buffer starts kZeroPrefix bytes into its (zero-filled) allocation: conv_wino.h reads
+                // its halo from that prefix
+                if (dev_alloc(&io.bufs[i], act_elems + kZeroPrefix / sizeof(T))) return -1;
+                else io.bufs[i] += kZeroPrefix / sizeof(T);
         const size_t B2 = (size_t)board_ * board_;
         for (IoSlot& io : io_) {
             if (dev_alloc(&io.planes, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
@@ -819,7 +939,59 @@ private:
         return it->second.e ? &it->second : nullptr;
     }
 
+    // index tables of the current batch geometry for conv_wino_kernel (built on first use)
+    int wino_tabs(const WinoTabs** out) {
+        WinoTabs& t = io_[cur_slot_].wino;
+        if (!t.src) {
+            const int tw = wino_tiles_per_side(board_);
+            const size_t max_blocks = ((size_t)max_batch_ * tw * tw + WinoCfg::NTL - 1) / WinoCfg::NTL;
+            if (dev_alloc(&t.tile_off, max_batch_ + 1) || dev_alloc(&t.src, max_blocks * WinoCfg::NPOS) ||
+                dev_alloc(&t.tile, max_blocks * WinoCfg::NTL) || dev_alloc(&t.out, max_blocks * WinoCfg::NTL * 4))
+                return -1;
+        }
+        if (!t.fresh) {
+            hipLaunchKernelGGL(wino_prefix_kernel, dim3(1), dim3(1024), 0, stream_, dgeom(), t.tile_off);
+            hipLaunchKernelGGL(wino_setup_kernel, dim3(wino_geom_.blocks), dim3(256), 0, stream_, dgeom(),
+                               (const int*)t.tile_off, wino_geom_.total_tiles, t.src, t.tile, t.out);
+            HIP_OK(hipGetLastError());
+            t.fresh = true;
+        }
+        *out = &t;
+        return 0;
+    }
+    bool use_wino(const ConvLayerDev& L) {
+        if (!L.wino) return false;
+        if (!wino_geom_valid_) { wino_geom_ = wino_geom(geom_); wino_geom_valid_ = true; }
+        return wino_geom_.fits;
+    }
+
     int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
+        if (use_wino(L)) {
+            const WinoTabs* tabs = nullptr;
+            if (wino_tabs(&tabs)) return -1;
+            WinoParams wp;
+            wp.tab_src = tabs->src; wp.tab_tile = tabs->tile; wp.tab_out = tabs->out;
+            wp.num_blocks = wino_geom_.blocks;
+            wp.zeros = d_zeros_;
+            wp.dbg = nullptr;
+            if (getenv("SAYURI_WINO_DBG") && !strcmp(name, "conv3x3_tower")) {
+                if (!d_wdbg_ && dev_alloc(&d_wdbg_, 64 * 4 * 16)) return -1;
+                wp.dbg = d_wdbg_;
+            }
+            ConvParams& p = wp.c;
+            p.in = in; p.w = L.wino; p.bias = L.bias; p.res = res; p.out = out;
+            p.g = dgeom();
+            p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.wino_ko_pad;
+            p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = wino_geom_.blocks;
+            const double px = geom_.total;
+            const double flops = 2.0 * px * L.cin * L.cout * 9;  // algorithmic (direct-form) count
+            const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 16);
+            const int grid = round_up(wino_geom_.blocks, 8) * (L.wino_ko_pad / WinoCfg::KO_T);
+            const WinoFn fn = wino_kernel_for(L.cin_s / 32);
+            return timed(name, flops, bytes, [&] {
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(WinoCfg::NT), WinoCfg::lds_bytes(), stream_, wp);
+            });
+        }
         if (const GldsChoice* gc = choose_glds(L)) {
             const TileTabs* tabs = nullptr;
             if (tile_tabs(*gc->e, &tabs)) return -1;
@@ -1034,6 +1206,7 @@ private:
         T* bufs[kNumBufs] = {};
         float *gate = nullptr, *separt = nullptr;
         std::map<int, TileTabs> tabs;   // index tables of the geometry this slot last ran (keyed by tile variant)
+        WinoTabs wino;
         std::vector<int> tabs_bsz;
     };
     IoSlot io_[2];
@@ -1057,12 +1230,15 @@ private:
     int *d_off_ = nullptr, *d_bsz_ = nullptr;
     float* d_zeros_ = nullptr;
     unsigned long long* d_dbg_ = nullptr;
+    unsigned long long* d_wdbg_ = nullptr;
     int* h_geom_ = nullptr;  // pinned 2-slot ring: [slot][off(max_batch+1) | bsz(max_batch)]
     int geom_slot_ = 0, next_ticket_ = 0;
     hipEvent_t tick_ev_[2] = {nullptr, nullptr};
     HostGeom geom_;
     std::vector<int> prev_bsz_;
     std::map<int, GldsChoice> glds_cache_;
+    WinoGeom wino_geom_;
+    bool wino_geom_valid_ = false;
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;
     // light per-launch timing of one kernel class inside time_runs()
@@ -1233,7 +1409,8 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
     };
     const int xin_c = depthwise ? cout : cin;
     std::vector<T> hx = to_nhwc(x, xin_c, cin_s);
-    T* dx = (T*)dalloc(hx.size() * sizeof(T));
+    T* dx = (T*)dalloc(hx.size() * sizeof(T) + kZeroPrefix);
+    if (dx) dx += kZeroPrefix / sizeof(T);  // conv_wino.h reads its halo from a zero prefix in front of the activations
     T* dy = (T*)dalloc((size_t)n * slot * cout_s * sizeof(T));
     T* dres = nullptr;
     if (!dx || !dy) { cleanup(); return fail("test_conv: hipMalloc failed"); }
@@ -1288,7 +1465,42 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         HIP_OK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
         int g_ntiles = 0;
         const GldsEntry* ge = nullptr;
-        if (sizeof(T) == 2 && k == 3) {
+        bool wino_done = false;
+        if (sizeof(T) == 2 && k == 3 && wino_enabled() && wino_kernel_for(cin_s / 32)) {
+            const WinoGeom wg = wino_geom(hg);
+            if (wg.fits) {
+                enable_big_lds_wino();
+                const int wko = round_up(cout_s, WinoCfg::KO_T);
+                const std::vector<f16> wimg = wino_image(w, cin, cout, cin_s, wko);
+                std::vector<float> wb(wko, 0.f);
+                if (bias) std::copy(bias, bias + cout, wb.begin());
+                f16* dwi = (f16*)dalloc(wimg.size() * 2);
+                float* dwb = (float*)dalloc(wb.size() * 4);
+                float* dz = (float*)dalloc(256);
+                int* toff = (int*)dalloc(sizeof(int) * (n + 1));
+                int* tsrc = (int*)dalloc(sizeof(int) * (size_t)wg.blocks * WinoCfg::NPOS);
+                int* ttile = (int*)dalloc(sizeof(int) * (size_t)wg.blocks * WinoCfg::NTL);
+                int* tout = (int*)dalloc(sizeof(int) * (size_t)wg.blocks * WinoCfg::NTL * 4);
+                if (!dwi || !dwb || !dz || !toff || !tsrc || !ttile || !tout) { cleanup(); return fail("test_conv: hipMalloc failed"); }
+                HIP_OK(hipMemcpy(dwi, wimg.data(), wimg.size() * 2, hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy(dwb, wb.data(), wb.size() * 4, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(wino_prefix_kernel, dim3(1), dim3(1024), 0, 0, g, toff);
+                hipLaunchKernelGGL(wino_setup_kernel, dim3(wg.blocks), dim3(256), 0, 0, g, (const int*)toff, wg.total_tiles,
+                                   tsrc, ttile, tout);
+                WinoParams wp;
+                wp.tab_src = tsrc; wp.tab_tile = ttile; wp.tab_out = tout; wp.num_blocks = wg.blocks; wp.zeros = dz; wp.dbg = nullptr;
+                ConvParams& p = wp.c;
+                p.in = dx; p.w = dwi; p.bias = dwb; p.res = dres; p.out = dy; p.g = g;
+                p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = wko; p.taps = 9; p.act = act; p.npos = 0;
+                p.num_pix_tiles = wg.blocks;
+                hipLaunchKernelGGL(wino_kernel_for(cin_s / 32), dim3(round_up(wg.blocks, 8) * (wko / WinoCfg::KO_T)),
+                                   dim3(WinoCfg::NT), WinoCfg::lds_bytes(), 0, wp);
+                HIP_OK(hipGetLastError());
+                HIP_OK(hipDeviceSynchronize());
+                wino_done = true;
+            }
+        }
+        if (sizeof(T) == 2 && k == 3 && !wino_done) {
             enable_big_lds_glds();
             ge = pick_glds(hg, ko_pad, &g_ntiles);
         }
@@ -1314,14 +1526,14 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         const typename ConvKernelTable<T>::Entry* best = nullptr;
         int best_npos = 0;
         for (const auto& e : ConvKernelTable<T>::entries()) {
-            if (ge) break;
+            if (ge || wino_done) break;
             if (e.wmt != wmt) continue;
             int npos, nsub;
             hg.tile_bounds(64 * e.wnt, &npos, &nsub);
             if (npos > e.npos_cap || nsub > kMaxSub || e.lds(npos) > kMaxLds) continue;
             if (!best || e.wnt > best->wnt) { best = &e; best_npos = npos; }
         }
-        if (!best && !ge) { cleanup(); return fail("test_conv: no tile configuration fits"); }
+        if (!best && !ge && !wino_done) { cleanup(); return fail("test_conv: no tile configuration fits"); }
         if (best) {
         ConvParams p;
         p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;

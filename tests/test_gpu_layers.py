@@ -163,3 +163,23 @@ def test_conv_batch256_tile_seams():
                                   _fp(np.ascontiguousarray(x[perm]).ravel()), _fp(w.ravel()), None, None, _fp(y2.ravel()))
     assert rc == 0
     np.testing.assert_array_equal(y2, y[perm])
+
+
+WINO_CASES = [
+    ([19] * 3, 256, 256),                    # the tower conv of the 20b256 net (8 chunks, 4 channel tiles)
+    ([19] * 7, 64, 64),                      # several tile blocks, blocks crossing samples
+    ([9, 13, 19, 7, 19, 5], 32 * 3, 64),     # mixed boards: odd and even sizes, ragged last tiles
+    ([19] * 2, 384, 384),                    # 40b384 tower conv (12 chunks, 6 channel tiles)
+    ([13] * 5, 128, 192),
+    ([19] * 4, 43, 96),                      # input conv shape (cin padded to 64, cout padded to 128)
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[f"{c[1]}x{c[2]}n{len(c[0])}b{min(c[0])}" for c in WINO_CASES])
+def test_conv_winograd_fused(case, monkeypatch):
+    """SAYURI_CONV=wino: the fused Winograd F(2x2,3x3) kernel (csrc/hip/conv_wino.h) against the same float64
+    direct-convolution reference and tolerance as the implicit-GEMM kernels."""
+    monkeypatch.setenv("SAYURI_CONV", "wino")
+    bsz, cin, cout = case
+    run_case(True, bsz, cin, cout, 3, act=5, with_res=True, seed=cin + cout)
+    run_case(True, bsz, cin, cout, 3, act=0, with_res=False, seed=cin + cout + 1)

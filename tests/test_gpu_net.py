@@ -57,6 +57,18 @@ def test_golden_parity(name, fp16, tmp_weights_dir):
         pipe.Destroy()
 
 
+def test_20b256_winograd_path(tmp_weights_dir, monkeypatch):
+    """The same network through the opt-in fused Winograd convolution (SAYURI_CONV=wino, conv_wino.h)."""
+    monkeypatch.setenv("SAYURI_CONV", "wino")
+    g = Golden("net_20b256", tmp_weights_dir)
+    cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=True)
+    try:
+        check(pipe, cases, FP16_ATOL, "20b256-wino")
+    finally:
+        pipe.Destroy()
+
+
 @pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
 def test_20b256_golden_and_oracle(fp16, tmp_weights_dir):
     """BASELINE.json configs[1] network: golden cases + fresh oracle evaluations."""
