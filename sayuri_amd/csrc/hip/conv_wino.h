@@ -9,21 +9,21 @@
 // tiles cover 20x20) and keeps fp16 products at the error level of a plain dot product (the transform matrices hold
 // only 0, +-1, +-1/2).
 //
-// Work split.  A workgroup owns KO_T = 64 output channels x NTL = 64 tiles (256 output pixels) and ALL sixteen
-// transform points: 4 waves, wave xi holds M[xi][nu = 0..3][64 ch][64 tiles] in 256 accumulator registers per lane.
+// Work split.  A workgroup owns KO_T = 64 output channels x NTL = 48 tiles (192 output pixels) and ALL sixteen
+// transform points: 4 waves, wave xi holds M[xi][nu = 0..3][64 ch][48 tiles] in 192 accumulator registers per lane.
 //   * raw input: per 32-channel chunk the 4x4 patches of the tile block (their union: a few board rows with a one /
-//     two cell frame, <= 512 positions) are DMA'd into LDS once (`global_load_lds_dwordx4`, k-group planes as in
-//     conv_glds.h) and double-buffered;
-//   * input transform in registers: V = B^T d B.  Wave xi reads the two patch rows B^T's row xi combines (8 x
-//     ds_read_b128 per 16 tiles), forms t[j] = d[ia][j] +- d[ib][j] and the four V[xi][nu] = t[ja] +- t[jb] with packed
-//     fp16 adds: the transformed tensor is never written anywhere (LDS stores are the slow port on this chip);
-//   * weights U = G g G^T are transformed once at load time and stored in MFMA fragment order; a wave's sixteen
-//     fragments of a chunk are 16 KiB of contiguous global memory, loaded straight into registers one chunk ahead
-//     (no other wave needs them, so LDS would only add a round trip);
+//     two cell frame, <= 512 positions) are DMA'd into LDS once (`global_load_lds_dwordx4`, 64 contiguous bytes per
+//     position, so the global side is coalesced) and double-buffered; layout and bank spreading: wino_pitch / wino_rot;
+//   * input transform in registers: V = B^T d B.  The K loop runs in stages of (chunk, nu pair); per stage and 16 tiles
+//     wave xi reads the two patch rows B^T's row xi combines (6 x ds_read_b128, two items ahead of their use), forms
+//     t[j] = d[ia][j] +- d[ib][j] and V[xi][nu] = t[ja] +- t[jb] with packed fp16 FMAs: the transformed tensor is never
+//     written anywhere (LDS stores are the slow port on this chip);
+//   * weights U = G g G^T are transformed once at load time and stored in MFMA fragment order; a wave's eight
+//     fragments of a stage are 8 KiB of contiguous global memory, loaded straight into a three-deep register ring two
+//     stages ahead (no other wave needs them, so LDS would only add a round trip), waited for with hand-counted vmcnt;
 //   * output transform: the nu half (A^T on the right) in registers, the xi half across the four waves through an
 //     fp32 staging tile in LDS; then bias, residual, activation and 128-byte row segments out.
-// Budget per 32-channel chunk and workgroup: 64 MFMA 16x16x32 per wave (1024 clocks), 64 KiB of weights + ~28 KiB of
-// raw input from L2, 128 KiB of LDS reads: the L2 path (about 56 B/clk/CU) is the bound, not the matrix cores.
+// Measured state and the list of what is still slow: DESIGN.md "Kernel 3".
 #pragma once
 #include "common.h"
 #include "conv_glds.h"
@@ -35,7 +35,6 @@ constexpr int kZeroPrefix = 4096;  // zero bytes every activation buffer carries
 struct WinoCfg {
     static constexpr int KO_T = 64, NF = 3, NTL = 16 * NF, NWAVE = 4, NT = 256;  // NF = 16-tile fragment columns
     static constexpr int NPOS = 512;                       // raw positions of a tile block (multiple of 64)
-    static constexpr int BI = NPOS / 64;                   // DMA instructions per wave per chunk (plane = wave)
     static constexpr int RAW_BYTES = NPOS * 64;            // [position][k-group][8 halves]
     static constexpr int Z_RS = KO_T * 4 + 16;             // staging row: 64 fp32 + pad
     static constexpr int STAGE_BYTES = 4 * 2 * NTL * Z_RS; // [xi][b][tile][ch]
@@ -57,6 +56,13 @@ struct WinoParams {
 };
 
 __host__ __device__ inline int wino_tiles_per_side(int bs) { return (bs + 1) >> 1; }
+// LDS image of a tile block's raw input: per raw row `pitch` positions of 64 bytes -- the tw+1 even patch columns, then
+// the tw+1 odd ones, then one pad position.  The odd pitch and the rotation of the four 16-byte k-group slots of a
+// position by ((pos >> 1) + row) & 3 were found by search (a bank simulation of ds_read_b128's lane groups): the
+// sixteen tiles of a fragment column then hit sixteen different 16-byte bank groups for every patch cell (4.0 LDS cycles
+// per read inside a sample, 4.5 averaged over blocks that cross samples; 10.5 with pitch 2tw+2 and no rotation).
+__host__ __device__ inline int wino_pitch(int tw) { return 2 * tw + 3; }
+__host__ __device__ inline int wino_rot(int pos, int row) { return ((pos >> 1) + row) & 3; }
 
 // tile_off[i] = number of Winograd tiles of samples 0..i-1
 __global__ __launch_bounds__(1024) void wino_prefix_kernel(BatchGeom g, int* __restrict__ tile_off) {
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void wino_setup_kernel(BatchGeom g, const int*
             int* sb = hdr + 8 + 8 * cnt;
             sb[0] = base; sb[1] = trlo; sb[2] = bs; sb[3] = n;
             sb[4] = off + a; sb[5] = off + b; sb[6] = rows; sb[7] = off;
-            base += rows * (2 * tw + 2);
+            base += rows * wino_pitch(tw);
             ++cnt; ++n;
         }
         hdr[0] = cnt;
@@ -121,13 +127,13 @@ __global__ __launch_bounds__(256) void wino_setup_kernel(BatchGeom g, const int*
         int src = -1;
         for (int s = 0; s < nsub; ++s) {
             const int* sb = hdr + 8 + 8 * s;
-            const int bs = sb[2], w2 = 2 * wino_tiles_per_side(bs) + 2, rel = pos - sb[0];
+            const int bs = sb[2], tw = wino_tiles_per_side(bs), w2 = wino_pitch(tw), rel = pos - sb[0];
             if (rel >= 0 && rel < sb[6] * w2) {
-                const int r = rel / w2, idx = rel - r * w2, half = w2 >> 1;
-                const int xc = idx < half ? 2 * idx : 2 * (idx - half) + 1;  // even columns first, then the odd ones
+                const int r = rel / w2, idx = rel - r * w2, half = tw + 1;
+                const int xc = idx < half ? 2 * idx : 2 * (idx - half) + 1;  // even columns first, then the odd ones (+ 1 pad cell)
                 const int y = 2 * sb[1] - 1 + r, x = xc - 1;
-                // bits 28-29: k-group rotation of this raw row in LDS (bank spreading, see conv_wino_kernel)
-                if (y >= 0 && y < bs && x >= 0 && x < bs) src = (sb[3] * g.slot_pix + y * bs + x) | (((r >> 1) & 3) << 28);
+                // bits 28-29: k-group rotation of this position in LDS (bank spreading, see conv_wino_kernel)
+                if (y >= 0 && y < bs && x >= 0 && x < bs) src = (sb[3] * g.slot_pix + y * bs + x) | (wino_rot(pos, r) << 28);
                 break;
             }
         }
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256) void wino_setup_kernel(BatchGeom g, const int*
     }
     if (tid < NTL) {
         const int gi = t0 + tid;
-        int lstr = 2 * wino_tiles_per_side(hdr[8 + 2]) + 2, lpos = 0, trl = 0;  // a dummy tile reads real positions, stores nothing
+        int lstr = wino_pitch(wino_tiles_per_side(hdr[8 + 2])), lpos = 0, trl = 0;  // a dummy tile reads real positions, stores nothing
         int orow[4] = {-1, -1, -1, -1};
         if (gi < total_tiles) {
             for (int s = 0; s < nsub; ++s) {
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void wino_setup_kernel(BatchGeom g, const int*
                 if (gi >= sb[4] && gi < sb[5]) {
                     const int bs = sb[2], tw = wino_tiles_per_side(bs), tt = gi - sb[7];
                     const int ty = tt / tw, tx = tt - ty * tw;
-                    lstr = 2 * tw + 2;
+                    lstr = wino_pitch(tw);
                     trl = ty - sb[1];
                     lpos = sb[0] + 2 * trl * lstr + tx;  // patch column j sits at tx + (j >> 1) of the even / odd half
 #pragma unroll
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void wino_setup_kernel(BatchGeom g, const int*
                 }
             }
         }
-        tab_tile[(size_t)blk * NTL + tid] = lpos | (lstr << 16) | ((trl & 3) << 24);
+        tab_tile[(size_t)blk * NTL + tid] = lpos | (lstr << 16) | ((trl & 1) << 24);
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) tab_out[((size_t)blk * NTL + tid) * 4 + ab] = orow[ab];
     }
@@ -177,7 +183,7 @@ template <int N> __device__ __forceinline__ void wait_a(f16x8 (&a)[2][4]) {
 // waits.  Batches: raw DMA of chunk c, weight loads of stage s.  Prologue: raw(0), A(0), A(1), raw(1).  Item k (stage
 // k / NF, column k % NF): first, when item k+2 opens chunk c2 >= 1 ... wait, the barrier, raw(c2+1); then, at
 // column 0, A(stage+2).
-template <int NCH, int NF> struct WinoOrder {
+template <int NCH, int NF, int BI> struct WinoOrder {
     static constexpr int nstages = 2 * NCH, nitems = nstages * NF;
     // batches issued after batch (kind, idx) up to and including item `upto`'s own batches (`upto` = -1: prologue
     // only); with before_dma the raw batch of item `upto` (and its A batch) are not counted
@@ -185,7 +191,7 @@ template <int NCH, int NF> struct WinoOrder {
         int cnt = 0;
         bool seen = false;
         auto ev = [&](int k2, int i2) {
-            if (seen) ++cnt;
+            if (seen) cnt += k2 == 0 ? BI : 8;
             if (k2 == kind && i2 == idx) seen = true;
         };
         ev(0, 0); ev(1, 0); ev(1, 1);
@@ -193,19 +199,19 @@ template <int NCH, int NF> struct WinoOrder {
         for (int k = 0; k <= upto; ++k) {
             const bool last = k == upto;
             if (last && before_dma) break;
-            if (k + 2 < nitems && (k + 2) % (2 * NF) == 0) {
-                const int c2 = (k + 2) / (2 * NF);
+            if (k + 3 < nitems && (k + 3) % (2 * NF) == 0) {
+                const int c2 = (k + 3) / (2 * NF);
                 if (c2 + 1 < NCH) ev(0, c2 + 1);
             }
             if (k % NF == 0 && k / NF + 2 < nstages) ev(1, k / NF + 2);
         }
-        return cnt * 8;
+        return cnt;
     }
 };
 
-template <int N> __device__ __forceinline__ void wait_lds_all(f16x8 (&r)[N]) {
-    static_assert(N == 6, "six patch fragments per tile column and stage");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]));
+// wait until at most YOUNG younger LDS reads are outstanding (LDS returns in order)
+template <int YOUNG> __device__ __forceinline__ void wait_patch(f16x8 (&r)[6]) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(YOUNG));
 }
 
 template <int ACT>
@@ -258,10 +264,10 @@ __device__ __forceinline__ void wino_store(const WinoParams& wp, const unsigned 
 }
 
 // NCH = 32-channel chunks of the input (cin_s / 32): the K loop is fully unrolled, every ring index is static.
-template <int NCH>
+template <int NCH, int BI>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoParams wp) {
     using Cfg = WinoCfg;
-    constexpr int NPOS = Cfg::NPOS, NTL = Cfg::NTL, BI = Cfg::BI, NF = Cfg::NF;
+    constexpr int NPOS = Cfg::NPOS, NTL = Cfg::NTL, NF = Cfg::NF;  // BI: DMA instructions per wave and chunk (64 positions each)
     const ConvParams& p = wp.c;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -299,17 +305,21 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoParams wp) {
     const int kg = lane >> 4;
     const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
     const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
-    uint32_t addr_a[NF], addr_b[NF], hoff[NF];
+    // byte address of patch cell (row i of the 4x4 patch, column cell c): c = 0..3 -> even tx, odd tx, even tx+1, odd tx+1
+    uint32_t cell[NF][2][4];
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
         const int pk = wp.tab_tile[(size_t)blk * NTL + n * 16 + (lane & 15)];
-        const int lpos = pk & 0xffff, lstr = (pk >> 16) & 0xff, trl = pk >> 24;
-        const uint32_t base = (uint32_t)(uintptr_t)smem + (uint32_t)(lpos * 64);
-        // raw row 2*trl + i of the subregion is stored with its k-groups rotated by (trl + (i >> 1)) & 3: tiles of
-        // neighbouring tile rows that share a bank group by position no longer share it by k-group
-        addr_a[n] = base + (uint32_t)(ia * lstr * 64) + (uint32_t)(((kg + trl + (ia >> 1)) & 3) * 16);
-        addr_b[n] = base + (uint32_t)(ib * lstr * 64) + (uint32_t)(((kg + trl + (ib >> 1)) & 3) * 16);
-        hoff[n] = (uint32_t)((lstr >> 1) * 64);  // from an even column to the odd column right of it
+        const int lpos = pk & 0xffff, pitch = (pk >> 16) & 0xff, trl = pk >> 24, half = (pitch - 1) >> 1;
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) {
+            const int i = ab ? ib : ia, row = 2 * trl + i;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int pos = lpos + i * pitch + (c & 1) * half + (c >> 1);
+                cell[n][ab][c] = (uint32_t)(uintptr_t)smem + (uint32_t)(pos * 64 + ((kg + wino_rot(pos, row)) & 3) * 16);
+            }
+        }
     }
     const f16 sgn = xi == 1 ? (f16)1.f : (f16)-1.f;
     const f16x8 sgn8 = {sgn, sgn, sgn, sgn, sgn, sgn, sgn, sgn};
@@ -363,73 +373,69 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoParams wp) {
     uint32_t negbits = 0xBC00BC00u;
     asm volatile("" : "+s"(negbits));
     const f16x8 neg8 = __builtin_bit_cast(f16x8, (u32x4){negbits, negbits, negbits, negbits});
-    f16x8 R[6];
+    f16x8 R[2][6];  // patch fragments of item j live in R[j & 1]; reads run TWO items ahead of their transform
     auto read_patch = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        constexpr int stage = k / NF, n = k % NF, H = stage & 1, RB = (stage >> 1) & 1;
+        constexpr int stage = k / NF, n = k % NF, H = stage & 1, RB = (stage >> 1) & 1, B = k & 1;
         constexpr int SO = RB * Cfg::RAW_BYTES;
-        // patch columns j = H .. H+2: (even tx, odd tx, even tx+1) or (odd tx, even tx+1, odd tx+1)
-        const uint32_t ae = addr_a[n], ao = ae + hoff[n], be = addr_b[n], bo = be + hoff[n];
-        if constexpr (H == 0) {
-            ds_read16<SO + 0>(R[0], ae);
-            ds_read16<SO + 0>(R[1], ao);
-            ds_read16<SO + 64>(R[2], ae);
-            ds_read16<SO + 0>(R[3], be);
-            ds_read16<SO + 0>(R[4], bo);
-            ds_read16<SO + 64>(R[5], be);
-        } else {
-            ds_read16<SO + 0>(R[0], ao);
-            ds_read16<SO + 64>(R[1], ae);
-            ds_read16<SO + 64>(R[2], ao);
-            ds_read16<SO + 0>(R[3], bo);
-            ds_read16<SO + 64>(R[4], be);
-            ds_read16<SO + 64>(R[5], bo);
-        }
+        // patch columns j = H .. H+2: cells (even tx, odd tx, even tx+1) or (odd tx, even tx+1, odd tx+1)
+        ds_read16<SO>(R[B][0], cell[n][0][H + 0]);
+        ds_read16<SO>(R[B][1], cell[n][0][H + 1]);
+        ds_read16<SO>(R[B][2], cell[n][0][H + 2]);
+        ds_read16<SO>(R[B][3], cell[n][1][H + 0]);
+        ds_read16<SO>(R[B][4], cell[n][1][H + 1]);
+        ds_read16<SO>(R[B][5], cell[n][1][H + 2]);
     };
     // t[j] = d[ia][j] + sgn * d[ib][j];  V[nu] = (t0 - t2, t1 + t2, t2 - t1, t1 - t3); a stage holds nu = 2H, 2H+1
-    auto transform = [&](auto hc, f16x8 (&V)[2]) {
+    auto transform = [&](auto hc, f16x8 (&Rb)[6], f16x8 (&V)[2]) {
         constexpr int H = decltype(hc)::value;
-        const f16x8 ta = R[0] + sgn8 * R[3], tb = R[1] + sgn8 * R[4], tc = R[2] + sgn8 * R[5];
+        const f16x8 ta = Rb[0] + sgn8 * Rb[3], tb = Rb[1] + sgn8 * Rb[4], tc = Rb[2] + sgn8 * Rb[5];
         if constexpr (H == 0) { V[0] = ta + neg8 * tc; V[1] = tb + tc; }   // ta, tb, tc = t0, t1, t2
         else { V[0] = tb + neg8 * ta; V[1] = ta + neg8 * tc; }             // ta, tb, tc = t1, t2, t3
     };
-    using Order = WinoOrder<NCH, NF>;
+    using Order = WinoOrder<NCH, NF, BI>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
 
     issue_raw(0, 0);
-    load_a(0, std::integral_constant<int, 0>{});
-    load_a(1, std::integral_constant<int, 1>{});
+    load_a(0, I0{});
+    load_a(1, I1{});
     if (dbg) dbg[1] = __builtin_amdgcn_s_memtime();
-    wait_vmcnt<Order::after(0, 0, -1, false) - (NCH > 1 ? 8 : 0)>();  // raw(1) is not out yet
+    wait_vmcnt<16>();  // raw(0) landed; the two weight batches may still be in flight
     __builtin_amdgcn_s_barrier();
     if (dbg) dbg[2] = __builtin_amdgcn_s_memtime();
     if constexpr (nchunks > 1) issue_raw(1, 1);
     f16x8 Vc[2], Vn[2];
     unsigned long long wait_a_cycles = 0;
-    read_patch(std::integral_constant<int, 0>{});
-    wait_lds_all(R);
-    transform(std::integral_constant<int, 0>{}, Vc);
-    if constexpr (nitems > 1) read_patch(std::integral_constant<int, 1>{});
+    read_patch(I0{});
+    read_patch(I1{});
+    wait_patch<6>(R[0]);
+    transform(I0{}, R[0], Vc);
+    read_patch(I2{});
 
     static_for<nitems>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int stage = k / NF, n = k % NF, SLOT = stage % 3, H = stage & 1;
         if constexpr (k + 1 < nitems) {
-            wait_lds_all(R);  // patch(k+1), read one item ago
-            transform(std::integral_constant<int, ((k + 1) / NF) & 1>{}, Vn);
+            // patch(k+1) was read two items ago; only patch(k+2) is younger
+            wait_patch<(k + 2 < nitems ? 6 : 0)>(R[(k + 1) & 1]);
+            transform(std::integral_constant<int, ((k + 1) / NF) & 1>{}, R[(k + 1) & 1], Vn);
         }
-        if constexpr (k + 2 < nitems) {
-            if constexpr ((k + 2) % (2 * NF) == 0) {
-                constexpr int chunk2 = (k + 2) / (2 * NF);
+        if constexpr (k + 3 < nitems) {
+            if constexpr ((k + 3) % (2 * NF) == 0) {
+                constexpr int chunk2 = (k + 3) / (2 * NF);
                 constexpr int young = Order::after(0, chunk2, k, true);
                 if constexpr (chunk2 == 4) { if (dbg) dbg[13] = __builtin_amdgcn_s_memtime(); }
-                wait_vmcnt<young>();
+                // this wave's reads of chunk2-1 are done (the DMA below overwrites that slot), raw(chunk2) has landed
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(young) : "memory");
                 if constexpr (chunk2 == 4) { if (dbg) dbg[14] = __builtin_amdgcn_s_memtime(); }
-                __builtin_amdgcn_s_barrier();  // raw(chunk2) is in LDS; every wave has read its last patch of chunk2-1
+                __builtin_amdgcn_s_barrier();
                 if constexpr (chunk2 == 4) { if (dbg) dbg[15] = __builtin_amdgcn_s_memtime(); }
                 if constexpr (chunk2 + 1 < nchunks) issue_raw(chunk2 + 1, (chunk2 + 1) & 1);
                 if constexpr (chunk2 < 7) { if (dbg) dbg[2 + chunk2] = __builtin_amdgcn_s_memtime(); }
             }
-            read_patch(std::integral_constant<int, k + 2>{});
+            read_patch(std::integral_constant<int, k + 3>{});
         }
         if constexpr (n == 0 && stage + 2 < nstages) load_a(stage + 2, std::integral_constant<int, (SLOT + 2) % 3>{});
         if constexpr (n == 0) {

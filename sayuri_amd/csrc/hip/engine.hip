@@ -227,7 +227,7 @@ static bool wino_enabled() {  // read when an engine finalises its weights / per
     const char* e = getenv("SAYURI_CONV");
     return e && !strncmp(e, "wino", 4);
 }
-struct WinoGeom { int blocks = 0, total_tiles = 0; bool fits = false; };
+struct WinoGeom { int blocks = 0, total_tiles = 0, max_pos = 0; bool fits = false; };
 static WinoGeom wino_geom(const HostGeom& geom) {
     WinoGeom wg;
     std::vector<int> toff(geom.n + 1, 0);
@@ -246,13 +246,14 @@ static WinoGeom wino_geom(const HostGeom& geom) {
             const int tw = wino_tiles_per_side(geom.bsz[m]);
             const int a = std::max(t0, toff[m]) - toff[m], b = std::min(t1, toff[m + 1]) - toff[m];
             const int rows = 2 * ((b - 1) / tw - a / tw + 1) + 2;
-            pos += rows * (2 * tw + 2);
+            pos += rows * wino_pitch(tw);
             ++sub;
         }
         max_pos = std::max(max_pos, pos);
         max_sub = std::max(max_sub, sub);
     }
     // a dummy tile of the last block reads the 4x4 patch at position 0 of the first subregion: always inside NPOS
+    wg.max_pos = max_pos;
     wg.fits = wg.total_tiles > 0 && max_pos <= WinoCfg::NPOS && max_sub <= kMaxSub;
     return wg;
 }
@@ -283,21 +284,26 @@ static std::vector<f16> wino_image(const float* w, int cin, int cout, int cin_s,
     return img;
 }
 typedef void (*WinoFn)(const WinoParams);
-// the kernel is instantiated per input width (cin_s / 32 chunks, K loop fully unrolled)
-static WinoFn wino_kernel_for(int nchunks) {
+// the kernel is instantiated per input width (cin_s / 32 chunks, K loop fully unrolled) and per raw-image size
+// (6 or 8 DMA instructions of 64 positions per wave and chunk)
+template <int BI> static WinoFn wino_kernel_bi(int nchunks) {
     switch (nchunks) {
-    case 2: return &conv_wino_kernel<2>;
-    case 3: return &conv_wino_kernel<3>;
-    case 4: return &conv_wino_kernel<4>;
-    case 6: return &conv_wino_kernel<6>;
-    case 8: return &conv_wino_kernel<8>;
-    case 12: return &conv_wino_kernel<12>;
+    case 2: return &conv_wino_kernel<2, BI>;
+    case 3: return &conv_wino_kernel<3, BI>;
+    case 4: return &conv_wino_kernel<4, BI>;
+    case 6: return &conv_wino_kernel<6, BI>;
+    case 8: return &conv_wino_kernel<8, BI>;
+    case 12: return &conv_wino_kernel<12, BI>;
     default: return nullptr;
     }
 }
+static WinoFn wino_kernel_for(int nchunks, int max_pos = WinoCfg::NPOS) {
+    return max_pos <= 6 * 64 ? wino_kernel_bi<6>(nchunks) : wino_kernel_bi<8>(nchunks);
+}
 static void enable_big_lds_wino() {
     for (int nch : {2, 3, 4, 6, 8, 12})
-        (void)hipFuncSetAttribute((const void*)wino_kernel_for(nch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        for (int mp : {6 * 64, 8 * 64})
+            (void)hipFuncSetAttribute((const void*)wino_kernel_for(nch, mp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
 }
 
 struct Stat {
@@ -987,7 +993,7 @@ private:
             const double flops = 2.0 * px * L.cin * L.cout * 9;  // algorithmic (direct-form) count
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 16);
             const int grid = round_up(wino_geom_.blocks, 8) * (L.wino_ko_pad / WinoCfg::KO_T);
-            const WinoFn fn = wino_kernel_for(L.cin_s / 32);
+            const WinoFn fn = wino_kernel_for(L.cin_s / 32, wino_geom_.max_pos);
             return timed(name, flops, bytes, [&] {
                 hipLaunchKernelGGL(fn, dim3(grid), dim3(WinoCfg::NT), WinoCfg::lds_bytes(), stream_, wp);
             });
@@ -1493,7 +1499,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
                 p.in = dx; p.w = dwi; p.bias = dwb; p.res = dres; p.out = dy; p.g = g;
                 p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = wko; p.taps = 9; p.act = act; p.npos = 0;
                 p.num_pix_tiles = wg.blocks;
-                hipLaunchKernelGGL(wino_kernel_for(cin_s / 32), dim3(round_up(wg.blocks, 8) * (wko / WinoCfg::KO_T)),
+                hipLaunchKernelGGL(wino_kernel_for(cin_s / 32, wg.max_pos), dim3(round_up(wg.blocks, 8) * (wko / WinoCfg::KO_T)),
                                    dim3(WinoCfg::NT), WinoCfg::lds_bytes(), 0, wp);
                 HIP_OK(hipGetLastError());
                 HIP_OK(hipDeviceSynchronize());
