@@ -332,6 +332,13 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoParams wp) {
 
     auto issue_raw = [&](int chunk, int slot) {
         const unsigned char* gb = gin0 + chunk * (kChunk * 2);  // uniform
+#if defined(SAYURI_WINO_ABL) && (SAYURI_WINO_ABL & 8)  // timing only: every DMA reads the zero prefix
+        if (chunk > 1) {
+#pragma unroll
+            for (int i = 0; i < BI; ++i) glds16(gin0 + (lane & 3) * 16, smem + slot * Cfg::RAW_BYTES + (xi + 4 * i) * 1024);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < BI; ++i) glds16(gb + voff[i], smem + slot * Cfg::RAW_BYTES + (xi + 4 * i) * 1024);
     };
@@ -351,6 +358,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoParams wp) {
     auto load_a = [&](int stage, auto slotc) {
         constexpr int slot = decltype(slotc)::value;
         const unsigned char* src = gw + (size_t)(stage >> 1) * W_CHUNK + (stage & 1) * 8 * 1024;  // uniform
+#if defined(SAYURI_WINO_ABL) && (SAYURI_WINO_ABL & 4)  // timing only: the weight ring is filled once
+        if (stage > 2) {
+            // keep the hand-counted vmcnt consistent: eight cheap loads of one cached line
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gload16<0>(A[slot][q >> 2][q & 3], gw, 0u);
+            return;
+        }
+#endif
         gload16<0>(A[slot][0][0], src, wlane);
         gload16<1024>(A[slot][0][1], src, wlane);
         gload16<2048>(A[slot][0][2], src, wlane);
@@ -378,6 +393,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoParams wp) {
         constexpr int k = decltype(kc)::value;
         constexpr int stage = k / NF, n = k % NF, H = stage & 1, RB = (stage >> 1) & 1, B = k & 1;
         constexpr int SO = RB * Cfg::RAW_BYTES;
+#if defined(SAYURI_WINO_ABL) && (SAYURI_WINO_ABL & 2)  // timing only: patch fragments read once per kernel
+        if (k > 2) { asm volatile("" : "+v"(R[B][0]), "+v"(R[B][1]), "+v"(R[B][2]), "+v"(R[B][3]), "+v"(R[B][4]), "+v"(R[B][5])); return; }
+#endif
         // patch columns j = H .. H+2: cells (even tx, odd tx, even tx+1) or (odd tx, even tx+1, odd tx+1)
         ds_read16<SO>(R[B][0], cell[n][0][H + 0]);
         ds_read16<SO>(R[B][1], cell[n][0][H + 1]);
@@ -389,6 +407,11 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoParams wp) {
     // t[j] = d[ia][j] + sgn * d[ib][j];  V[nu] = (t0 - t2, t1 + t2, t2 - t1, t1 - t3); a stage holds nu = 2H, 2H+1
     auto transform = [&](auto hc, f16x8 (&Rb)[6], f16x8 (&V)[2]) {
         constexpr int H = decltype(hc)::value;
+#if defined(SAYURI_WINO_ABL) && (SAYURI_WINO_ABL & 1)  // timing only: no transform arithmetic
+        V[0] = Rb[0]; V[1] = Rb[4];
+        asm volatile("" : "+v"(Rb[1]), "+v"(Rb[2]), "+v"(Rb[3]), "+v"(Rb[5]));
+        return;
+#endif
         const f16x8 ta = Rb[0] + sgn8 * Rb[3], tb = Rb[1] + sgn8 * Rb[4], tc = Rb[2] + sgn8 * Rb[5];
         if constexpr (H == 0) { V[0] = ta + neg8 * tc; V[1] = tb + tc; }   // ta, tb, tc = t0, t1, t2
         else { V[0] = tb + neg8 * ta; V[1] = ta + neg8 * tc; }             // ta, tb, tc = t1, t2, t3

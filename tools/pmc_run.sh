@@ -7,6 +7,6 @@ tag=$1; shift
 set_=$1; shift
 mkdir -p gpurun_out
 env "$@" timeout 70 rocprofv3 --pmc $set_ --kernel-trace -d gpurun_out/pmc_$tag -o p -- \
-    python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$tag.out 2> gpurun_out/pmc_$tag.err
+    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --selfplay-seconds 0 > gpurun_out/pmc_$tag.out 2> gpurun_out/pmc_$tag.err
 echo "pmc_$tag rc=$?"
 grep -E "Memory access fault|Segmentation|error" gpurun_out/pmc_$tag.err | head -3
