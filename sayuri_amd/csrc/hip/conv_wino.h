@@ -511,4 +511,246 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoParams wp) {
     if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[12] = __builtin_amdgcn_s_memtime(); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eight-wave variant: two waves per SIMD, so that one wave's transform arithmetic, LDS waits and epilogue overlap the
+// other's MFMAs (the four-wave kernel above spends half of its life issuing VALU instructions with nothing else on
+// the SIMD: DESIGN.md "Kernel 3").  Wave (xi, h) owns transform row xi and the nu PAIR h -- (0,1) or (3,2) -- for all 64
+// output channels and 48 tiles: 96 accumulators, its own eight weight fragments per chunk (no weight is loaded
+// twice), a two-chunk weight ring.  With the patch columns of pair 1 taken in the order j = 3,2,1 both pairs use one
+// formula, Vx = ta - tc, Vy = tb + sy*tc (sy = +1 / -1); pair 1 then accumulates -M[xi][3], which the output transform
+// undoes.
+struct Wino8Cfg {
+    static constexpr int KO_T = 64, NF = 3, NTL = 16 * NF, NWAVE = 8, NT = 512;
+    static constexpr int NPOS = WinoCfg::NPOS, RAW_BYTES = NPOS * 64;
+    static constexpr int Z_RS = KO_T * 4 + 16;
+    static constexpr int STAGE_BYTES = 8 * NTL * Z_RS;     // one b at a time: [wave][tile][ch]
+    static constexpr int OUTROW_OFF = STAGE_BYTES > 2 * RAW_BYTES ? STAGE_BYTES : 2 * RAW_BYTES;
+    static constexpr size_t lds_bytes() { return OUTROW_OFF + NTL * 4 * 4; }
+    static_assert(NTL == WinoCfg::NTL, "both kernels share the block tables");
+};
+
+template <int ACT>
+__device__ __forceinline__ void wino8_store(const WinoParams& wp, const unsigned char* stage, const int* out_row, int kt, int tid,
+                                            int b, const f32x4& bias0, const f32x4& bias1) {
+    constexpr int NTL = Wino8Cfg::NTL, RS = Wino8Cfg::Z_RS, SLAB = NTL * RS;
+    const ConvParams& p = wp.c;
+    f16* __restrict__ gout = (f16*)p.out;
+    const f16* __restrict__ gres = (const f16*)p.res;
+    const int cg = tid & 7;
+    const int ko = kt * Wino8Cfg::KO_T + cg * 8;
+    // items (tile, a) x 8 channel groups = 768 per phase: two rounds of 512 threads, the second half full
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int it = (k * 512 + tid) >> 3;  // tile*2 + a
+        if (it >= NTL * 2) break;
+        const int tile = it >> 1, a = it & 1;
+        const int row = out_row[tile * 4 + a * 2 + b];
+        f16x8 rr = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (gres && row >= 0) rr = *(const f16x8*)(gres + (size_t)row * p.cout_s + ko);
+        // Y[a][b] = sum_xi At[a][xi] (P[xi,0][b] + P[xi,1][b]);  At = [[1,1,1,0],[0,1,-1,-1]]
+        const unsigned char* z = stage + (size_t)tile * RS + cg * 32;
+        f32x4 v0 = bias0, v1 = bias1;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const int xi = a ? x + 1 : x;
+            const float sg = (a && x > 0) ? -1.f : 1.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned char* zs = z + (size_t)(xi * 2 + h) * SLAB;
+                v0 += sg * *(const f32x4*)zs;
+                v1 += sg * *(const f32x4*)(zs + 16);
+            }
+        }
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (gres) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += (float)rr[q];
+        }
+        f16x8 hh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hh[q] = (f16)activate(v[q], ACT);
+        if (row >= 0) *(f16x8*)(gout + (size_t)row * p.cout_s + ko) = hh;
+    }
+}
+
+// NCH = 32-channel chunks (fully unrolled), DI = DMA instructions per wave and chunk (3: up to 384 raw positions, 4: 512)
+template <int NCH, int DI>
+__global__ __launch_bounds__(512) void conv_wino8_kernel(const WinoParams wp) {
+    using Cfg = Wino8Cfg;
+    constexpr int NPOS = Cfg::NPOS, NTL = Cfg::NTL, NF = Cfg::NF;
+    const ConvParams& p = wp.c;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xi = wave >> 1, H = wave & 1;
+    const int kts = p.ko_pad / Cfg::KO_T;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int kt = rest % kts;
+    const int blk = (rest / kts) * 8 + xcd;
+    if (blk >= wp.num_blocks) return;
+    unsigned long long* dbg = (wp.dbg && lane == 0 && blockIdx.x < 64) ? wp.dbg + ((size_t)blockIdx.x * 4 + (wave & 3)) * 16 : nullptr;
+    if (dbg && wave < 4) dbg[0] = __builtin_amdgcn_s_memtime();
+
+    // ---- DMA role: instruction q = wave + 8*i moves positions 16q .. 16q+15 (see conv_wino_kernel)
+    const unsigned char* gin0 = (const unsigned char*)p.in - kZeroPrefix;
+    uint32_t voff[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+        const int src = wp.tab_src[(size_t)blk * NPOS + (wave + 8 * i) * 16 + (lane >> 2)];
+        const uint32_t kq = (uint32_t)((lane & 3) - (src >> 28)) & 3u;
+        voff[i] = src >= 0 ? (uint32_t)kZeroPrefix + (uint32_t)(src & 0x0fffffff) * (uint32_t)(p.cin_s * 2) + kq * 16u : 0u;
+    }
+    int* out_row = (int*)(smem + Cfg::OUTROW_OFF);
+    if (tid < NTL * 4) out_row[tid] = wp.tab_out[(size_t)blk * NTL * 4 + tid];
+
+    // ---- patch cells: rows ia / ib of B^T's row xi; columns j = 0,1,2 (pair 0) or 3,2,1 (pair 1)
+    const int kg = lane >> 4;
+    const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+    const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    uint32_t cell[NF][2][3];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+        const int pk = wp.tab_tile[(size_t)blk * NTL + n * 16 + (lane & 15)];
+        const int lpos = pk & 0xffff, pitch = (pk >> 16) & 0xff, trl = pk >> 24, half = (pitch - 1) >> 1;
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) {
+            const int i = ab ? ib : ia, row = 2 * trl + i;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int j = H ? 3 - c : c;  // patch column; cell = even/odd half (j & 1), tile column tx + (j >> 1)
+                const int pos = lpos + i * pitch + (j & 1) * half + (j >> 1);
+                cell[n][ab][c] = (uint32_t)(uintptr_t)smem + (uint32_t)(pos * 64 + ((kg + wino_rot(pos, row)) & 3) * 16);
+            }
+        }
+    }
+    const f16 sgn = xi == 1 ? (f16)1.f : (f16)-1.f;
+    const f16x8 sgn8 = {sgn, sgn, sgn, sgn, sgn, sgn, sgn, sgn};
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t negbits = 0xBC00BC00u, sybits = H ? 0xBC00BC00u : 0x3C003C00u;
+    asm volatile("" : "+s"(negbits), "+s"(sybits));
+    const f16x8 neg8 = __builtin_bit_cast(f16x8, (u32x4){negbits, negbits, negbits, negbits});
+    const f16x8 sy8 = __builtin_bit_cast(f16x8, (u32x4){sybits, sybits, sybits, sybits});
+
+    constexpr int nchunks = NCH;
+    // weights [kt][chunk][xi][nu][m]: this wave's Vx pairs with nu = 0 / 3, Vy with nu = 1 / 2
+    const unsigned char* gw = (const unsigned char*)p.w + ((size_t)kt * nchunks * 4 + xi) * 16 * 1024;
+    const int nux = H ? 3 : 0, nuy = H ? 2 : 1;
+    const uint32_t wlane = (uint32_t)lane * 16u;
+    constexpr size_t W_CHUNK = 4 * 16 * 1024;
+
+    auto issue_raw = [&](int chunk, int slot) {
+        const unsigned char* gb = gin0 + chunk * (kChunk * 2);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) glds16(gb + voff[i], smem + slot * Cfg::RAW_BYTES + (wave + 8 * i) * 1024);
+    };
+    f32x4 acc[2][4][NF];  // [x / y][m][n]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < NF; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 A[2][2][4];  // [ring slot][x / y][m]
+    auto load_a = [&](int chunk, auto slotc) {
+        constexpr int slot = decltype(slotc)::value;
+        const unsigned char* sx = gw + (size_t)chunk * W_CHUNK + nux * 4096;
+        const unsigned char* sy = gw + (size_t)chunk * W_CHUNK + nuy * 4096;
+        gload16<0>(A[slot][0][0], sx, wlane);
+        gload16<1024>(A[slot][0][1], sx, wlane);
+        gload16<2048>(A[slot][0][2], sx, wlane);
+        gload16<3072>(A[slot][0][3], sx, wlane);
+        gload16<0>(A[slot][1][0], sy, wlane);
+        gload16<1024>(A[slot][1][1], sy, wlane);
+        gload16<2048>(A[slot][1][2], sy, wlane);
+        gload16<3072>(A[slot][1][3], sy, wlane);
+    };
+    f16x8 R[6];
+    auto read_patch = [&](auto slotc, int n) {
+        constexpr int SO = decltype(slotc)::value * Cfg::RAW_BYTES;
+        ds_read16<SO>(R[0], cell[n][0][0]);
+        ds_read16<SO>(R[1], cell[n][0][1]);
+        ds_read16<SO>(R[2], cell[n][0][2]);
+        ds_read16<SO>(R[3], cell[n][1][0]);
+        ds_read16<SO>(R[4], cell[n][1][1]);
+        ds_read16<SO>(R[5], cell[n][1][2]);
+    };
+
+    issue_raw(0, 0);
+    load_a(0, std::integral_constant<int, 0>{});
+    static_for<nchunks>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, S = c & 1;
+        if constexpr (c == 0) { if (dbg && wave < 4) dbg[1] = __builtin_amdgcn_s_memtime(); }
+        wait_vmcnt<8>();               // raw(c) landed; the weights of chunk c were issued after it
+        __builtin_amdgcn_s_barrier();  // every wave's pieces are in LDS; every wave is done with the other ring slot
+        if constexpr (c < 8) { if (dbg && wave < 4) dbg[2 + c] = __builtin_amdgcn_s_memtime(); }
+        if constexpr (c + 1 < nchunks) {
+            issue_raw(c + 1, S ^ 1);
+            load_a(c + 1, std::integral_constant<int, S ^ 1>{});
+        }
+        wait_a<(c + 1 < nchunks ? DI + 8 : 0)>(A[S]);
+        read_patch(std::integral_constant<int, S>{}, 0);
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            wait_patch<0>(R);
+            // t[j] = d[ia][j] + sgn * d[ib][j] for this pair's three columns; Vx = ta - tc, Vy = tb + sy * tc
+            const f16x8 ta = R[0] + sgn8 * R[3], tb = R[1] + sgn8 * R[4], tc = R[2] + sgn8 * R[5];
+            f16x8 V[2];
+            V[0] = ta + neg8 * tc;
+            V[1] = tb + sy8 * tc;
+            if (n + 1 < NF) read_patch(std::integral_constant<int, S>{}, n + 1);
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[v][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[S][v][m], V[v], acc[v][m][n], 0, 0, 0);
+        }
+    });
+
+    // ---- output transform.  Pair 0 holds (M0, M1), pair 1 holds (-M3, M2).  Z[b] = M A with A^T = [[1,1,1,0],[0,1,-1,-1]]:
+    // partial sums P[b=0] = M0 + M1 | M2,  P[b=1] = M1 | -M2 - M3; the xi sum and the pair sum go through LDS, one b at a time.
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    if (dbg && wave < 4) dbg[10] = __builtin_amdgcn_s_memtime();
+    unsigned char* stage = smem;
+    constexpr int RS = Cfg::Z_RS;
+    const int cgo = tid & 7, koo = kt * Cfg::KO_T + cgo * 8;
+    const bool ko_ok = koo < p.cout_s;  // cout_s is a multiple of 32: 8-channel groups never straddle it
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
+    if (ko_ok) { bias0 = *(const f32x4*)(p.bias + koo); bias1 = *(const f32x4*)(p.bias + koo + 4); }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        lds_barrier();  // raw ring / previous phase no longer read
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int kol = m * 16 + 4 * kg;
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                const int tile = n * 16 + (lane & 15);
+                f32x4 z;
+                if (b == 0) z = H ? acc[1][m][n] : acc[0][m][n] + acc[1][m][n];
+                else z = H ? acc[0][m][n] - acc[1][m][n] : acc[1][m][n];
+                *(f32x4*)(stage + ((size_t)(wave * NTL + tile) * RS) + kol * 4) = z;
+            }
+        }
+        lds_barrier();
+        if (b == 1) { if (dbg && wave < 4) dbg[11] = __builtin_amdgcn_s_memtime(); }
+        if (ko_ok) {
+            switch (p.act) {
+            case kMish: wino8_store<kMish>(wp, stage, out_row, kt, tid, b, bias0, bias1); break;
+            case kIdentity: wino8_store<kIdentity>(wp, stage, out_row, kt, tid, b, bias0, bias1); break;
+            case kReLU: wino8_store<kReLU>(wp, stage, out_row, kt, tid, b, bias0, bias1); break;
+            case kSwish: wino8_store<kSwish>(wp, stage, out_row, kt, tid, b, bias0, bias1); break;
+            case kELU: wino8_store<kELU>(wp, stage, out_row, kt, tid, b, bias0, bias1); break;
+            case kSELU: wino8_store<kSELU>(wp, stage, out_row, kt, tid, b, bias0, bias1); break;
+            case kGELU: wino8_store<kGELU>(wp, stage, out_row, kt, tid, b, bias0, bias1); break;
+            default: wino8_store<kHardSwish>(wp, stage, out_row, kt, tid, b, bias0, bias1); break;
+            }
+        }
+    }
+    if (dbg && wave < 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[12] = __builtin_amdgcn_s_memtime(); dbg[9] = dbg[0]; dbg[13] = dbg[14] = dbg[15] = dbg[5]; }
+}
+
 }  // namespace sayuri

@@ -297,13 +297,34 @@ template <int BI> static WinoFn wino_kernel_bi(int nchunks) {
     default: return nullptr;
     }
 }
-static WinoFn wino_kernel_for(int nchunks, int max_pos = WinoCfg::NPOS) {
-    return max_pos <= 6 * 64 ? wino_kernel_bi<6>(nchunks) : wino_kernel_bi<8>(nchunks);
+template <int DI> static WinoFn wino8_kernel_di(int nchunks) {
+    switch (nchunks) {
+    case 2: return &conv_wino8_kernel<2, DI>;
+    case 3: return &conv_wino8_kernel<3, DI>;
+    case 4: return &conv_wino8_kernel<4, DI>;
+    case 6: return &conv_wino8_kernel<6, DI>;
+    case 8: return &conv_wino8_kernel<8, DI>;
+    case 12: return &conv_wino8_kernel<12, DI>;
+    default: return nullptr;
+    }
+}
+// SAYURI_CONV=wino8: the eight-wave variant (two waves per SIMD)
+static bool wino_eight() {
+    const char* e = getenv("SAYURI_CONV");
+    return e && !strncmp(e, "wino8", 5);
+}
+struct WinoLaunch { WinoFn fn; int threads; size_t lds; };
+static WinoLaunch wino_kernel_for(int nchunks, int max_pos = WinoCfg::NPOS, bool eight = false) {
+    if (eight)
+        return {max_pos <= 6 * 64 ? wino8_kernel_di<3>(nchunks) : wino8_kernel_di<4>(nchunks), Wino8Cfg::NT, Wino8Cfg::lds_bytes()};
+    return {max_pos <= 6 * 64 ? wino_kernel_bi<6>(nchunks) : wino_kernel_bi<8>(nchunks), WinoCfg::NT, WinoCfg::lds_bytes()};
 }
 static void enable_big_lds_wino() {
     for (int nch : {2, 3, 4, 6, 8, 12})
         for (int mp : {6 * 64, 8 * 64})
-            (void)hipFuncSetAttribute((const void*)wino_kernel_for(nch, mp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+            for (bool eight : {false, true})
+                (void)hipFuncSetAttribute((const void*)wino_kernel_for(nch, mp, eight).fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kMaxLds);
 }
 
 struct Stat {
@@ -589,7 +610,7 @@ public:
             }
             fprintf(stderr, "[wino timeline, mean over 64 wgs, wave 0, cycles since start]\n");
             const char* nm[13] = {"", "tables+first issue", "first barrier", "chunk1", "chunk2", "chunk3", "chunk4", "chunk5",
-                                  "chunk6", "sum of weight waits", "loop end", "Z staged", "end"};
+                                  "chunk6", "sum of weight waits", "loop end", "Z staged (wino8: b=1 staged)", "end"};
             for (int k = 1; k <= 12; ++k) fprintf(stderr, "  %-20s %9.0f\n", nm[k], sum[k] / 64);
             {
                 double a = 0, b = 0, c = 0;
@@ -771,7 +792,7 @@ private:
                 T* w = nullptr;
                 if (dev_upload(&w, img) || dev_upload(&L.bias, b)) return -1;
                 L.w = w;
-                if (sizeof(T) == 2 && L.k == 3 && wino_enabled() && wino_kernel_for(L.cin_s / 32)) {
+                if (sizeof(T) == 2 && L.k == 3 && wino_enabled() && wino_kernel_for(L.cin_s / 32).fn) {
                     L.wino_ko_pad = round_up(L.cout_s, WinoCfg::KO_T);
                     if ((int)b.size() < L.wino_ko_pad) return fail("winograd: bias image shorter than the channel tiles");
                     const std::vector<f16> wimg = wino_image(L.hw.data(), L.cin, L.cout, L.cin_s, L.wino_ko_pad);
@@ -993,9 +1014,9 @@ private:
             const double flops = 2.0 * px * L.cin * L.cout * 9;  // algorithmic (direct-form) count
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 16);
             const int grid = round_up(wino_geom_.blocks, 8) * (L.wino_ko_pad / WinoCfg::KO_T);
-            const WinoFn fn = wino_kernel_for(L.cin_s / 32, wino_geom_.max_pos);
+            const WinoLaunch wl = wino_kernel_for(L.cin_s / 32, wino_geom_.max_pos, wino_eight_);
             return timed(name, flops, bytes, [&] {
-                hipLaunchKernelGGL(fn, dim3(grid), dim3(WinoCfg::NT), WinoCfg::lds_bytes(), stream_, wp);
+                hipLaunchKernelGGL(wl.fn, dim3(grid), dim3(wl.threads), wl.lds, stream_, wp);
             });
         }
         if (const GldsChoice* gc = choose_glds(L)) {
@@ -1245,6 +1266,7 @@ private:
     std::map<int, GldsChoice> glds_cache_;
     WinoGeom wino_geom_;
     bool wino_geom_valid_ = false;
+    const bool wino_eight_ = wino_eight();
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;
     // light per-launch timing of one kernel class inside time_runs()
@@ -1472,7 +1494,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         int g_ntiles = 0;
         const GldsEntry* ge = nullptr;
         bool wino_done = false;
-        if (sizeof(T) == 2 && k == 3 && wino_enabled() && wino_kernel_for(cin_s / 32)) {
+        if (sizeof(T) == 2 && k == 3 && wino_enabled() && wino_kernel_for(cin_s / 32).fn) {
             const WinoGeom wg = wino_geom(hg);
             if (wg.fits) {
                 enable_big_lds_wino();
@@ -1499,8 +1521,8 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
                 p.in = dx; p.w = dwi; p.bias = dwb; p.res = dres; p.out = dy; p.g = g;
                 p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = wko; p.taps = 9; p.act = act; p.npos = 0;
                 p.num_pix_tiles = wg.blocks;
-                hipLaunchKernelGGL(wino_kernel_for(cin_s / 32, wg.max_pos), dim3(round_up(wg.blocks, 8) * (wko / WinoCfg::KO_T)),
-                                   dim3(WinoCfg::NT), WinoCfg::lds_bytes(), 0, wp);
+                const WinoLaunch wl = wino_kernel_for(cin_s / 32, wg.max_pos, wino_eight());
+                hipLaunchKernelGGL(wl.fn, dim3(round_up(wg.blocks, 8) * (wko / WinoCfg::KO_T)), dim3(wl.threads), wl.lds, 0, wp);
                 HIP_OK(hipGetLastError());
                 HIP_OK(hipDeviceSynchronize());
                 wino_done = true;

@@ -175,11 +175,12 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", ["wino", "wino8"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[f"{c[1]}x{c[2]}n{len(c[0])}b{min(c[0])}" for c in WINO_CASES])
-def test_conv_winograd_fused(case, monkeypatch):
-    """SAYURI_CONV=wino: the fused Winograd F(2x2,3x3) kernel (csrc/hip/conv_wino.h) against the same float64
-    direct-convolution reference and tolerance as the implicit-GEMM kernels."""
-    monkeypatch.setenv("SAYURI_CONV", "wino")
+def test_conv_winograd_fused(case, variant, monkeypatch):
+    """SAYURI_CONV=wino | wino8: the fused Winograd F(2x2,3x3) kernels (csrc/hip/conv_wino.h, four / eight waves)
+    against the same float64 direct-convolution reference and tolerance as the implicit-GEMM kernels."""
+    monkeypatch.setenv("SAYURI_CONV", variant)
     bsz, cin, cout = case
     run_case(True, bsz, cin, cout, 3, act=5, with_res=True, seed=cin + cout)
     run_case(True, bsz, cin, cout, 3, act=0, with_res=False, seed=cin + cout + 1)

@@ -57,9 +57,10 @@ def test_golden_parity(name, fp16, tmp_weights_dir):
         pipe.Destroy()
 
 
-def test_20b256_winograd_path(tmp_weights_dir, monkeypatch):
-    """The same network through the opt-in fused Winograd convolution (SAYURI_CONV=wino, conv_wino.h)."""
-    monkeypatch.setenv("SAYURI_CONV", "wino")
+@pytest.mark.parametrize("variant", ["wino", "wino8"])
+def test_20b256_winograd_path(variant, tmp_weights_dir, monkeypatch):
+    """The same network through the opt-in fused Winograd convolutions (SAYURI_CONV=wino | wino8, conv_wino.h)."""
+    monkeypatch.setenv("SAYURI_CONV", variant)
     g = Golden("net_20b256", tmp_weights_dir)
     cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
     pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=True)
