@@ -416,6 +416,82 @@ __global__ __launch_bounds__(128 * WAVN_) void conv_glds_kernel(const GldsParams
         return;
     }
 
+    if constexpr (ABL & 512) {
+        // ---- epilogue, register form: bias, residual and activation are applied to the accumulators where they are
+        // (the residual is fetched in accumulator layout, 8 bytes per lane), the fp16 result goes through LDS ONCE
+        // ([pixel][channel], half the bytes of the fp32 staging, one phase instead of two) and leaves as whole rows.
+        // Same arithmetic order as the staged form below (acc + bias, + residual, activation): bit-identical results.
+        constexpr int RS16 = KO_T * 2 + 16;
+        static_assert(PT * RS16 <= Cfg::RING_BYTES, "the fp16 staging tile re-uses the DMA rings");
+        unsigned char* st16 = smem;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // rowid visible, rings no longer read
+        const f16* __restrict__ gres = (const f16*)p.res;
+        int grow[WNT];
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) grow[j] = rowid[(wave_n * WNT + j) * 16 + (lane & 15)];
+        const int kol0 = wave_m * WMT * 16 + 4 * (lane >> 4);  // channel inside the tile of row tile i = kol0 + 16 i
+        auto fetch_res = [&](int i, f16x4 (&rr)[WNT]) {
+            const int ko = kt * KO_T + kol0 + i * 16;
+            const bool ok = ko < p.cout_s;  // cout_s is a multiple of 32: 4-channel groups never straddle it
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+                rr[j] = (ok && grow[j] >= 0) ? *(const f16x4*)(gres + (size_t)grow[j] * p.cout_s + ko) : f16x4{0, 0, 0, 0};
+        };
+        auto body = [&](auto actc) {
+            constexpr int ACT = decltype(actc)::value;
+            f16x4 rcur[WNT], rnext[WNT];
+            if (gres) fetch_res(0, rcur);
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) {
+                if (gres && i + 1 < WMT) fetch_res(i + 1, rnext);
+                const f32x4 bias = *(const f32x4*)(p.bias + kt * KO_T + kol0 + i * 16);
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) {
+                    f32x4 v = acc[i][j] + bias;
+                    if (gres) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += (float)rcur[j][q];
+                    }
+                    f16x4 h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = (f16)activate(v[q], ACT);
+                    const int rl = (wave_n * WNT + j) * 16 + (lane & 15);
+                    *(f16x4*)(st16 + rl * RS16 + (kol0 + i * 16) * 2) = h;
+                }
+                if (gres && i + 1 < WMT) {
+#pragma unroll
+                    for (int j = 0; j < WNT; ++j) rcur[j] = rnext[j];
+                }
+            }
+        };
+        switch (p.act) {
+        case kMish: body(std::integral_constant<int, kMish>{}); break;
+        case kIdentity: body(std::integral_constant<int, kIdentity>{}); break;
+        case kReLU: body(std::integral_constant<int, kReLU>{}); break;
+        case kSwish: body(std::integral_constant<int, kSwish>{}); break;
+        case kELU: body(std::integral_constant<int, kELU>{}); break;
+        case kSELU: body(std::integral_constant<int, kSELU>{}); break;
+        case kGELU: body(std::integral_constant<int, kGELU>{}); break;
+        default: body(std::integral_constant<int, kHardSwish>{}); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // whole rows out: LPR lanes x 16 bytes per row
+        constexpr int LPR = KO_T / 8, RPI = 64 / LPR;
+        f16* __restrict__ gout = (f16*)p.out;
+        const int col = (lane % LPR) * 8, ko = kt * KO_T + col;
+        if (ko < p.cout_s) {
+#pragma unroll
+            for (int r0 = 0; r0 < PT; r0 += NWAVE * RPI) {
+                const int r = r0 + wave * RPI + lane / LPR;
+                const int g = rowid[r];
+                if (g >= 0) *(f16x8*)(gout + (size_t)g * p.cout_s + ko) = *(const f16x8*)(st16 + r * RS16 + col * 2);
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: fp32 accumulators (+ bias) -> LDS [pixel][channel], two phases of PT/2
     // pixels (wave columns 0-1, then 2-3), then whole rows: + residual, activation, fp16 store.
     // Barriers here are raw s_barrier + lgkmcnt(0): a __syncthreads() would also drain vmcnt,

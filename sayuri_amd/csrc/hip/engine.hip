@@ -100,6 +100,13 @@ static void register_all_glds() {
     register_glds<8, 3>(); register_glds<8, 2>(); register_glds<8, 1>();
     register_glds<4, 3>(); register_glds<4, 2>(); register_glds<4, 1>();
     register_glds<8, 6, 2>();  // four-wave variant of the <8,3> tile (same 256 x 192 workgroup tile and tile tables)
+    if (const char* epi = getenv("SAYURI_EPI")) {  // A/B switch: 2 = register-form epilogue (conv_glds.h, ABL bit 512)
+        if (atoi(epi) == 2) {
+            auto& e = glds_entries();
+            e[0].fn = &conv_glds_kernel<8, 3, 512, 4>; e[1].fn = &conv_glds_kernel<8, 2, 512, 4>; e[2].fn = &conv_glds_kernel<8, 1, 512, 4>;
+            e[3].fn = &conv_glds_kernel<4, 3, 512, 4>; e[4].fn = &conv_glds_kernel<4, 2, 512, 4>; e[5].fn = &conv_glds_kernel<4, 1, 512, 4>;
+        }
+    }
     if (const char* abl = getenv("SAYURI_ABL")) {  // timing-only ablations of the <8,3> kernel
         GldsEntry& e = glds_entries()[0];
         switch (atoi(abl)) {
