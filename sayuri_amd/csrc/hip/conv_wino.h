@@ -676,23 +676,33 @@ __global__ __launch_bounds__(512) void conv_wino8_kernel(const WinoParams wp) {
         ds_read16<SO>(R[5], cell[n][1][2]);
     };
 
+    unsigned long long w_dma = 0, w_bar = 0, w_issue = 0, w_a = 0, w_patch = 0;
     issue_raw(0, 0);
     load_a(0, std::integral_constant<int, 0>{});
     static_for<nchunks>([&](auto cc) {
         constexpr int c = decltype(cc)::value, S = c & 1;
         if constexpr (c == 0) { if (dbg && wave < 4) dbg[1] = __builtin_amdgcn_s_memtime(); }
+        unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+        if (dbg) tq0 = __builtin_amdgcn_s_memtime();
         wait_vmcnt<8>();               // raw(c) landed; the weights of chunk c were issued after it
+        if (dbg) tq1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();  // every wave's pieces are in LDS; every wave is done with the other ring slot
+        if (dbg) tq2 = __builtin_amdgcn_s_memtime();
         if constexpr (c < 8) { if (dbg && wave < 4) dbg[2 + c] = __builtin_amdgcn_s_memtime(); }
         if constexpr (c + 1 < nchunks) {
             issue_raw(c + 1, S ^ 1);
             load_a(c + 1, std::integral_constant<int, S ^ 1>{});
         }
+        if (dbg) tq3 = __builtin_amdgcn_s_memtime();
         wait_a<(c + 1 < nchunks ? DI + 8 : 0)>(A[S]);
+        if (dbg) { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); w_dma += tq1 - tq0; w_bar += tq2 - tq1; w_issue += tq3 - tq2; w_a += t4 - tq3; }
         read_patch(std::integral_constant<int, S>{}, 0);
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
+            unsigned long long tp = 0;
+            if (dbg) tp = __builtin_amdgcn_s_memtime();
             wait_patch<0>(R);
+            if (dbg) w_patch += __builtin_amdgcn_s_memtime() - tp;
             // t[j] = d[ia][j] + sgn * d[ib][j] for this pair's three columns; Vx = ta - tc, Vy = tb + sy * tc
             const f16x8 ta = R[0] + sgn8 * R[3], tb = R[1] + sgn8 * R[4], tc = R[2] + sgn8 * R[5];
             f16x8 V[2];
@@ -713,7 +723,7 @@ __global__ __launch_bounds__(512) void conv_wino8_kernel(const WinoParams wp) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
-    if (dbg && wave < 4) dbg[10] = __builtin_amdgcn_s_memtime();
+    if (dbg && wave < 4) { dbg[10] = __builtin_amdgcn_s_memtime(); dbg[9] = w_dma; dbg[13] = w_bar; dbg[14] = w_issue; dbg[15] = w_a; dbg[8] = w_patch; }
     unsigned char* stage = smem;
     constexpr int RS = Cfg::Z_RS;
     const int cgo = tid & 7, koo = kt * Cfg::KO_T + cgo * 8;
@@ -750,7 +760,7 @@ __global__ __launch_bounds__(512) void conv_wino8_kernel(const WinoParams wp) {
             }
         }
     }
-    if (dbg && wave < 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[12] = __builtin_amdgcn_s_memtime(); dbg[9] = dbg[0]; dbg[13] = dbg[14] = dbg[15] = dbg[5]; }
+    if (dbg && wave < 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[12] = __builtin_amdgcn_s_memtime(); }
 }
 
 }  // namespace sayuri

@@ -627,6 +627,15 @@ public:
                 }
                 fprintf(stderr, "  chunk3->4: compute %.0f, vmcnt wait %.0f, barrier %.0f\n", a / 64, b / 64, c / 64);
             }
+            if (wino_eight_) {  // wino8: slots 9, 13, 14, 15, 8 hold per-wave sums of wait cycles
+                double w[5] = {};
+                for (int wg = 0; wg < 64; ++wg) {
+                    const unsigned long long* d = &h[(size_t)wg * 4 * 16];
+                    w[0] += (double)d[9]; w[1] += (double)d[13]; w[2] += (double)d[14]; w[3] += (double)d[15]; w[4] += (double)d[8];
+                }
+                fprintf(stderr, "  wino8 K-loop sums per wave: DMA wait %.0f, barrier %.0f, issue next loads %.0f, weight wait %.0f, patch waits %.0f\n",
+                        w[0] / 64, w[1] / 64, w[2] / 64, w[3] / 64, w[4] / 64);
+            }
             const unsigned long long* d0 = &h[0];
             fprintf(stderr, "  wg0 waves end: %llu %llu %llu %llu\n", d0[12] - d0[0], d0[16 + 12] - d0[0], d0[32 + 12] - d0[0], d0[48 + 12] - d0[0]);
         }
