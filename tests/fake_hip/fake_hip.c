@@ -1,0 +1,158 @@
+/* fake_hip.c -- TEST INFRASTRUCTURE: a CPU stand-in for the device side of include/sayuri_hip.h, so that the host
+ * side of the hot path (HipForwardPipe: staging, leaf-batch collector, ring pump, hand-out of results;
+ * reference src/neural/batch_forward_pipe.cc:7-193) can be exercised -- and run under ThreadSanitizer -- on a box
+ * without a GPU.  Loaded with RTLD_GLOBAL ahead of libsayuri_hip.so by tests/test_collector_cpu.py; never part of
+ * the product.
+ *
+ * The "network" is a fixed, cheap function of each sample's own planes (fake_eval below), so a test can tell for
+ * every reply whether it belongs to the request that asked for it.  submit() is asynchronous like the real one:
+ * a worker thread per context finishes a batch FAKE_HIP_DELAY_US microseconds after it was enqueued, two tickets
+ * may be in flight. */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../../include/sayuri_hip.h"
+
+struct job {
+    int n, state; /* 0 free, 1 queued, 2 done */
+    const float* planes;
+    const int* bsz;
+    float *prob, *pass, *misc, *own;
+    struct timespec due;
+};
+struct sayuri_hip_ctx {
+    sayuri_hip_netdesc desc;
+    int board, max_batch, next, stop;
+    long delay_us;
+    struct job jobs[2];
+    int order[2], n_order; /* FIFO of queued tickets */
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_done;
+    pthread_t worker;
+    long submits, evals;
+};
+
+static void fake_eval(const sayuri_hip_ctx* c, int n, const float* planes, const int* bsz, float* prob, float* pass,
+                      float* misc, float* own) {
+    const int B2 = c->board * c->board, C = c->desc.input_channels;
+    const int PC = c->desc.probabilities_channels, PP = c->desc.pass_probability_outputs, VM = c->desc.value_misc_outputs;
+    for (int i = 0; i < n; ++i) {
+        const float* x = planes + (size_t)i * C * B2;
+        double s = 0;
+        for (int k = 0; k < C * B2; ++k) s += x[k] * (double)(1 + k % 7);
+        const int bs = bsz ? bsz[i] : c->board;
+        for (int k = 0; k < PC; ++k)
+            for (int p = 0; p < B2; ++p) prob[((size_t)i * PC + k) * B2 + p] = x[(size_t)k * B2 + p] + 0.5f * x[(size_t)5 * B2 + p] + (float)k;
+        for (int k = 0; k < PP; ++k) pass[(size_t)i * PP + k] = (float)(s * 0.001) + (float)k;
+        for (int k = 0; k < VM; ++k) misc[(size_t)i * VM + k] = (float)(s * 0.002) - (float)k + (float)bs;
+        for (int p = 0; p < B2; ++p) own[(size_t)i * B2 + p] = x[(size_t)7 * B2 + p] - x[(size_t)8 * B2 + p];
+    }
+}
+
+static void* worker_main(void* arg) {
+    sayuri_hip_ctx* c = (sayuri_hip_ctx*)arg;
+    pthread_mutex_lock(&c->mu);
+    for (;;) {
+        while (!c->stop && c->n_order == 0) pthread_cond_wait(&c->cv_work, &c->mu);
+        if (c->stop && c->n_order == 0) break;
+        const int t = c->order[0];
+        struct job* j = &c->jobs[t];
+        const struct timespec due = j->due;
+        pthread_mutex_unlock(&c->mu);
+        clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &due, NULL);
+        fake_eval(c, j->n, j->planes, j->bsz, j->prob, j->pass, j->misc, j->own);
+        pthread_mutex_lock(&c->mu);
+        j->state = 2;
+        c->order[0] = c->order[1];
+        --c->n_order;
+        pthread_cond_broadcast(&c->cv_done);
+    }
+    pthread_mutex_unlock(&c->mu);
+    return NULL;
+}
+
+int sayuri_hip_device_count(void) {
+    const char* e = getenv("FAKE_HIP_DEVICES");
+    return e ? atoi(e) : 1;
+}
+const char* sayuri_hip_last_error(void) { return "fake_hip: no error text"; }
+
+sayuri_hip_ctx* sayuri_hip_create(int device, const sayuri_hip_netdesc* desc, int max_batch, int board, int use_fp16) {
+    (void)device; (void)use_fp16;
+    sayuri_hip_ctx* c = (sayuri_hip_ctx*)calloc(1, sizeof(*c));
+    c->desc = *desc;
+    c->desc.blocks = NULL;
+    c->board = board;
+    c->max_batch = max_batch;
+    const char* d = getenv("FAKE_HIP_DELAY_US");
+    c->delay_us = d ? atol(d) : 200;
+    pthread_mutex_init(&c->mu, NULL);
+    pthread_cond_init(&c->cv_work, NULL);
+    pthread_cond_init(&c->cv_done, NULL);
+    pthread_create(&c->worker, NULL, worker_main, c);
+    return c;
+}
+void sayuri_hip_destroy(sayuri_hip_ctx* c) {
+    if (!c) return;
+    pthread_mutex_lock(&c->mu);
+    c->stop = 1;
+    pthread_cond_broadcast(&c->cv_work);
+    pthread_mutex_unlock(&c->mu);
+    pthread_join(c->worker, NULL);
+    free(c);
+}
+int sayuri_hip_load_tensor(sayuri_hip_ctx* c, int layer_id, int kind, const float* host, size_t n) {
+    (void)c; (void)layer_id; (void)kind;
+    return host && n > 0 ? 0 : -1;
+}
+void* sayuri_hip_host_alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
+void sayuri_hip_host_free(void* p) { free(p); }
+
+int sayuri_hip_forward(sayuri_hip_ctx* c, int n, const float* planes, const int* bsz, float* prob, float* pass,
+                       float* misc, float* own) {
+    if (!c || n <= 0 || n > c->max_batch) return -1;
+    fake_eval(c, n, planes, bsz, prob, pass, misc, own);
+    return 0;
+}
+int sayuri_hip_submit(sayuri_hip_ctx* c, int n, const float* planes, const int* bsz, float* prob, float* pass,
+                      float* misc, float* own, int* ticket) {
+    if (!c || n <= 0 || n > c->max_batch) return -1;
+    pthread_mutex_lock(&c->mu);
+    const int t = c->next;
+    struct job* j = &c->jobs[t];
+    if (j->state != 0) { pthread_mutex_unlock(&c->mu); return -1; } /* more than two batches in flight */
+    c->next ^= 1;
+    j->n = n; j->planes = planes; j->bsz = bsz; j->prob = prob; j->pass = pass; j->misc = misc; j->own = own;
+    clock_gettime(CLOCK_MONOTONIC, &j->due);
+    j->due.tv_nsec += (c->delay_us % 1000000) * 1000;
+    j->due.tv_sec += c->delay_us / 1000000 + j->due.tv_nsec / 1000000000;
+    j->due.tv_nsec %= 1000000000;
+    j->state = 1;
+    c->order[c->n_order++] = t;
+    ++c->submits;
+    c->evals += n;
+    *ticket = t;
+    pthread_cond_signal(&c->cv_work);
+    pthread_mutex_unlock(&c->mu);
+    return 0;
+}
+int sayuri_hip_wait(sayuri_hip_ctx* c, int t) {
+    if (!c || t < 0 || t > 1) return -1;
+    pthread_mutex_lock(&c->mu);
+    if (c->jobs[t].state == 0) { pthread_mutex_unlock(&c->mu); return -1; }
+    while (c->jobs[t].state != 2) pthread_cond_wait(&c->cv_done, &c->mu);
+    c->jobs[t].state = 0;
+    pthread_mutex_unlock(&c->mu);
+    return 0;
+}
+int sayuri_hip_query(sayuri_hip_ctx* c, int t) {
+    if (!c || t < 0 || t > 1) return -1;
+    pthread_mutex_lock(&c->mu);
+    const int s = c->jobs[t].state;
+    pthread_mutex_unlock(&c->mu);
+    return s == 0 ? -1 : s == 2;
+}
+size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* c) { (void)c; return 0; }

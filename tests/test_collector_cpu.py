@@ -1,0 +1,111 @@
+"""The host side of the hot path -- staging, leaf-batch collector, ring pump, hand-out of results
+(sayuri_amd/csrc/host/hip_forward_pipe.cc; reference src/neural/batch_forward_pipe.cc:7-193) -- on a box without a
+GPU: tests/fake_hip/fake_hip.c stands in for the device side of include/sayuri_hip.h (loaded RTLD_GLOBAL ahead of the
+real library, so the host library's calls resolve to it).  Its "network" is a cheap fixed function of each sample's own
+planes, so every reply can be checked against the request that asked for it: what is tested is that hundreds of
+concurrent blocking callers, ragged board sizes, partial batches, ring rotation and the wake tree never mix requests up.
+
+Runs in a subprocess: symbol interposition needs a process that has not loaded the real device library yet."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from _golden import Golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE_SRC = os.path.join(ROOT, "tests", "fake_hip", "fake_hip.c")
+
+DRIVER = textwrap.dedent(r"""
+    import ctypes, sys, threading
+    import numpy as np
+    ctypes.CDLL(sys.argv[1], mode=ctypes.RTLD_GLOBAL)      # the fake device side wins symbol resolution
+    from sayuri_amd.pipe import HipForwardPipe
+
+    B, C = 19, 43
+    def expected(planes, bs, off):
+        grid = np.zeros((C, B, B), np.float32)
+        grid[:, :bs, :bs] = planes.reshape(C, bs, bs)
+        x = grid.reshape(C, B * B).astype(np.float64)
+        w = 1 + (np.arange(C * B * B) % 7)
+        s = float((x.ravel() * w).sum())
+        prob = (x[off] + 0.5 * x[5] + off).reshape(B, B)[:bs, :bs].ravel()
+        own = (x[7] - x[8]).reshape(B, B)[:bs, :bs].ravel()
+        misc = np.float32(s * 0.002) - np.arange(15, dtype=np.float32) + np.float32(bs)
+        tail = [np.float32(s * 0.001) + off, misc[0], misc[1], misc[2], misc[3], misc[8], misc[13], misc[14], off]
+        return np.concatenate([prob, own, np.asarray(tail, np.float64)])
+
+    def check(outs, cases, label):
+        for (p, bs, off), got in zip(cases, outs):
+            exp = expected(p, bs, off)
+            assert got.shape == exp.shape, (label, got.shape, exp.shape)
+            err = np.abs(got - exp).max()
+            assert err <= 1e-3 * max(1.0, np.abs(exp).max()), (label, bs, off, err)
+
+    rng = np.random.default_rng(int(sys.argv[3]))
+    def make(n):
+        cases = []
+        for _ in range(n):
+            bs = int(rng.choice([19, 19, 13, 9, 7]))
+            cases.append((rng.integers(0, 4, size=(C, bs * bs)).astype(np.float32), bs, int(rng.integers(0, 5))))
+        return cases
+
+    pipe = HipForwardPipe(sys.argv[2], board_size=19, batch_size=16, fp16=True)
+    assert pipe.GetNumWorkers() == 1
+    total = 0
+    for rnd in range(int(sys.argv[4])):
+        n = int(rng.choice([1, 2, 15, 16, 17, 33, 100, 250]))
+        cases = make(n)
+        planes, bsz, offs = [c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases]
+        check(pipe.Forward(planes, bsz, offsets=offs), cases, f"queue round {rnd} n={n}")   # n blocked callers
+        if n <= 16:
+            check(pipe.BatchForward(planes, bsz, offsets=offs), cases, f"batch round {rnd}")
+        total += n
+    # two Python threads driving the queue at once (each call spawns its own callers), plus the async Submit path
+    errs = []
+    def worker(seed):
+        try:
+            r = np.random.default_rng(seed)
+            for _ in range(6):
+                cs = [(r.integers(0, 4, size=(C, 361)).astype(np.float32), 19, int(r.integers(0, 5))) for _ in range(40)]
+                check(pipe.Forward([c[0] for c in cs], [19] * 40, offsets=[c[2] for c in cs]), cs, f"thread {seed}")
+        except Exception as e:       # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=worker, args=(s,)) for s in (1, 2, 3)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errs, errs
+    eps, tot = pipe.netbench(64, 0.5)
+    assert tot > 0
+    pt = pipe.pump_times()
+    assert pt["evals"] >= total + 3 * 6 * 40 + tot, pt
+    assert pt["batches"] > 0 and pt["evals"] / pt["batches"] <= 16
+    # smaller NN board: Construct() while idle, then the same checks on 13x13
+    pipe.Construct(13, 8)
+    B = 13
+    cs = [(rng.integers(0, 4, size=(C, bs * bs)).astype(np.float32), bs, 0) for bs in (13, 9, 13, 5, 13, 13, 9, 13, 13)]
+    check(pipe.Forward([c[0] for c in cs], [c[1] for c in cs], offsets=[0] * len(cs)), cs, "13x13")
+    pipe.Destroy()
+    print("collector ok", total, pt["batches"], pt["partial_batches"])
+""")
+
+
+@pytest.fixture(scope="module")
+def fake_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("fake_hip") / "libfake_hip.so")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", FAKE_SRC, "-o", out, "-lpthread"])
+    return out
+
+
+@pytest.mark.parametrize("delay_us,seed", [(0, 1), (200, 2), (3000, 3)])
+def test_collector_keeps_requests_apart(fake_lib, tmp_weights_dir, delay_us, seed):
+    """delay 0: batches finish before the next one is full (mostly partial batches); 200 us: steady state;
+    3 ms: the ring fills up and callers park on the epoch futex."""
+    weights = Golden("tiny_res", tmp_weights_dir).weights_path
+    env = dict(os.environ, FAKE_HIP_DELAY_US=str(delay_us), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    rounds = "10" if delay_us < 3000 else "5"
+    r = subprocess.run([sys.executable, "-c", DRIVER, fake_lib, weights, str(seed), rounds], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "collector ok" in r.stdout
