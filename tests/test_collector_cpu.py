@@ -109,3 +109,37 @@ def test_collector_keeps_requests_apart(fake_lib, tmp_weights_dir, delay_us, see
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "collector ok" in r.stdout
+
+
+SELFPLAY_DRIVER = textwrap.dedent(r"""
+    import ctypes, glob, gzip, sys
+    ctypes.CDLL(sys.argv[1], mode=ctypes.RTLD_GLOBAL)
+    from sayuri_amd.pipe import HipForwardPipe
+    from sayuri_amd import search as S
+    pipe = HipForwardPipe(sys.argv[2], board_size=9, batch_size=16, fp16=True, waittime_ms=2)
+    opts = dict(playouts=24, parallel_games=40, num_games=40, seed=5, dirichlet_noise=1, random_moves_factor=0.1,
+                selfplay_query=["bkp:9:7:0.7", "bkp:7:9:0.3"], target_directory=sys.argv[3])
+    st = S.selfplay(pipe, opts, move_cap=24, name_suffix="-cpu")
+    pt = pipe.pump_times()
+    assert st["games_done"] == 40 and st["chunks_saved"] == 40, st
+    assert st["nn_queries"] == pt["evals"] > 2000, (st, pt)
+    assert pt["evals"] / pt["batches"] > 4, "games are not being batched together"
+    chunks = glob.glob(sys.argv[3] + "/tdata/*-cpu/*.gz")
+    assert len(chunks) == 40
+    lines = gzip.open(chunks[0]).read().decode().split("\n")
+    assert (len(lines) - 1) % 53 == 0
+    pipe.Destroy()
+    print("selfplay ok", st["moves"], pt["batches"])
+""")
+
+
+def test_selfplay_through_the_collector_without_a_gpu(fake_lib, tmp_weights_dir, tmp_path):
+    """The whole host-side path of a self-play run -- game threads, search, encoder, NN cache, collector, training-data
+    writer -- on the fake device: 40 games of 9x9 / 7x7 finish, every NN query went through the pump, the chunks have the
+    53-line record format."""
+    weights = Golden("tiny_res", tmp_weights_dir).weights_path
+    env = dict(os.environ, FAKE_HIP_DELAY_US="300", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", SELFPLAY_DRIVER, fake_lib, weights, str(tmp_path)], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "selfplay ok" in r.stdout
