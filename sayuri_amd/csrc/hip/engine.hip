@@ -1227,7 +1227,7 @@ private:
         const T* pc = bufs_[pb];
         const T* vc = bufs_[vb];
         return timed("head_tail", 0, 0, [&] {
-            hipLaunchKernelGGL(head_tail_kernel<T>, dim3(geom_.n), dim3(256), smem, stream_, pc, vc, g, h);
+            hipLaunchKernelGGL(head_tail_kernel<T>, dim3(2 * geom_.n), dim3(256), smem, stream_, pc, vc, g, h);
         });
     }
 

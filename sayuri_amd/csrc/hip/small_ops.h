@@ -341,40 +341,48 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const T* __restrict__ pc
     float* inter = pool + 3 * maxc;      // [3*maxc]
     float* pinter = inter + 3 * maxc;    // [Cp] policy intermediate (kept for the per-pixel pass)
     float* scratch = pinter + maxc;      // [2*256]
-    const int n = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    // two workgroups per sample: the policy half and the value half share nothing, and each is a chain of dependent
+    // small steps (pool -> FC -> FC -> per-pixel pass) that one workgroup can only run one after the other
+    const int n = blockIdx.x >> 1, role = blockIdx.x & 1, tid = threadIdx.x, nt = blockDim.x;
     const int bs = g.bsz[n], npix = bs * bs, B2 = h.board * h.board;
     const T* pc = pconv + (size_t)n * g.slot_pix * h.cs_p;
     const T* vc = vconv + (size_t)n * g.slot_pix * h.cs_v;
 
-    // policy: pooling -> intermediate FC (act) -> pass FC
-    block_pool<T>(pc, npix, h.Cp, h.cs_p, bs, false, pool, scratch, tid, nt);
-    block_fc(h.p_inter, pool, pinter, h.act, tid, nt);
-    __syncthreads();
-    block_fc(h.pass_fc, pinter, h.pass + (size_t)n * h.pass_fc.out, kIdentity, tid, nt);
-
-    // value: pooling -> intermediate FC (act) -> misc FC
-    block_pool<T>(vc, npix, h.Cv, h.cs_v, bs, true, pool, scratch, tid, nt);
-    block_fc(h.v_inter, pool, inter, h.act, tid, nt);
-    __syncthreads();
-    block_fc(h.v_misc, inter, h.misc + (size_t)n * h.v_misc.out, kIdentity, tid, nt);
+    if (role == 0) {
+        // policy: pooling -> intermediate FC (act) -> pass FC
+        block_pool<T>(pc, npix, h.Cp, h.cs_p, bs, false, pool, scratch, tid, nt);
+        block_fc(h.p_inter, pool, pinter, h.act, tid, nt);
+        __syncthreads();
+        block_fc(h.pass_fc, pinter, h.pass + (size_t)n * h.pass_fc.out, kIdentity, tid, nt);
+    } else {
+        // value: pooling -> intermediate FC (act) -> misc FC
+        block_pool<T>(vc, npix, h.Cv, h.cs_v, bs, true, pool, scratch, tid, nt);
+        block_fc(h.v_inter, pool, inter, h.act, tid, nt);
+        __syncthreads();
+        block_fc(h.v_misc, inter, h.misc + (size_t)n * h.v_misc.out, kIdentity, tid, nt);
+    }
 
     // per-pixel outputs in the NN grid (off-board cells of a smaller sample = 0)
     for (int cell = tid; cell < B2; cell += nt) {
         const int y = cell / h.board, x = cell - y * h.board;
         const bool on = y < bs && x < bs;
         const int pp = y * bs + x;
-        float pr[8];
-        for (int k = 0; k < h.prob_ch; ++k) pr[k] = on ? h.prob_b[k] : 0.f;
-        float ow = on ? h.own_b[0] : 0.f;
-        if (on) {
-            for (int c = 0; c < h.Cp; ++c) {
-                const float v = to_float(pc[(size_t)pp * h.cs_p + c]) + pinter[c];
-                for (int k = 0; k < h.prob_ch; ++k) pr[k] += v * h.prob_w[k * h.Cp + c];
+        if (role == 0) {
+            float pr[8];
+            for (int k = 0; k < h.prob_ch; ++k) pr[k] = on ? h.prob_b[k] : 0.f;
+            if (on) {
+                for (int c = 0; c < h.Cp; ++c) {
+                    const float v = to_float(pc[(size_t)pp * h.cs_p + c]) + pinter[c];
+                    for (int k = 0; k < h.prob_ch; ++k) pr[k] += v * h.prob_w[k * h.Cp + c];
+                }
             }
-            for (int c = 0; c < h.Cv; ++c) ow += to_float(vc[(size_t)pp * h.cs_v + c]) * h.own_w[c];
+            for (int k = 0; k < h.prob_ch; ++k) h.prob[((size_t)n * h.prob_ch + k) * B2 + cell] = pr[k];
+        } else {
+            float ow = on ? h.own_b[0] : 0.f;
+            if (on)
+                for (int c = 0; c < h.Cv; ++c) ow += to_float(vc[(size_t)pp * h.cs_v + c]) * h.own_w[c];
+            h.own[(size_t)n * B2 + cell] = ow;
         }
-        for (int k = 0; k < h.prob_ch; ++k) h.prob[((size_t)n * h.prob_ch + k) * B2 + cell] = pr[k];
-        h.own[(size_t)n * B2 + cell] = ow;
     }
 }
 
