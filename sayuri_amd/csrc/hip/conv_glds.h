@@ -71,7 +71,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 
 // WAVN = wave columns of the workgroup (2 wave rows always): 4 -> eight waves, two per SIMD; 2 -> four waves, one
 // per SIMD, each with a twice as wide register tile (fewer LDS fragment reads per MFMA, 512 registers per lane).
-template <int WMT_, int WNT_, int WAVN_ = 4> struct GldsCfg {
+// SB = 1: the halo tile is single-buffered (the two-workgroups-per-CU variant: 72.5 KiB instead of 97 KiB at <4,3>)
+template <int WMT_, int WNT_, int WAVN_ = 4, int SB_ = 0> struct GldsCfg {
     static constexpr int WMT = WMT_, WNT = WNT_, WAVM = 2, WAVN = WAVN_, NWAVE = WAVM * WAVN;
     static constexpr int KO_T = WAVM * WMT * 16;
     static constexpr int PT = WAVN * WNT * 16;
@@ -87,7 +88,7 @@ template <int WMT_, int WNT_, int WAVN_ = 4> struct GldsCfg {
     static constexpr int B_BYTES = NPOS * 64;
     static constexpr int STAGE_RS = KO_T * 4 + 16;                        // epilogue staging row (fp32 + pad)
     static constexpr int STAGE_BYTES = (PT / 2) * STAGE_RS;
-    static constexpr int RING_BYTES = 2 * A_BYTES + 2 * B_BYTES;
+    static constexpr int RING_BYTES = 2 * A_BYTES + (SB_ ? 1 : 2) * B_BYTES;
     static_assert(A_INSTR % NWAVE == 0, "KO_T must be a multiple of 128");
     static_assert(BI <= 6, "halo DMA is spread over the six DMA slots of a group");
     static_assert(STAGE_BYTES <= RING_BYTES, "the epilogue staging tile re-uses the DMA rings");
@@ -230,9 +231,12 @@ __device__ __forceinline__ void epi_store(const EpiRows<KO_T, PT, NW>& e, const 
 
 // ABL: timing-only ablation mask (never used by the engine proper): 1 = no weight DMA after the
 // first group, 2 = no halo DMA after the first chunk, 8 = no epilogue.
+// ABL & 2048 (a real variant, not an ablation): two workgroups per CU -- 128 registers per lane, the halo tile
+// single-buffered -- so that one workgroup's epilogue and group-start bubbles overlap the other's MFMAs.
 template <int WMT, int WNT, int ABL = 0, int WAVN_ = 4>
-__global__ __launch_bounds__(128 * WAVN_) void conv_glds_kernel(const GldsParams gp) {
-    using Cfg = GldsCfg<WMT, WNT, WAVN_>;
+__global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void conv_glds_kernel(const GldsParams gp) {
+    constexpr bool SB = (ABL & 2048) != 0;
+    using Cfg = GldsCfg<WMT, WNT, WAVN_, SB ? 1 : 0>;
     constexpr int KO_T = Cfg::KO_T, PT = Cfg::PT, WAVN = Cfg::WAVN, NWAVE = Cfg::NWAVE;
     constexpr int AI = Cfg::AI, BI = Cfg::BI, NPOS = Cfg::NPOS;
     const ConvParams& p = gp.c;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(128 * WAVN_) void conv_glds_kernel(const GldsParams
         for (int i = 0; i < AI; ++i) glds16(base + aoff[i], slot + adst[i]);
     };
     auto issue_b1 = [&](int chunk, int i) {
-        unsigned char* slot = Bring + (chunk & 1) * Cfg::B_BYTES;
+        unsigned char* slot = Bring + (SB ? 0 : (chunk & 1)) * Cfg::B_BYTES;
         const unsigned char* s = bsrc[i];
         if (s != (const unsigned char*)gp.zeros) s += (size_t)chunk * kChunk * 2;
         glds16(s, slot + bdst[i]);
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(128 * WAVN_) void conv_glds_kernel(const GldsParams
     }
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more_b = chunk + 1 < nchunks;
-        const unsigned char* Bc = Bring + (chunk & 1) * Cfg::B_BYTES + (size_t)kg * NPOS * 16;
+        const unsigned char* Bc = Bring + (SB ? 0 : (chunk & 1)) * Cfg::B_BYTES + (size_t)kg * NPOS * 16;
 #pragma unroll
         for (int row = 0; row < 3; ++row) {
             const int G = chunk * 3 + row;
@@ -330,6 +334,16 @@ __global__ __launch_bounds__(128 * WAVN_) void conv_glds_kernel(const GldsParams
             if constexpr (!(ABL & 256)) wait_vmcnt<0>();
             if constexpr (ABL & 16) t1 = __builtin_amdgcn_s_memtime();
             if constexpr (!(ABL & 128)) __builtin_amdgcn_s_barrier();
+            if constexpr (SB) {
+                // every wave is done with the previous chunk's halo tile: reload it in place (the other workgroup of
+                // this CU has the matrix cores meanwhile)
+                if (row == 0 && chunk > 0) {
+#pragma unroll
+                    for (int i = 0; i < BI; ++i) issue_b1(chunk, i);
+                    wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
             if constexpr (ABL & 16) t2 = __builtin_amdgcn_s_memtime();
             const bool more_a = G + 1 < ngroups;
             const int dy = row - 1;
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(128 * WAVN_) void conv_glds_kernel(const GldsParams
                     // halo pieces: three or fewer go out at slots 0, 2, 3; more than three one per slot
                     constexpr int bpiece = BI > 3 ? slot : (slot == 0 ? 0 : slot == 2 ? 1 : slot == 3 ? 2 : -1);
                     constexpr int atap = slot < 3 ? slot : -1;
-                    if constexpr (!(ABL & 2) && bpiece >= 0 && bpiece < BI) {
+                    if constexpr (!(ABL & 2) && !SB && bpiece >= 0 && bpiece < BI) {
                         if (row == 0 && more_b) issue_b1(chunk + 1, bpiece);
                     }
                     if constexpr (!(ABL & 1) && atap >= 0) {

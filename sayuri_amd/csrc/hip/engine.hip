@@ -85,6 +85,7 @@ struct GldsEntry {
     size_t lds;
     int npos_cap, npos, pt;
     int threads;  // workgroup size: 512 (two waves per SIMD) or 256 (one wave per SIMD, twice as wide register tiles)
+    bool two_wg = false;  // the two-workgroups-per-CU variant (single-buffered halo, 128 registers)
 };
 static std::vector<GldsEntry>& glds_entries() {
     static std::vector<GldsEntry> e;
@@ -100,6 +101,11 @@ static void register_all_glds() {
     register_glds<8, 3>(); register_glds<8, 2>(); register_glds<8, 1>();
     register_glds<4, 3>(); register_glds<4, 2>(); register_glds<4, 1>();
     register_glds<8, 6, 2>();  // four-wave variant of the <8,3> tile (same 256 x 192 workgroup tile and tile tables)
+    {   // two workgroups per CU: 128 x 192 tiles, 72.5 KiB of LDS and 128 registers each (SAYURI_CONV=glds2x)
+        typedef GldsCfg<4, 3, 4, 1> Cfg;
+        glds_entries().push_back({4, 3, &conv_glds_kernel<4, 3, 2048, 4>, &tile_setup_kernel<Cfg::PT, Cfg::NPOS>, Cfg::lds_bytes(),
+                                  Cfg::NPOS_CAP, Cfg::NPOS, Cfg::PT, Cfg::NT, true});
+    }
     if (const char* epi = getenv("SAYURI_EPI")) {  // A/B switch: 2 = register-form epilogue (conv_glds.h, ABL bit 512)
         if (atoi(epi) == 2) {
             auto& e = glds_entries();
@@ -133,13 +139,14 @@ static void enable_big_lds_glds() {
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
 }
 // SAYURI_CONV=v0 | glds[:wnt]   (tuning / A-B switch; default = glds, auto tile)
-struct ConvOverride { bool v0 = false; int wnt = 0; bool four_wave = false; };
+struct ConvOverride { bool v0 = false; int wnt = 0; bool four_wave = false; bool two_wg = false; };
 static ConvOverride conv_override() {
     ConvOverride o;
     const char* e = getenv("SAYURI_CONV");
     if (!e) return o;
     if (!strncmp(e, "v0", 2)) { o.v0 = true; return o; }
     if (!strncmp(e, "glds4", 5)) { o.four_wave = true; return o; }
+    if (!strncmp(e, "glds2x", 6)) { o.two_wg = true; return o; }
     if (!strncmp(e, "glds", 4)) (void)sscanf(e, "glds:%d", &o.wnt);
     return o;
 }
@@ -207,12 +214,12 @@ static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_
     if (ko_pad % 128 != 0) return nullptr;
     static const ConvOverride ov = conv_override();
     if (ov.v0) return nullptr;
-    const int wmt = ko_pad % 256 == 0 ? 8 : 4;
+    const int wmt = (ko_pad % 256 == 0 && !ov.two_wg) ? 8 : 4;
     const int kot_tiles = ko_pad / (wmt * 32);
     const GldsEntry* best = nullptr;
     double best_cost = 1e30;
     for (const auto& e : glds_entries()) {
-        if (e.wmt != wmt) continue;
+        if (e.wmt != wmt || e.two_wg != ov.two_wg) continue;
         if ((e.threads == 256) != ov.four_wave && !(ov.four_wave && wmt != 8)) continue;
         if (ov.wnt && e.wnt != ov.wnt) continue;
         const int PT = e.pt;
