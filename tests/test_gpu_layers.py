@@ -184,3 +184,19 @@ def test_conv_winograd_fused(case, variant, monkeypatch):
     bsz, cin, cout = case
     run_case(True, bsz, cin, cout, 3, act=5, with_res=True, seed=cin + cout)
     run_case(True, bsz, cin, cout, 3, act=0, with_res=False, seed=cin + cout + 1)
+
+
+@pytest.mark.parametrize("env", [("SAYURI_CONV", "glds2x"), ("SAYURI_CONV", "glds4"), ("SAYURI_CONV", "v0"), ("SAYURI_EPI", "2")],
+                         ids=lambda e: f"{e[0]}={e[1]}")
+def test_conv_kernel_variants(env):
+    """The A/B switches of the implicit-GEMM kernel (two workgroups per CU, four-wave tiles, the generic kernel, the
+    register-form epilogue) are read once per process, so each runs the fp16 layer cases in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **{env[0]: env[1]})
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_layers.py"), "-x", "-q", "-k",
+                        "(test_conv_mfma or test_conv_epilogue_variants or test_conv_batch256) and not fp32"],
+                       env=e, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
