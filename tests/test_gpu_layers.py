@@ -200,3 +200,34 @@ def test_conv_kernel_variants(env):
                         "(test_conv_mfma or test_conv_epilogue_variants or test_conv_batch256) and not fp32"],
                        env=e, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("variant", ["wino", "wino8"])
+def test_conv_winograd_batch256_blocks(variant, monkeypatch):
+    """Full bench geometry (256 x 19x19 = 25 600 Winograd tiles, 534 tile blocks, every block seam and sample crossing):
+    a subset of samples against the float64 reference, and sample independence -- permuting the batch permutes the
+    outputs bit for bit, although every sample then sits in other tile blocks / fragment columns."""
+    monkeypatch.setenv("SAYURI_CONV", variant)
+    rng = np.random.default_rng(17)
+    n, cin, cout = 256, 64, 64
+    x = rng.standard_normal((n, cin, 361)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    bias = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    bs_arr = np.full(n, 19, np.int32)
+    lib = _lib.hip()
+
+    def run(xx):
+        y = np.zeros((n, cout, 361), np.float32)
+        rc = lib.sayuri_hip_test_conv(0, 1, n, bs_arr.ctypes.data_as(_lib.c_int_p), 19, cin, cout, 3, 0, 5, 0,
+                                      _fp(np.ascontiguousarray(xx).ravel()), _fp(w.ravel()), _fp(bias), None, _fp(y.ravel()))
+        assert rc == 0, lib.sayuri_hip_last_error().decode()
+        return y
+
+    y = run(x)
+    w16 = w.astype(np.float16).astype(np.float64)
+    for i in (0, 1, 99, 100, 177, 255):
+        ref = conv_ref([x[i].astype(np.float16).astype(np.float64)], [19], w16, bias.astype(np.float64), None, 3, False, 5,
+                       False)[0]
+        assert np.abs(y[i] - ref).max() <= 4e-3 * np.abs(ref).max()
+    perm = rng.permutation(n)
+    np.testing.assert_array_equal(run(x[perm]), y[perm])
