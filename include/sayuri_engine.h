@@ -89,6 +89,16 @@ long sayuri_engine_search_gather(void* search, char* text, long cap); /* the gam
  * stats[10]: games_started, games_done, moves, playouts, nn_queries, cache_lookups, cache_hits, records, chunks, 0 */
 int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
                         int move_cap, uint64_t* stats, double* elapsed);
+/* The same with the periodic exchange hook of the games-parallel multi-GPU path: every interval_seconds the thread
+ * that called this function hands on_stats a snapshot (the same 10 counters, seconds since start) and this process's
+ * own halt wish -- 1 once the newest file in the option weights_dir is no longer weights_file (reference
+ * Engine::ShouldHalt, src/selfplay/engine.cc:88-90).  A non-zero return makes the loop wind down as the reference
+ * does (src/selfplay/pipe.cc:246-258: max games = games in flight + 25, rounded up to 25).  stats[9] returns the
+ * final max-games value.  The driver all-gathers the records inside the hook (sayuri_amd/shard.py). */
+typedef int (*sayuri_selfplay_stats_fn)(const uint64_t* stats10, double elapsed, int local_halt, void* user);
+int sayuri_selfplay_run_ex(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
+                           int move_cap, sayuri_selfplay_stats_fn on_stats, void* user, double interval_seconds,
+                           uint64_t* stats, double* elapsed);
 
 #ifdef __cplusplus
 }

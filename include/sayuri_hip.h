@@ -169,6 +169,9 @@ int sayuri_hip_test_conv(int device, int use_fp16, int n, const int* board_sizes
                          int cin, int cout, int k, int depthwise, int act, int post_residual,
                          const float* x, const float* w, const float* bias, const float* res,
                          float* y);
+/* Kernel family the calling thread's last sayuri_hip_test_conv ran: 0 generic implicit GEMM (conv_mfma.h),
+ * 1 LDS-DMA tiles across samples (conv_glds.h), 2 one workgroup per board (conv_board.h), 3 depthwise. */
+int sayuri_hip_test_last_conv_kind(void);
 
 #ifdef __cplusplus
 }

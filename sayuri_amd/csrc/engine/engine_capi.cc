@@ -6,6 +6,7 @@
 #include <sstream>
 #include <string>
 
+#include "../../../include/sayuri_engine.h"
 #include "engine_options.h"
 #include "search.h"
 #include "selfplay.h"
@@ -157,6 +158,7 @@ int sayuri_engine_search_think(void* s, void* game) {
     return MoveToIndex(*static_cast<GameState*>(game), static_cast<Search*>(s)->ThinkBestMove());
 }
 // indices of the buffered training samples that came from single-candidate searches (see search.h); returns the count
+// (call it BEFORE sayuri_engine_search_gather, which empties the list; cap = 0 queries the count without copying)
 int sayuri_engine_search_single_candidate(void* s, int* out, int cap) {
     const auto& v = static_cast<Search*>(s)->single_candidate_records();
     for (size_t i = 0; i < v.size() && static_cast<int>(i) < cap; ++i) out[i] = v[i];
@@ -168,8 +170,27 @@ void sayuri_engine_search_update_territory_helper(void* s) { static_cast<Search*
 // chunks_saved, 0.  Returns 0, or -1 with the message in sayuri_engine_last_error().
 static thread_local std::string g_engine_err;
 const char* sayuri_engine_last_error() { return g_engine_err.c_str(); }
-int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
-                        int move_cap, std::uint64_t* stats, double* elapsed) {
+namespace {
+void PackStats(const SelfplayStats& st, std::uint64_t* v) {
+    const std::uint64_t a[10] = {st.games_started, st.games_done, st.moves, st.playouts, st.nn_queries,
+                                 st.cache_lookups, st.cache_hits, st.records, st.chunks_saved, 0};
+    std::memcpy(v, a, sizeof(a));
+}
+struct StatsHook {
+    sayuri_selfplay_stats_fn fn;
+    void* user;
+};
+int StatsTrampoline(const SelfplayStats* st, int local_halt, void* user) {
+    const StatsHook* h = static_cast<const StatsHook*>(user);
+    std::uint64_t v[10];
+    PackStats(*st, v);
+    return h->fn(v, st->elapsed, local_halt, h->user);
+}
+} // namespace
+
+int sayuri_selfplay_run_ex(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
+                           int move_cap, sayuri_selfplay_stats_fn on_stats, void* user, double interval_seconds,
+                           std::uint64_t* stats, double* elapsed) {
     try {
         EngineOptions opt;
         opt.Parse(options ? options : "");
@@ -177,16 +198,23 @@ int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options
         if (raw_pipe) pipe = std::shared_ptr<NetworkForwardPipe>(static_cast<NetworkForwardPipe*>(raw_pipe), [](NetworkForwardPipe*) {});
         SelfplayPipe sp(pipe, weights_version, opt, name_suffix ? name_suffix : "");
         sp.engine().move_cap = move_cap;
+        StatsHook hook{on_stats, user};
+        if (on_stats) sp.SetStatsCallback(&StatsTrampoline, &hook, interval_seconds > 0 ? interval_seconds : 2.0);
         const SelfplayStats st = sp.Run(seconds);
-        const std::uint64_t v[10] = {st.games_started, st.games_done, st.moves, st.playouts, st.nn_queries,
-                                     st.cache_lookups, st.cache_hits, st.records, st.chunks_saved, 0};
-        std::memcpy(stats, v, sizeof(v));
+        PackStats(st, stats);
+        stats[9] = static_cast<std::uint64_t>(sp.max_games());
         *elapsed = st.elapsed;
         return 0;
     } catch (const std::exception& e) {
         g_engine_err = e.what();
         return -1;
     }
+}
+
+int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
+                        int move_cap, std::uint64_t* stats, double* elapsed) {
+    return sayuri_selfplay_run_ex(raw_pipe, weights_version, options, name_suffix, seconds, move_cap, nullptr, nullptr, 0.0, stats,
+                                  elapsed);
 }
 
 // The network evaluation facade on a forward pipe (for GPU parity tests of search moves).
@@ -199,14 +227,28 @@ void* sayuri_engine_net_new_pipe(void* raw_pipe, int weights_version, const char
     return net;
 }
 
+// Returns the size of the serialized records.  Gathering empties the search's training buffer, so the text is parked
+// per calling thread until a call with a large enough `cap` has copied it out: a short buffer loses nothing, the
+// caller retries with the returned size (a call for a different search handle drops a parked text).
 long sayuri_engine_search_gather(void* s, char* buf, long cap) {
-    std::vector<TrainingData> chunk;
-    static_cast<Search*>(s)->GatherTrainingBuffer(chunk);
-    std::ostringstream oss;
-    for (auto& d : chunk) d.StreamOut(oss);
-    const std::string str = oss.str();
-    if (static_cast<long>(str.size()) <= cap) std::memcpy(buf, str.data(), str.size());
-    return static_cast<long>(str.size());
+    static thread_local void* parked_for = nullptr;
+    static thread_local std::string parked;
+    if (parked_for != s) {
+        std::vector<TrainingData> chunk;
+        static_cast<Search*>(s)->GatherTrainingBuffer(chunk);
+        std::ostringstream oss;
+        for (auto& d : chunk) d.StreamOut(oss);
+        parked = oss.str();
+        parked_for = s;
+    }
+    const long size = static_cast<long>(parked.size());
+    if (size <= cap && (buf || size == 0)) {
+        if (size > 0) std::memcpy(buf, parked.data(), parked.size());
+        parked.clear();
+        parked.shrink_to_fit();
+        parked_for = nullptr;
+    }
+    return size;
 }
 
 } // extern "C"

@@ -91,6 +91,9 @@ void EngineOptions::Parse(const std::string& text) {
         OPT_INT("scoring_rule", selfplay.scoring_rule);
         else if (k == "selfplay_query") selfplay.selfplay_queries.push_back(v);
         else if (k == "target_directory") selfplay.target_directory = v;
+        else if (k == "weights_dir") selfplay.weights_dir = v;
+        else if (k == "weights_file") selfplay.weights_file = v;
+        OPT_INT("stagger_moves", selfplay.stagger_moves);
         else if (k == "seed") selfplay.seed = std::stoull(v);
         else throw std::invalid_argument("unknown engine option: " + k);
 #undef OPT_INT

@@ -25,6 +25,12 @@ struct SelfplayOptions {
     std::vector<std::string> selfplay_queries; // "bkp:19:7.5:0.2", "bhp:9:2:0.1", "srs:area:territory"
     std::string target_directory;
     std::uint64_t seed{0}; // 0 = from the clock
+    // weights roll-over (reference Engine::SelectWeights / ShouldHalt, engine.cc:63-90): the loop winds down once the
+    // newest file in weights_dir is no longer weights_file
+    std::string weights_dir, weights_file;
+    // extension (measurement only): the first game of worker g starts after g * stagger_moves / parallel_games
+    // policy-sampled moves, so that a short window sees games in every phase, as a long-running self-play does
+    int stagger_moves{0};
 };
 
 struct EngineOptions {

@@ -1,5 +1,8 @@
 #include "selfplay.h"
 
+#include <dirent.h>
+#include <sys/stat.h>
+
 #include <malloc.h>
 #include <pthread.h>
 #include <sched.h>
@@ -218,6 +221,43 @@ void SelfplayEngine::SetFairKomi(int g) {
     s.state.SetKomi(AdjustKomiToHalf(s.state.GetKomi() + lead));
 }
 
+void SelfplayEngine::PlayPolicyMoves(int g, int count) {
+    Slot& s = At(g);
+    Rng& rng = s.search->caller_rng();
+    for (int i = 0; i < count; ++i) {
+        if (s.state.GetPasses() >= 2 || s.state.IsGameOver()) break;
+        s.state.PlayMove(network_.GetVertexWithPolicy(s.state, 1.0f, false, rng));
+        s.comments.emplace_back();
+    }
+}
+
+std::string SelfplayEngine::SelectWeights() const {
+    if (!opt_.selfplay.weights_file.empty() && opt_.selfplay.weights_dir.empty()) return opt_.selfplay.weights_file;
+    std::string best = opt_.selfplay.weights_file;
+    if (opt_.selfplay.weights_dir.empty()) return best;
+    DIR* d = opendir(opt_.selfplay.weights_dir.c_str());
+    if (!d) return best;
+    bool have = false;
+    struct timespec best_time {};
+    while (struct dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name == "." || name == "..") continue;
+        const std::string path = opt_.selfplay.weights_dir + "/" + name;
+        struct stat st {};
+        if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+        const bool newer = !have || st.st_mtim.tv_sec > best_time.tv_sec ||
+                           (st.st_mtim.tv_sec == best_time.tv_sec && st.st_mtim.tv_nsec > best_time.tv_nsec);
+        if (newer) { best = path; best_time = st.st_mtim; have = true; }
+    }
+    closedir(d);
+    return best;
+}
+
+bool SelfplayEngine::ShouldHalt() const {
+    if (opt_.selfplay.weights_dir.empty()) return false;
+    return SelectWeights() != opt_.selfplay.weights_file;
+}
+
 bool SelfplayEngine::Step(int g) {
     Slot& s = At(g);
     if (s.state.IsGameOver()) return false;
@@ -283,7 +323,7 @@ std::string SelfplayEngine::GatherSgfString(int g) {
 SelfplayPipe::SelfplayPipe(std::shared_ptr<NetworkForwardPipe> pipe, int weights_version, const EngineOptions& opt,
                            const std::string& name_suffix)
     : opt_(opt), engine_(std::move(pipe), weights_version, opt) {
-    max_games_ = std::max(opt_.selfplay.num_games, engine_.GetParallelGames());
+    max_games_.store(std::max(opt_.selfplay.num_games, engine_.GetParallelGames()));
     const std::string& target = opt_.selfplay.target_directory;
     if (!target.empty()) {
         // a name not used by an earlier run in this directory (pipe.cc:44-80), plus the caller's suffix (rank id)
@@ -382,6 +422,16 @@ void SelfplayPipe::WriterLoop() {
     }
 }
 
+void SelfplayPipe::WindDown() {
+    // pipe.cc:248-254: finish the games in flight plus a buffer, rounded up to a multiple of 25
+    constexpr int kBufferGames = 25;
+    const int accum = std::max(engine_.GetParallelGames(), accumulation_games_.load(std::memory_order_relaxed));
+    const int cap = (accum + kBufferGames + kBufferGames - 1) / kBufferGames * kBufferGames;
+    int cur = max_games_.load();
+    while (cap < cur && !max_games_.compare_exchange_weak(cur, cap)) {
+    }
+}
+
 SelfplayStats SelfplayPipe::Run(double seconds) {
     // Hundreds of game threads build and drop a search tree per move.  Keep freed heap inside the process instead of
     // trimming / unmapping it: every munmap or brk shrink takes the address-space lock exclusively and stalls the page
@@ -407,7 +457,7 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
     }
     for (int g = 0; g < games; ++g) engine_.search(g).SetAbortFlag(&stop_);
     for (int g = 0; g < games; ++g) {
-        workers.emplace_back([this, g, &started, &cpus]() {
+        workers.emplace_back([this, g, games, &started, &cpus]() {
             if (cpus.size() > 1) {
                 cpu_set_t one;
                 CPU_ZERO(&one);
@@ -427,10 +477,21 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                 }
             }
             try {
-            while (!stop_.load(std::memory_order_relaxed) && accumulation_games_.fetch_add(1) < max_games_) {
+            bool first_game = true, halting = false;
+            while (!stop_.load(std::memory_order_relaxed) && accumulation_games_.fetch_add(1) < max_games_.load(std::memory_order_relaxed)) {
+                if (g == 0 && !halting) {  // pipe.cc:246-258: only the main worker looks, once per game
+                    if (halt_wish_.load(std::memory_order_relaxed) || engine_.ShouldHalt()) {
+                        halt_wish_.store(true, std::memory_order_relaxed);
+                        if (!stats_cb_) WindDown();  // alone: act at once; with an exchange hook the verdict comes from there
+                        halting = !stats_cb_;
+                    }
+                }
                 started.fetch_add(1);
                 auto item = std::make_shared<DataSgf>();
                 engine_.PrepareGame(g);
+                if (first_game && opt_.selfplay.stagger_moves > 0)
+                    engine_.PlayPolicyMoves(g, static_cast<int>(static_cast<long long>(g) * opt_.selfplay.stagger_moves / std::max(games, 1)));
+                first_game = false;
                 // the game loop, abandoned between moves when the clock has run out
                 Search& search = engine_.search(g);
                 bool abandoned = false;
@@ -472,17 +533,28 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
     };
     SelfplayStats st;
     bool timed_out = false;
-    if (seconds > 0) {
-        // wake up often enough to stop close to the deadline
-        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
-            if (played_games_.load() >= max_games_) break;
+    {
+        // wake up often enough to stop close to the deadline; hand the counters to the exchange hook on its period
+        double next_cb = stats_interval_;
+        for (;;) {
+            const double now = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (seconds > 0 && now >= seconds) break;
+            if (played_games_.load() >= max_games_.load()) break;
+            if (stop_.load()) break;  // a worker failed (error_ is set): report now, not at the deadline
+            if (seconds <= 0 && accumulation_games_.load() >= max_games_.load() + games) break;  // every worker has left its loop
+            if (stats_cb_ && now >= next_cb) {
+                SelfplayStats snap;
+                snapshot(snap);
+                if (stats_cb_(&snap, halt_wish_.load() ? 1 : 0, stats_user_) != 0) WindDown();
+                next_cb += stats_interval_;
+            }
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
-        if (played_games_.load() < max_games_) {
+        if (seconds > 0 && played_games_.load() < max_games_.load() && !stop_.load()) {
             snapshot(st); // the window ends here: what the workers do while winding down is not counted
             timed_out = true;
         }
-        stop_.store(true);
+        if (seconds > 0 || stop_.load()) stop_.store(true);
     }
     for (auto& w : workers) w.join();
     if (!timed_out) snapshot(st);

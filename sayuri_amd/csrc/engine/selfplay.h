@@ -31,6 +31,9 @@ class SelfplayEngine { // engine.h:12-69
 public:
     SelfplayEngine(std::shared_ptr<NetworkForwardPipe> pipe, int weights_version, const EngineOptions& opt);
     void PrepareGame(int g);                                       // engine.cc:193-232
+    void PlayPolicyMoves(int g, int count);                        // extension: `count` policy-sampled moves, no search, no records
+    std::string SelectWeights() const;                             // engine.cc:63-86
+    bool ShouldHalt() const;                                       // engine.cc:88-90
     bool Step(int g);                                              // one self-play move; false once the game is over
     void Selfplay(int g);                                          // engine.cc:234-241
     void GatherTrainingData(std::vector<TrainingData>& chunk, int g);
@@ -78,6 +81,13 @@ public:
     // Plays until `num_games` games are complete, or (seconds > 0) until the clock runs out: games still in
     // progress are then abandoned and not written.
     SelfplayStats Run(double seconds = 0);
+    // Periodic exchange hook: every `interval` seconds the calling thread of Run() hands a snapshot of the counters and
+    // this process's own halt wish (ShouldHalt: newer weights have appeared) to `cb`; a non-zero return = "some
+    // process wants to halt", and the loop winds down as pipe.cc:246-258 does (max_games rounded up to the next 25).
+    // The multi-GPU driver all-gathers the records there (sayuri_amd/shard.py) -- the path's only exchange.
+    using StatsCallback = int (*)(const SelfplayStats* stats, int local_halt, void* user);
+    void SetStatsCallback(StatsCallback cb, void* user, double interval) { stats_cb_ = cb; stats_user_ = user; stats_interval_ = interval; }
+    int max_games() const { return max_games_.load(); }
     const std::string& filename_hash() const { return hash_; }
     SelfplayEngine& engine() { return engine_; }
 
@@ -98,7 +108,12 @@ private:
     std::atomic<int> accumulation_games_{0}, played_games_{0};
     std::atomic<bool> stop_{false};
     std::atomic<std::uint64_t> records_{0}, chunks_{0};
-    int max_games_{0};
+    std::atomic<int> max_games_{0};
+    std::atomic<bool> halt_wish_{false};     // set by worker 0 (ShouldHalt) or by the stats callback's verdict
+    void WindDown();                         // pipe.cc:248-254
+    StatsCallback stats_cb_{nullptr};
+    void* stats_user_{nullptr};
+    double stats_interval_{2.0};
     std::string error_;
 };
 

@@ -14,6 +14,9 @@
 
 namespace sayuri {
 
+// Zero bytes every activation buffer carries in front of row 0 (the halo source of conv_board.h's 32-bit-offset DMA).
+constexpr int kZeroPrefix = 4096;
+
 enum Act : int { kIdentity = 0, kReLU, kELU, kSELU, kGELU, kMish, kSwish, kHardSwish };
 
 typedef _Float16 f16;

@@ -1,0 +1,448 @@
+// conv_board.h -- the tower convolution (fp16 3x3 implicit GEMM) with ONE WORKGROUP PER BOARD.
+//
+// A Go board is small: 19 x 19 = 361 pixels x 256 channels of fp32 accumulators is 370 KB, which fits the 512 KB
+// register file of one CU.  So a workgroup owns whole samples (one 19x19 board, two 13x13, four 9x9 ...: up to 384
+// pixels = 24 column tiles of 16) and ALL output channels of the layer (KO_T = 256 / 192 / 128):
+//   * a 256-sample batch of 19x19 boards is exactly 256 workgroups = one full wave of the chip's 256 CUs, no tail
+//     (conv_glds.h's 192-pixel tiles gave 482 workgroups = 1.88 waves);
+//   * the halo of a tile is the boards' own zero frame -- no neighbouring tile is ever read, and a layer's output
+//     tile is exactly the next layer's input tile;
+//   * every weight byte is staged once per board (half the L2 -> LDS weight traffic of the 192-pixel tiles) and a
+//     K group (3 taps x 32 channels) is 4.4 k MFMA cycles per SIMD between workgroup barriers instead of 2.3 k;
+//   * the workgroup sees every pixel and every channel of its samples, so the squeeze-and-excitation unit that
+//     follows a block's second convolution (global pooling -> FC -> FC -> scale + residual + activation,
+//     reference se_unit.cc:70-128) runs INSIDE this kernel's epilogue on the accumulators (conv_board_se.h).
+//
+// Waves: 4 along M x 2 along N.  Wave (m, n) owns output channels [m*WMT*16, (m+1)*WMT*16) and the column tiles
+// [col0, col0 + nj) of the tile, nj = 12 or 11 for a 19x19 board: waves w and w + 4 share a SIMD, so each SIMD gets
+// 23 column tiles x WMT row tiles -- balanced without padding the 23rd tile to a 24th.
+// K loop, LDS rings and the hand-counted ds_read_b128 stream follow conv_glds.h: weights and halo reach LDS by
+// global_load_lds_dwordx4 only, one s_barrier per K group, fragment reads are inline asm with compile-time lgkmcnt.
+// Epilogue: no LDS staging.  v_permlane16_swap pairs the 4-channel accumulator quads of two row tiles into 8
+// consecutive channels per lane (16 bytes of fp16), four lanes cover 64 contiguous bytes of one NHWC pixel row.
+#pragma once
+#include "common.h"
+#include "conv_glds.h"
+#include "conv_mfma.h"
+
+namespace sayuri {
+
+constexpr int kBoardCols = 24;              // 16-pixel column tiles per workgroup
+constexpr int kBoardPT = kBoardCols * 16;   // pixel slots per tile
+constexpr int kBoardMaxPos = 512;           // halo positions per tile (DMA blocks of 64)
+constexpr int kBoardMaxSub = 32;            // samples per tile
+constexpr int kBoardNJ = kBoardCols / 2;    // column tiles per wave
+
+struct BoardParams {
+    ConvParams c;          // num_pix_tiles = number of board tiles; in must carry the kZeroPrefix zero bytes in front
+    const int* tab_src;    // [tile][npos]   activation row feeding each halo position, -1 = zero
+    const int2* tab_pix;   // [tile][384]    x = lpos | lstr << 16, y = output activation row (-1 = none)
+    const int* tab_cols;   // [tile]         column tiles in use (1..24) | board size << 8
+    int npos;              // halo positions per tile of this launch (multiple of 64, <= 512)
+};
+
+// Which samples share a tile: consecutive samples OF ONE BOARD SIZE, greedily, while pixels <= 384, halo positions
+// <= 512 and samples <= 32 (one size per tile keeps the halo row pitch wave-uniform: the B-fragment addresses of a
+// kernel row are then the previous row's plus a scalar).  The same scan runs on the host (grid size, LDS size) and
+// in board_setup_kernel.
+struct BoardPack {
+    int px = 0, pos = 0, cnt = 0, bs0 = 0;
+    __host__ __device__ bool fits(int bs) const {
+        return (cnt == 0 || bs == bs0) && cnt < kBoardMaxSub && px + bs * bs <= kBoardPT &&
+               pos + (bs + 2) * (bs + 2) <= kBoardMaxPos;
+    }
+    __host__ __device__ void add(int bs) { px += bs * bs; pos += (bs + 2) * (bs + 2); ++cnt; bs0 = bs; }
+};
+
+// Index tables of one batch geometry, one workgroup per tile (shared by every layer of the forward).
+__global__ __launch_bounds__(256) void board_setup_kernel(BatchGeom g, int npos, int* __restrict__ tab_src,
+                                                          int2* __restrict__ tab_pix, int* __restrict__ tab_cols) {
+    __shared__ int sub[kBoardMaxSub][4];  // {first halo position, first pixel slot, board size, sample}
+    __shared__ int hdr[2];                // {samples, pixels}
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int t = 0, s = 0;
+        BoardPack pk;
+        int cnt = 0;
+        for (; s < g.n_samples; ++s) {
+            const int bs = g.bsz[s];
+            if (pk.cnt > 0 && !pk.fits(bs)) {
+                if (t == tile) break;
+                ++t;
+                pk = BoardPack{};
+            }
+            if (t == tile) {
+                sub[cnt][0] = pk.pos; sub[cnt][1] = pk.px; sub[cnt][2] = bs; sub[cnt][3] = s;
+                ++cnt;
+            }
+            pk.add(bs);
+        }
+        hdr[0] = cnt;
+        hdr[1] = cnt > 0 ? sub[cnt - 1][1] + sub[cnt - 1][2] * sub[cnt - 1][2] : 0;
+        tab_cols[tile] = ((hdr[1] + 15) / 16) | (sub[0][2] << 8);
+    }
+    __syncthreads();
+    const int nsub = hdr[0], npx = hdr[1];
+    for (int pos = tid; pos < npos; pos += blockDim.x) {
+        int src = -1;
+        for (int s = 0; s < nsub; ++s) {
+            const int bs = sub[s][2], w2 = bs + 2, rel = pos - sub[s][0];
+            if (rel >= 0 && rel < w2 * w2) {
+                const int r = rel / w2, xc = rel - r * w2;
+                const int y = r - 1, x = xc - 1;
+                if (y >= 0 && y < bs && x >= 0 && x < bs) src = sub[s][3] * g.slot_pix + y * bs + x;
+                break;
+            }
+        }
+        tab_src[(size_t)tile * npos + pos] = src;
+    }
+    for (int i = tid; i < kBoardPT; i += blockDim.x) {
+        int lstr = sub[0][2] + 2, lpos = lstr + 1, orow = -1;  // an interior cell: every tap stays inside the tile
+        if (i < npx) {
+            for (int s = 0; s < nsub; ++s) {
+                const int bs = sub[s][2], pp = i - sub[s][1];
+                if (pp >= 0 && pp < bs * bs) {
+                    const int y = pp / bs, x = pp - y * bs;
+                    lstr = bs + 2;
+                    lpos = sub[s][0] + (y + 1) * (bs + 2) + x + 1;
+                    orow = sub[s][3] * g.slot_pix + pp;
+                    break;
+                }
+            }
+        }
+        tab_pix[(size_t)tile * kBoardPT + i] = make_int2(lpos | (lstr << 16), orow);
+    }
+}
+
+template <int WMT_> struct BoardCfg {
+    static constexpr int WMT = WMT_, WAVM = 4, WAVN = 2, NWAVE = 8, NJ = kBoardNJ;
+    static constexpr int KO_T = WAVM * WMT * 16;
+    static constexpr int A_TAP_BYTES = KO_T * 64;   // one tap x 32 channels of weights
+    static constexpr int A_BYTES = 3 * A_TAP_BYTES; // one K group
+    static constexpr int A_INSTR = KO_T / 16;       // 1 KiB DMA instructions per tap tile
+    static constexpr int AI = (A_INSTR + NWAVE - 1) / NWAVE;
+    static constexpr int KO_PARTS = KO_T / 64;      // 64-row pieces per k-group plane
+    static constexpr size_t lds_bytes(int npos) { return 2 * (size_t)A_BYTES + 2 * (size_t)npos * 64; }
+};
+
+namespace board_sched {
+// The fragment stream of one K group: MFMA block b = 12*dx + j (tap-in-row dx, column tile j) issues WMT MFMAs
+// with A(dx, 0..WMT-1) and B(b).  LDS reads in program order:
+//   before block 0:  B(0), A(0,0) .. A(0,WMT-1), B(1)
+//   block b:         B(b+2) | wait | MFMA 0 .. WMT-1; in the last block of a tap (j == 11) A(dx+1, i) follows MFMA i
+// A fragment i always lives in afr[i] (the next tap's fragment lands in the register its MFMA has just read),
+// B fragments in a ring of 3.
+constexpr int kNB = 3 * kBoardNJ;
+template <int WMT> constexpr int late_a(int b) { return (b >= 0 && b % kBoardNJ == kBoardNJ - 1 && b / kBoardNJ < 2) ? WMT : 0; }
+// LDS reads younger than B(b) when block b waits for it (the first block of a tap waits per MFMA instead)
+template <int WMT> constexpr int young_b(int b) {
+    if (b < 2) return 2;  // block 0 waits for A(0, WMT-1): B(1), B(2) are younger; block 1: B(2), B(3)
+    return late_a<WMT>(b - 2) + (b + 1 < kNB ? 1 : 0) + late_a<WMT>(b - 1) + (b + 2 < kNB ? 1 : 0);
+}
+}  // namespace board_sched
+
+template <int N> __device__ __forceinline__ void wait_lgkm1(f16x8& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm2(f16x8& a, f16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+// the first NF fragments of the A ring and one B fragment
+template <int N, int NF, int NA> __device__ __forceinline__ void wait_lgkm_all(f16x8 (&a)[NA], f16x8& b) {
+    static_assert(NF >= 2 && NF <= 4 && NF <= NA, "2..4 A fragments per tap");
+    if constexpr (NF == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(b) : "n"(N));
+    else if constexpr (NF == 3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b) : "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b) : "n"(N));
+}
+
+__device__ __forceinline__ void swap16(f32x4& a, f32x4& b) {
+    // per register, rows of 16 lanes: a's odd rows <-> b's even rows.  Inline asm: with hipcc (ROCm 7.2)
+    // __builtin_amdgcn_permlane16_swap loses its second result here (the code that follows reads the first result for
+    // both halves -- seen in the .s, and as wrong channels 4-7 / 12-15 of every row tile on the GPU); s_nop 1 = the
+    // two wait states a VALU write of either operand needs before the swap reads it.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = a[q], y = b[q];
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+        a[q] = x;
+        b[q] = y;
+    }
+}
+
+// The accumulators live in the AGPR half of the register file for the whole kernel ("+a"): as compiler-allocated
+// VGPRs hipcc shuffles the 192 accumulator registers around the K loop's back-edge and spills.  The statement is
+// volatile, so the MFMA stream keeps the written order relative to the fragment reads and waits.  A and B come out of
+// LDS reads retired by an s_waitcnt (no VALU-write hazard); consecutive MFMAs never share an accumulator.
+__device__ __forceinline__ void mma_agpr(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mma_vgpr(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// hipcc splits a 256-register budget evenly once a kernel names AGPRs: 128 accumulator registers (32 output tiles)
+// sit in AGPRs, the remaining ones share the VGPR half with the fragments
+template <int WMT, int I, int J> __device__ __forceinline__ void mma_tile(f32x4& acc, const f16x8& a, const f16x8& b) {
+    if constexpr (WMT * J + I < 32) mma_agpr(acc, a, b);
+    else mma_vgpr(acc, a, b);
+}
+
+// LDS-DMA with a scalar base: lane l moves 16 bytes from sbase + voff(l) to lds_dst + 16*l.  Inline asm because hipcc
+// turns (uniform pointer + per-lane offset) into a per-lane 64-bit pointer held in two VGPRs per DMA piece.  M0 is
+// compiler-reserved: saved and restored inside the statement; s_nop 4 covers an SGPR operand fresh from a VALU
+// readfirstlane, s_nop 0 the M0 write (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+// The main loop: returns with the accumulators (bias included) of this wave's (WMT x 12) output tiles.
+// `full` = the wave's 12th column tile is in use (else its MFMAs are skipped; other unused tiles are computed on
+// whatever the padded pixel slots point at and never stored).
+template <int WMT>
+__device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
+                                               int kt, int wave, int lane, int col0, bool full, int bs) {
+    using Cfg = BoardCfg<WMT>;
+    using namespace board_sched;
+    constexpr int KO_T = Cfg::KO_T, NJ = Cfg::NJ, AI = Cfg::AI, NA = WMT;
+    const ConvParams& p = bp.c;
+    const int npos = bp.npos, b_bytes = npos * 64;
+    const uint32_t a_ring = (uint32_t)(uintptr_t)smem;
+    const uint32_t b_ring = a_ring + 2 * Cfg::A_BYTES;
+    const int wave_m = wave & 3;
+    const int kg = lane >> 4;
+    const int ls16 = (bs + 2) * 16;  // halo row pitch in bytes of one k-group plane
+
+    // ---- halo DMA: instruction q = wave + 8*i moves k-group plane q & 3 of position block q >> 2 (64 positions);
+    // sources are 32-bit offsets from (in - kZeroPrefix): a halo cell reads the buffer's zero prefix, so adding the
+    // chunk offset needs no test
+    const unsigned char* gin0 = (const unsigned char*)p.in - kZeroPrefix;
+    const unsigned char* gw = (const unsigned char*)p.w;
+    const int nbinstr = npos / 64 * 4;
+    uint32_t boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave + 8 * i, kgq = q & 3, blk = q >> 2;
+        int src = -1;
+        if (q < nbinstr) src = bp.tab_src[(size_t)tile * npos + blk * 64 + lane];
+        boff[i] = (src >= 0 ? (uint32_t)kZeroPrefix + (uint32_t)src * (uint32_t)(p.cin_s * 2) : 0u) + kgq * 16;
+    }
+    // per-lane B fragment addresses of the current (halo slot, kernel row); moved by scalars from group to group
+    uint32_t bb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int2 e = bp.tab_pix[(size_t)tile * kBoardPT + (col0 + j) * 16 + (lane & 15)];
+        const uint32_t lp = e.x & 0xffff;
+        bb[j] = b_ring + (lp - 1) * 16 + (uint32_t)kg * npos * 16 - ls16;  // kernel row 0 (dy = -1) in slot 0
+    }
+    const int nchunks = p.cin_s / kChunk;
+    const int ngroups = nchunks * 3;
+    const uint32_t lane16 = lane * 16;
+    const size_t tap_stride = (size_t)nchunks * 4 * p.ko_pad * 16;  // bytes between taps
+    const size_t chunk_stride = (size_t)4 * p.ko_pad * 16;          // bytes between chunks
+    // weight piece q = wave + 8*i of a tap tile -> plane q / KO_PARTS, rows (q % KO_PARTS)*64 + lane
+    auto issue_a = [&](int G, int dx, int i) {  // piece i of the weight tile (group G, tap-in-row dx) -> ring slot G & 1
+        const int q = wave + 8 * i;
+        if (q >= Cfg::A_INSTR) return;
+        const int kgq = q / Cfg::KO_PARTS, part = q % Cfg::KO_PARTS;
+        const int chunk = G / 3, row = G - chunk * 3;
+        const unsigned char* base = gw + (size_t)(row * 3 + dx) * tap_stride + (size_t)chunk * chunk_stride +
+                                    (size_t)((kgq * p.ko_pad + kt * KO_T + part * 64) * 16);
+        glds16_s(lane16, base, a_ring + (G & 1) * Cfg::A_BYTES + dx * Cfg::A_TAP_BYTES + (kgq * KO_T + part * 64) * 16);
+    };
+    auto issue_b = [&](int chunk, int i) {
+        const int q = wave + 8 * i;
+        if (q >= nbinstr) return;
+        glds16_s(boff[i], gin0 + chunk * (kChunk * 2), b_ring + (chunk & 1) * b_bytes + ((q & 3) * npos + (q >> 2) * 64) * 16);
+    };
+
+    // accumulators start at the bias: D rows 4*(lane>>4)+r of row tile i are 4 consecutive output channels
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+        const f32x4 b4 = *(const f32x4*)(p.bias + kt * KO_T + (wave_m * WMT + i) * 16 + 4 * kg);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = b4;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table / bias loads are done before the first DMA goes out
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_b(0, i);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int i = 0; i < AI; ++i) issue_a(0, dx, i);
+
+    const uint32_t arow_off = (uint32_t)((kg * KO_T + wave_m * WMT * 16 + (lane & 15)) * 16);
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more_b = chunk + 1 < nchunks;
+        static_for<3>([&](auto rowc) {
+            constexpr int row = decltype(rowc)::value;
+            const int G = chunk * 3 + row;
+            // A(G) and B(chunk) were issued during earlier groups and nothing after them
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            const bool more_a = G + 1 < ngroups;
+            const uint32_t abase = a_ring + (G & 1) * Cfg::A_BYTES + arow_off;
+            f16x8 afr[NA], bfr[3];
+            ds_read16<0>(bfr[0], bb[0]);
+            static_for<WMT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ds_read16<i * 256>(afr[i], abase);
+            });
+            ds_read16<0>(bfr[1], bb[1]);
+            static_for<kNB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                constexpr int dx = b / NJ, j = b % NJ;
+                // DMA of the next group / chunk, front-loaded: weights at blocks 0, 3, 6, ..., halo pieces at blocks 1
+                // and 4 of rows 0 and 1 (the next chunk's slot is free from the start of this chunk)
+                if constexpr (b % 3 == 0 && b / 3 < 3 * AI) {
+                    if (more_a) issue_a(G + 1, (b / 3) / AI, (b / 3) % AI);
+                }
+                if constexpr ((b == 1 || b == 4) && row < 2) {
+                    if (more_b) issue_b(chunk + 1, row * 2 + (b == 4 ? 1 : 0));
+                }
+                if constexpr (b + 2 < kNB) {
+                    constexpr int b2 = b + 2;
+                    ds_read16<16 * (b2 / NJ)>(bfr[b2 % 3], bb[b2 % NJ]);
+                }
+                if constexpr (b == 0) wait_lgkm_all<young_b<WMT>(0), WMT>(afr, bfr[0]);
+                else if constexpr (j > 0) wait_lgkm1<young_b<WMT>(b)>(bfr[b % 3]);
+                static_for<WMT>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    // first block of a tap: A(dx, i) went out during the previous block, A(dx, i+1..) and B(b+2) after it
+                    if constexpr (j == 0 && dx > 0) wait_lgkm2<WMT - i>(afr[i], bfr[b % 3]);
+                    if constexpr (j == NJ - 1) {
+                        if (full) mma_tile<WMT, i, j>(acc[i][j], afr[i], bfr[b % 3]);
+                    } else {
+                        mma_tile<WMT, i, j>(acc[i][j], afr[i], bfr[b % 3]);
+                    }
+                    if constexpr (j == NJ - 1 && dx < 2)
+                        ds_read16<(dx + 1) * Cfg::A_TAP_BYTES + i * 256>(afr[i], abase);
+                });
+            });
+            // next kernel row: one halo row further; after the third row the other halo slot, two rows back
+            const int delta = row < 2 ? ls16 : ((chunk & 1) ? -b_bytes : b_bytes) - 2 * ls16;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bb[j] += (uint32_t)delta;
+        });
+    }
+    // the last MFMAs retire before the epilogue reads the accumulators (hipcc pads nothing after an asm statement)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
+
+template <int ACT> __device__ __forceinline__ f16x8 board_act8(const float (&v)[8]) {
+    f16x8 h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h[q] = (f16)activate(v[q], ACT);
+    return h;
+}
+
+// Plain epilogue: optional residual, activation, fp16 NHWC store -- straight from the accumulators (bias is in).
+template <int WMT, int ACT>
+__device__ __forceinline__ void board_epilogue(const BoardParams& bp, f32x4 (&acc)[WMT][kBoardNJ], int tile, int kt, int wave,
+                                               int lane, int col0, int nj) {
+    using Cfg = BoardCfg<WMT>;
+    constexpr int NJ = Cfg::NJ, NPAIR = WMT / 2;
+    constexpr bool LONE = (WMT & 1) != 0;
+    const ConvParams& p = bp.c;
+    const int R = lane >> 4, px = lane & 15, wave_m = wave & 3;
+    const f16* __restrict__ gres = (const f16*)p.res;
+    f16* __restrict__ gout = (f16*)p.out;
+    const int ko_w = kt * Cfg::KO_T + wave_m * WMT * 16;
+    const int2* pix = bp.tab_pix + (size_t)tile * kBoardPT + col0 * 16 + px;
+    // after the swap of pair pr this lane holds row tile 2*pr + (R & 1), channels (R >> 1)*8 .. +7 of it
+    int cb[NPAIR > 0 ? NPAIR : 1];
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) cb[pr] = ko_w + (2 * pr + (R & 1)) * 16 + (R >> 1) * 8;
+    const int cl = ko_w + (WMT - 1) * 16 + 4 * R;  // lone row tile: accumulator layout, 4 channels per lane
+
+    auto res8 = [&](int orow, int pr) -> f16x8 {
+        if (gres && orow >= 0 && cb[pr] < p.cout_s) return *(const f16x8*)(gres + (size_t)orow * p.cout_s + cb[pr]);
+        return f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    auto res4 = [&](int orow) -> f16x4 {
+        if (gres && orow >= 0 && cl < p.cout_s) return *(const f16x4*)(gres + (size_t)orow * p.cout_s + cl);
+        return f16x4{0, 0, 0, 0};
+    };
+    // output rows two column tiles ahead, residual rows one column tile ahead of the arithmetic
+    int orow[3];
+    f16x8 rr[2][NPAIR > 0 ? NPAIR : 1];
+    f16x4 rl[2];
+    orow[0] = nj > 0 ? pix[0].y : -1;
+    orow[1] = nj > 1 ? pix[16].y : -1;
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) rr[0][pr] = res8(orow[0], pr);
+    if constexpr (LONE) rl[0] = res4(orow[0]);
+    static_for<NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (j < nj) {  // wave-uniform
+            if constexpr (j + 2 < NJ) orow[(j + 2) % 3] = j + 2 < nj ? pix[(j + 2) * 16].y : -1;
+            if constexpr (j + 1 < NJ) {
+#pragma unroll
+                for (int pr = 0; pr < NPAIR; ++pr) rr[(j + 1) & 1][pr] = res8(orow[(j + 1) % 3], pr);
+                if constexpr (LONE) rl[(j + 1) & 1] = res4(orow[(j + 1) % 3]);
+            }
+            const int my = orow[j % 3];
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                f32x4 a = acc[2 * pr][j], b = acc[2 * pr + 1][j];
+                swap16(a, b);
+                float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                if (gres) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += (float)rr[j & 1][pr][q];
+                }
+                const f16x8 h = board_act8<ACT>(v);
+                if (my >= 0 && cb[pr] < p.cout_s) *(f16x8*)(gout + (size_t)my * p.cout_s + cb[pr]) = h;
+            }
+            if constexpr (LONE) {
+                f32x4 v = acc[WMT - 1][j];
+                if (gres) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += (float)rl[j & 1][q];
+                }
+                f16x4 h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[q] = (f16)activate(v[q], ACT);
+                if (my >= 0 && cl < p.cout_s) *(f16x4*)(gout + (size_t)my * p.cout_s + cl) = h;
+            }
+        }
+    });
+}
+
+template <int WMT>
+__global__ __launch_bounds__(512, 2) void conv_board_kernel(const BoardParams bp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ConvParams& p = bp.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x % p.num_pix_tiles;
+    const int kt = blockIdx.x / p.num_pix_tiles;
+    // column tiles: wave column 0 (waves 0-3) takes the first ceil(n/2), wave column 1 (waves 4-7, the SIMD partners
+    // of 0-3) the rest
+    const int info = __builtin_amdgcn_readfirstlane(bp.tab_cols[tile]);
+    const int ncols = info & 0xff, bs = info >> 8;
+    const int nj0 = (ncols + 1) >> 1;
+    const int wave_n = wave >> 2;
+    const int col0 = wave_n ? nj0 : 0;
+    const int nj = wave_n ? ncols - nj0 : nj0;
+
+    f32x4 acc[WMT][kBoardNJ];
+    board_mainloop<WMT>(bp, smem, acc, tile, kt, wave, lane, col0, nj == kBoardNJ, bs);
+
+    switch (p.act) {
+    case kMish: board_epilogue<WMT, kMish>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    case kIdentity: board_epilogue<WMT, kIdentity>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    case kReLU: board_epilogue<WMT, kReLU>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    case kSwish: board_epilogue<WMT, kSwish>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    case kELU: board_epilogue<WMT, kELU>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    case kSELU: board_epilogue<WMT, kSELU>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    case kGELU: board_epilogue<WMT, kGELU>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    default: board_epilogue<WMT, kHardSwish>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    }
+}
+
+}  // namespace sayuri

@@ -69,11 +69,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// WAVN = wave columns of the workgroup (2 wave rows always): 4 -> eight waves, two per SIMD; 2 -> four waves, one
-// per SIMD, each with a twice as wide register tile (fewer LDS fragment reads per MFMA, 512 registers per lane).
-// SB = 1: the halo tile is single-buffered (the two-workgroups-per-CU variant: 72.5 KiB instead of 97 KiB at <4,3>)
-template <int WMT_, int WNT_, int WAVN_ = 4, int SB_ = 0> struct GldsCfg {
-    static constexpr int WMT = WMT_, WNT = WNT_, WAVM = 2, WAVN = WAVN_, NWAVE = WAVM * WAVN;
+template <int WMT_, int WNT_> struct GldsCfg {
+    static constexpr int WMT = WMT_, WNT = WNT_, WAVM = 2, WAVN = 4, NWAVE = WAVM * WAVN;
     static constexpr int KO_T = WAVM * WMT * 16;
     static constexpr int PT = WAVN * WNT * 16;
     static constexpr int NT = 64 * NWAVE;
@@ -88,7 +85,7 @@ template <int WMT_, int WNT_, int WAVN_ = 4, int SB_ = 0> struct GldsCfg {
     static constexpr int B_BYTES = NPOS * 64;
     static constexpr int STAGE_RS = KO_T * 4 + 16;                        // epilogue staging row (fp32 + pad)
     static constexpr int STAGE_BYTES = (PT / 2) * STAGE_RS;
-    static constexpr int RING_BYTES = 2 * A_BYTES + (SB_ ? 1 : 2) * B_BYTES;
+    static constexpr int RING_BYTES = 2 * A_BYTES + 2 * B_BYTES;
     static_assert(A_INSTR % NWAVE == 0, "KO_T must be a multiple of 128");
     static_assert(BI <= 6, "halo DMA is spread over the six DMA slots of a group");
     static_assert(STAGE_BYTES <= RING_BYTES, "the epilogue staging tile re-uses the DMA rings");
@@ -101,7 +98,6 @@ struct GldsParams {
     const void* zeros;    // >= 64 bytes of zeros in global memory (source of halo / dummy rows)
     const int* tab_src;   // [tile][NPOS]   activation row feeding each halo position, -1 = zero
     const int2* tab_pix;  // [tile][PT]     x = lpos | lstr << 16, y = output activation row (-1 = none)
-    unsigned long long* dbg;  // ABL & 16 only: s_memtime timeline [wg][wave][group][4]
 };
 
 // Per-tile index tables (shared by all layers of one forward).  One workgroup per pixel tile.
@@ -229,14 +225,9 @@ __device__ __forceinline__ void epi_store(const EpiRows<KO_T, PT, NW>& e, const 
     }
 }
 
-// ABL: timing-only ablation mask (never used by the engine proper): 1 = no weight DMA after the
-// first group, 2 = no halo DMA after the first chunk, 8 = no epilogue.
-// ABL & 2048 (a real variant, not an ablation): two workgroups per CU -- 128 registers per lane, the halo tile
-// single-buffered -- so that one workgroup's epilogue and group-start bubbles overlap the other's MFMAs.
-template <int WMT, int WNT, int ABL = 0, int WAVN_ = 4>
-__global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void conv_glds_kernel(const GldsParams gp) {
-    constexpr bool SB = (ABL & 2048) != 0;
-    using Cfg = GldsCfg<WMT, WNT, WAVN_, SB ? 1 : 0>;
+template <int WMT, int WNT>
+__global__ __launch_bounds__(512, 2) void conv_glds_kernel(const GldsParams gp) {
+    using Cfg = GldsCfg<WMT, WNT>;
     constexpr int KO_T = Cfg::KO_T, PT = Cfg::PT, WAVN = Cfg::WAVN, NWAVE = Cfg::NWAVE;
     constexpr int AI = Cfg::AI, BI = Cfg::BI, NPOS = Cfg::NPOS;
     const ConvParams& p = gp.c;
@@ -295,7 +286,7 @@ __global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void con
         for (int i = 0; i < AI; ++i) glds16(base + aoff[i], slot + adst[i]);
     };
     auto issue_b1 = [&](int chunk, int i) {
-        unsigned char* slot = Bring + (SB ? 0 : (chunk & 1)) * Cfg::B_BYTES;
+        unsigned char* slot = Bring + (chunk & 1) * Cfg::B_BYTES;
         const unsigned char* s = bsrc[i];
         if (s != (const unsigned char*)gp.zeros) s += (size_t)chunk * kChunk * 2;
         glds16(s, slot + bdst[i]);
@@ -315,36 +306,15 @@ __global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void con
     const int kg = lane >> 4;
     const int arow_off = (kg * KO_T + wave_m * WMT * 16 + (lane & 15)) * 16;
 
-    unsigned long long* dbg = nullptr;
-    if constexpr (ABL & 16) {
-        if (gp.dbg && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300)) {
-            dbg = gp.dbg + ((size_t)(blockIdx.x ? 1 : 0) * 8 + wave) * 32 * 4;
-            dbg[31 * 4 + 0] = __builtin_amdgcn_s_memtime();  // kernel-side start marker
-        }
-    }
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more_b = chunk + 1 < nchunks;
-        const unsigned char* Bc = Bring + (SB ? 0 : (chunk & 1)) * Cfg::B_BYTES + (size_t)kg * NPOS * 16;
+        const unsigned char* Bc = Bring + (chunk & 1) * Cfg::B_BYTES + (size_t)kg * NPOS * 16;
 #pragma unroll
         for (int row = 0; row < 3; ++row) {
             const int G = chunk * 3 + row;
-            unsigned long long t0 = 0, t1 = 0, t2 = 0;
-            if constexpr (ABL & 16) t0 = __builtin_amdgcn_s_memtime();
             // A(G) and B(chunk) were issued during the previous group and nothing after them.
-            if constexpr (!(ABL & 256)) wait_vmcnt<0>();
-            if constexpr (ABL & 16) t1 = __builtin_amdgcn_s_memtime();
-            if constexpr (!(ABL & 128)) __builtin_amdgcn_s_barrier();
-            if constexpr (SB) {
-                // every wave is done with the previous chunk's halo tile: reload it in place (the other workgroup of
-                // this CU has the matrix cores meanwhile)
-                if (row == 0 && chunk > 0) {
-#pragma unroll
-                    for (int i = 0; i < BI; ++i) issue_b1(chunk, i);
-                    wait_vmcnt<0>();
-                    __builtin_amdgcn_s_barrier();
-                }
-            }
-            if constexpr (ABL & 16) t2 = __builtin_amdgcn_s_memtime();
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
             const bool more_a = G + 1 < ngroups;
             const int dy = row - 1;
             // ---- software-pipelined fragment stream (hand-counted LDS queue) ----
@@ -369,30 +339,18 @@ __global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void con
                 constexpr int dx = q / WMT, i = q % WMT;
                 // DMA of the next group, front-loaded: block 0: tap 0 + halo piece 0, block WMT/2:
                 // tap 1, block WMT: tap 2 + halo piece 1, block 3*WMT/2: halo piece 2.
-                constexpr int SP = (ABL & 32) ? (WMT / 4 > 0 ? WMT / 4 : 1) : WMT / 2;  // DMA slot spacing
+                constexpr int SP = WMT / 2;  // DMA slot spacing
                 constexpr int NSLOT = BI > 3 ? 6 : 4;
                 if constexpr (q % SP == 0 && q / SP < NSLOT) {
                     constexpr int slot = q / SP;
                     // halo pieces: three or fewer go out at slots 0, 2, 3; more than three one per slot
                     constexpr int bpiece = BI > 3 ? slot : (slot == 0 ? 0 : slot == 2 ? 1 : slot == 3 ? 2 : -1);
                     constexpr int atap = slot < 3 ? slot : -1;
-                    if constexpr (!(ABL & 2) && !SB && bpiece >= 0 && bpiece < BI) {
+                    if constexpr (bpiece >= 0 && bpiece < BI) {
                         if (row == 0 && more_b) issue_b1(chunk + 1, bpiece);
                     }
-                    if constexpr (!(ABL & 1) && atap >= 0) {
+                    if constexpr (atap >= 0) {
                         if (more_a) issue_a(G + 1, atap);
-                    }
-                }
-                if constexpr ((ABL & 64) && q == NQ / 2) {
-                    // warm L2 / Infinity Cache with this tile's residual rows while the MFMAs run:
-                    // group G touches rows G*8+wave .. (PT rows total => PT/8 groups)
-                    if (p.res && G < PT / NWAVE) {
-                        const int grow = rowid[G * NWAVE + wave];
-                        if (grow >= 0) {
-                            const char* src = (const char*)p.res + ((size_t)grow * p.cout_s + kt * KO_T) * 2 + (lane % (KO_T / 8)) * 16;
-                            uint4 dummy;
-                            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dummy) : "v"(src) : "memory");
-                        }
                     }
                 }
                 if constexpr (i == IB && dx < 2) {
@@ -413,97 +371,7 @@ __global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void con
                 for (int j = 0; j < WNT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q % D], bfr[dx & 1][j], acc[i][j], 0, 0, 0);
             });
-            if constexpr (ABL & 16) {
-                if (dbg && G < 30) {
-                    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-                    dbg[G * 4 + 0] = t0; dbg[G * 4 + 1] = t1; dbg[G * 4 + 2] = t2; dbg[G * 4 + 3] = t3;
-                }
-            }
         }
-    }
-    if constexpr (ABL & 16) {
-        if (dbg) dbg[31 * 4 + 1] = __builtin_amdgcn_s_memtime();  // end of main loop
-    }
-
-    if constexpr (ABL & 8) {
-        if (acc[0][0][0] == 12345.678f) ((float*)p.out)[tid] = acc[1][1][1];
-        return;
-    }
-
-    if constexpr (ABL & 512) {
-        // ---- epilogue, register form: bias, residual and activation are applied to the accumulators where they are
-        // (the residual is fetched in accumulator layout, 8 bytes per lane), the fp16 result goes through LDS ONCE
-        // ([pixel][channel], half the bytes of the fp32 staging, one phase instead of two) and leaves as whole rows.
-        // Same arithmetic order as the staged form below (acc + bias, + residual, activation): bit-identical results.
-        constexpr int RS16 = KO_T * 2 + 16;
-        static_assert(PT * RS16 <= Cfg::RING_BYTES, "the fp16 staging tile re-uses the DMA rings");
-        unsigned char* st16 = smem;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // rowid visible, rings no longer read
-        const f16* __restrict__ gres = (const f16*)p.res;
-        int grow[WNT];
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) grow[j] = rowid[(wave_n * WNT + j) * 16 + (lane & 15)];
-        const int kol0 = wave_m * WMT * 16 + 4 * (lane >> 4);  // channel inside the tile of row tile i = kol0 + 16 i
-        auto fetch_res = [&](int i, f16x4 (&rr)[WNT]) {
-            const int ko = kt * KO_T + kol0 + i * 16;
-            const bool ok = ko < p.cout_s;  // cout_s is a multiple of 32: 4-channel groups never straddle it
-#pragma unroll
-            for (int j = 0; j < WNT; ++j)
-                rr[j] = (ok && grow[j] >= 0) ? *(const f16x4*)(gres + (size_t)grow[j] * p.cout_s + ko) : f16x4{0, 0, 0, 0};
-        };
-        auto body = [&](auto actc) {
-            constexpr int ACT = decltype(actc)::value;
-            f16x4 rcur[WNT], rnext[WNT];
-            if (gres) fetch_res(0, rcur);
-#pragma unroll
-            for (int i = 0; i < WMT; ++i) {
-                if (gres && i + 1 < WMT) fetch_res(i + 1, rnext);
-                const f32x4 bias = *(const f32x4*)(p.bias + kt * KO_T + kol0 + i * 16);
-#pragma unroll
-                for (int j = 0; j < WNT; ++j) {
-                    f32x4 v = acc[i][j] + bias;
-                    if (gres) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += (float)rcur[j][q];
-                    }
-                    f16x4 h;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) h[q] = (f16)activate(v[q], ACT);
-                    const int rl = (wave_n * WNT + j) * 16 + (lane & 15);
-                    *(f16x4*)(st16 + rl * RS16 + (kol0 + i * 16) * 2) = h;
-                }
-                if (gres && i + 1 < WMT) {
-#pragma unroll
-                    for (int j = 0; j < WNT; ++j) rcur[j] = rnext[j];
-                }
-            }
-        };
-        switch (p.act) {
-        case kMish: body(std::integral_constant<int, kMish>{}); break;
-        case kIdentity: body(std::integral_constant<int, kIdentity>{}); break;
-        case kReLU: body(std::integral_constant<int, kReLU>{}); break;
-        case kSwish: body(std::integral_constant<int, kSwish>{}); break;
-        case kELU: body(std::integral_constant<int, kELU>{}); break;
-        case kSELU: body(std::integral_constant<int, kSELU>{}); break;
-        case kGELU: body(std::integral_constant<int, kGELU>{}); break;
-        default: body(std::integral_constant<int, kHardSwish>{}); break;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // whole rows out: LPR lanes x 16 bytes per row
-        constexpr int LPR = KO_T / 8, RPI = 64 / LPR;
-        f16* __restrict__ gout = (f16*)p.out;
-        const int col = (lane % LPR) * 8, ko = kt * KO_T + col;
-        if (ko < p.cout_s) {
-#pragma unroll
-            for (int r0 = 0; r0 < PT; r0 += NWAVE * RPI) {
-                const int r = r0 + wave * RPI + lane / LPR;
-                const int g = rowid[r];
-                if (g >= 0) *(f16x8*)(gout + (size_t)g * p.cout_s + ko) = *(const f16x8*)(st16 + r * RS16 + col * 2);
-            }
-        }
-        return;
     }
 
     // ---- epilogue: fp32 accumulators (+ bias) -> LDS [pixel][channel], two phases of PT/2
@@ -523,9 +391,6 @@ __global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void con
 #pragma unroll
     for (int phase = 0; phase < 2; ++phase) {
         if (phase) lds_barrier();  // staging tile of the previous phase fully read
-        if constexpr (ABL & 16) {
-            if (dbg) dbg[(28 + phase) * 4 + 0] = __builtin_amdgcn_s_memtime();
-        }
         if ((wave_n / (WAVN / 2)) == phase) {
 #pragma unroll
             for (int i = 0; i < WMT; ++i) {
@@ -539,9 +404,6 @@ __global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void con
             }
         }
         lds_barrier();
-        if constexpr (ABL & 16) {
-            if (dbg) dbg[(28 + phase) * 4 + 1] = __builtin_amdgcn_s_memtime();
-        }
         const EpiRows<KO_T, PT, NWAVE>& rows = phase ? rows1 : rows0;
         switch (p.act) {
         case kMish: epi_store<kMish, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
@@ -553,12 +415,6 @@ __global__ __launch_bounds__(128 * WAVN_, (ABL & 2048) ? 4 : WAVN_ / 2) void con
         case kGELU: epi_store<kGELU, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
         default: epi_store<kHardSwish, KO_T, PT, NWAVE>(rows, gp, stage, kt, wave, lane); break;
         }
-        if constexpr (ABL & 16) {
-            if (dbg) dbg[(28 + phase) * 4 + 2] = __builtin_amdgcn_s_memtime();
-        }
-    }
-    if constexpr (ABL & 16) {
-        if (dbg) dbg[31 * 4 + 2] = __builtin_amdgcn_s_memtime();  // end of epilogue
     }
 }
 

@@ -23,12 +23,13 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "conv_glds.h"
-#include "conv_wino.h"
+#include "conv_board.h"
 #include "small_ops.h"
 
 namespace sayuri {
 
 static thread_local std::string g_err;
+static thread_local int g_test_conv_kind = 0;  // kernel family the last sayuri_hip_test_conv call ran: 0 generic, 1 glds, 2 board, 3 depthwise
 static int fail(const std::string& m) { g_err = m; return -1; }
 
 #define HIP_OK(expr)                                                                      \
@@ -77,77 +78,53 @@ template <> void register_all_convs<float>() {
     register_conv<float, 4, 2>();
 }
 
-// tuned fp16 3x3 kernels (conv_glds.h)
+// tuned fp16 3x3 kernels for any batch geometry (conv_glds.h): 192 / 128 / 64-pixel tiles across samples
 struct GldsEntry {
     int wmt, wnt;
     void (*fn)(const GldsParams);
     void (*setup)(BatchGeom, int*, int2*);
     size_t lds;
     int npos_cap, npos, pt;
-    int threads;  // workgroup size: 512 (two waves per SIMD) or 256 (one wave per SIMD, twice as wide register tiles)
-    bool two_wg = false;  // the two-workgroups-per-CU variant (single-buffered halo, 128 registers)
 };
 static std::vector<GldsEntry>& glds_entries() {
     static std::vector<GldsEntry> e;
     return e;
 }
-template <int WMT, int WNT, int WAVN = 4> static void register_glds() {
-    typedef GldsCfg<WMT, WNT, WAVN> Cfg;
-    glds_entries().push_back({WMT, WNT, &conv_glds_kernel<WMT, WNT, 0, WAVN>, &tile_setup_kernel<Cfg::PT, Cfg::NPOS>,
-                              Cfg::lds_bytes(), Cfg::NPOS_CAP, Cfg::NPOS, Cfg::PT, Cfg::NT});
+template <int WMT, int WNT> static void register_glds() {
+    typedef GldsCfg<WMT, WNT> Cfg;
+    glds_entries().push_back({WMT, WNT, &conv_glds_kernel<WMT, WNT>, &tile_setup_kernel<Cfg::PT, Cfg::NPOS>, Cfg::lds_bytes(),
+                              Cfg::NPOS_CAP, Cfg::NPOS, Cfg::PT});
 }
 static void register_all_glds() {
     if (!glds_entries().empty()) return;
     register_glds<8, 3>(); register_glds<8, 2>(); register_glds<8, 1>();
     register_glds<4, 3>(); register_glds<4, 2>(); register_glds<4, 1>();
-    register_glds<8, 6, 2>();  // four-wave variant of the <8,3> tile (same 256 x 192 workgroup tile and tile tables)
-    {   // two workgroups per CU: 128 x 192 tiles, 72.5 KiB of LDS and 128 registers each (SAYURI_CONV=glds2x)
-        typedef GldsCfg<4, 3, 4, 1> Cfg;
-        glds_entries().push_back({4, 3, &conv_glds_kernel<4, 3, 2048, 4>, &tile_setup_kernel<Cfg::PT, Cfg::NPOS>, Cfg::lds_bytes(),
-                                  Cfg::NPOS_CAP, Cfg::NPOS, Cfg::PT, Cfg::NT, true});
-    }
-    if (const char* epi = getenv("SAYURI_EPI")) {  // A/B switch: 2 = register-form epilogue (conv_glds.h, ABL bit 512)
-        if (atoi(epi) == 2) {
-            auto& e = glds_entries();
-            e[0].fn = &conv_glds_kernel<8, 3, 512, 4>; e[1].fn = &conv_glds_kernel<8, 2, 512, 4>; e[2].fn = &conv_glds_kernel<8, 1, 512, 4>;
-            e[3].fn = &conv_glds_kernel<4, 3, 512, 4>; e[4].fn = &conv_glds_kernel<4, 2, 512, 4>; e[5].fn = &conv_glds_kernel<4, 1, 512, 4>;
-        }
-    }
-    if (const char* abl = getenv("SAYURI_ABL")) {  // timing-only ablations of the <8,3> kernel
-        GldsEntry& e = glds_entries()[0];
-        switch (atoi(abl)) {
-        case 1: e.fn = &conv_glds_kernel<8, 3, 1>; break;
-        case 2: e.fn = &conv_glds_kernel<8, 3, 2>; break;
-        case 3: e.fn = &conv_glds_kernel<8, 3, 3>; break;
-        case 8: e.fn = &conv_glds_kernel<8, 3, 8>; break;
-        case 11: e.fn = &conv_glds_kernel<8, 3, 11>; break;
-        case 16: e.fn = &conv_glds_kernel<8, 3, 16>; break;
-        case 32: e.fn = &conv_glds_kernel<8, 3, 32>; break;
-        case 64: e.fn = &conv_glds_kernel<8, 3, 64>; break;
-        case 96: e.fn = &conv_glds_kernel<8, 3, 96>; break;
-        case 48: e.fn = &conv_glds_kernel<8, 3, 48>; break;
-        case 80: e.fn = &conv_glds_kernel<8, 3, 80>; break;
-        case 128: e.fn = &conv_glds_kernel<8, 3, 128>; break;  // timing only: no group barrier (wrong results)
-        case 384: e.fn = &conv_glds_kernel<8, 3, 384>; break;  // timing only: no group barrier, no DMA wait
-        default: break;
-        }
-    }
 }
+// one-workgroup-per-board kernels (conv_board.h), by output-channel tile
+typedef void (*BoardFn)(const BoardParams);
+struct BoardEntry { int kot; BoardFn fn; BoardFn fn_se; size_t (*lds)(int); };
+static const BoardEntry kBoardEntries[] = {
+    {256, &conv_board_kernel<4>, nullptr, &BoardCfg<4>::lds_bytes},
+    {192, &conv_board_kernel<3>, nullptr, &BoardCfg<3>::lds_bytes},
+    {128, &conv_board_kernel<2>, nullptr, &BoardCfg<2>::lds_bytes},
+};
 static void enable_big_lds_glds() {
     register_all_glds();
     for (const auto& e : glds_entries())
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    for (const auto& e : kBoardEntries) {
+        (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        if (e.fn_se) (void)hipFuncSetAttribute((const void*)e.fn_se, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    }
 }
-// SAYURI_CONV=v0 | glds[:wnt]   (tuning / A-B switch; default = glds, auto tile)
-struct ConvOverride { bool v0 = false; int wnt = 0; bool four_wave = false; bool two_wg = false; };
+// SAYURI_CONV=v0 | glds[:wnt] | board   (A/B switch for tests and tuning; default: board where it applies, else glds)
+struct ConvOverride { bool v0 = false, no_board = false; int wnt = 0; };
 static ConvOverride conv_override() {
     ConvOverride o;
     const char* e = getenv("SAYURI_CONV");
     if (!e) return o;
-    if (!strncmp(e, "v0", 2)) { o.v0 = true; return o; }
-    if (!strncmp(e, "glds4", 5)) { o.four_wave = true; return o; }
-    if (!strncmp(e, "glds2x", 6)) { o.two_wg = true; return o; }
-    if (!strncmp(e, "glds", 4)) (void)sscanf(e, "glds:%d", &o.wnt);
+    if (!strncmp(e, "v0", 2)) { o.v0 = true; o.no_board = true; return o; }
+    if (!strncmp(e, "glds", 4)) { o.no_board = true; (void)sscanf(e, "glds:%d", &o.wnt); }
     return o;
 }
 
@@ -212,15 +189,14 @@ struct HostGeom {
 // this batch geometry; nullptr when none applies (the generic conv_mfma kernel is used then).
 static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_out) {
     if (ko_pad % 128 != 0) return nullptr;
-    static const ConvOverride ov = conv_override();
+    const ConvOverride ov = conv_override();  // read per geometry change, so a test can switch it between pipes
     if (ov.v0) return nullptr;
-    const int wmt = (ko_pad % 256 == 0 && !ov.two_wg) ? 8 : 4;
+    const int wmt = ko_pad % 256 == 0 ? 8 : 4;
     const int kot_tiles = ko_pad / (wmt * 32);
     const GldsEntry* best = nullptr;
     double best_cost = 1e30;
     for (const auto& e : glds_entries()) {
-        if (e.wmt != wmt || e.two_wg != ov.two_wg) continue;
-        if ((e.threads == 256) != ov.four_wave && !(ov.four_wave && wmt != 8)) continue;
+        if (e.wmt != wmt) continue;
         if (ov.wnt && e.wnt != ov.wnt) continue;
         const int PT = e.pt;
         int npos, nsub;
@@ -234,111 +210,39 @@ static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_
     return best;
 }
 
-// ------------------------------------------------------------------ fused Winograd (conv_wino.h)
-// SAYURI_CONV=wino routes every fp16 3x3 layer whose batch geometry fits the kernel's raw-position budget through
-// conv_wino_kernel; anything else keeps the implicit-GEMM kernels.
-static bool wino_enabled() {  // read when an engine finalises its weights / per test_conv call
-    const char* e = getenv("SAYURI_CONV");
-    return e && !strncmp(e, "wino", 4);
-}
-struct WinoGeom { int blocks = 0, total_tiles = 0, max_pos = 0; bool fits = false; };
-static WinoGeom wino_geom(const HostGeom& geom) {
-    WinoGeom wg;
-    std::vector<int> toff(geom.n + 1, 0);
-    for (int i = 0; i < geom.n; ++i) {
-        const int tw = wino_tiles_per_side(geom.bsz[i]);
-        toff[i + 1] = toff[i] + tw * tw;
-    }
-    wg.total_tiles = toff[geom.n];
-    wg.blocks = (wg.total_tiles + WinoCfg::NTL - 1) / WinoCfg::NTL;
-    int s = 0, max_pos = 0, max_sub = 0;
-    for (int t0 = 0; t0 < wg.total_tiles; t0 += WinoCfg::NTL) {  // mirrors wino_setup_kernel
-        const int t1 = std::min(t0 + WinoCfg::NTL, wg.total_tiles);
-        while (s + 1 < geom.n && toff[s + 1] <= t0) ++s;
-        int pos = 0, sub = 0;
-        for (int m = s; m < geom.n && toff[m] < t1; ++m) {
-            const int tw = wino_tiles_per_side(geom.bsz[m]);
-            const int a = std::max(t0, toff[m]) - toff[m], b = std::min(t1, toff[m + 1]) - toff[m];
-            const int rows = 2 * ((b - 1) / tw - a / tw + 1) + 2;
-            pos += rows * wino_pitch(tw);
-            ++sub;
+// The one-workgroup-per-board plan of a batch geometry (conv_board.h): consecutive samples packed greedily.
+struct BoardPlan { int ntiles = 0, npos = 0; bool ok = false; double fill = 0; };
+static BoardPlan board_plan(const HostGeom& geom) {
+    BoardPlan bp;
+    const ConvOverride ov = conv_override();
+    if (ov.no_board || geom.n <= 0) return bp;
+    BoardPack pk;
+    int max_pos = 0;
+    for (int s = 0; s < geom.n; ++s) {
+        const int bs = geom.bsz[s];
+        if (!BoardPack{}.fits(bs)) return bp;  // a board that does not fit a tile on its own
+        if (pk.cnt > 0 && !pk.fits(bs)) {
+            max_pos = std::max(max_pos, pk.pos);
+            ++bp.ntiles;
+            pk = BoardPack{};
         }
-        max_pos = std::max(max_pos, pos);
-        max_sub = std::max(max_sub, sub);
+        pk.add(bs);
     }
-    // a dummy tile of the last block reads the 4x4 patch at position 0 of the first subregion: always inside NPOS
-    wg.max_pos = max_pos;
-    wg.fits = wg.total_tiles > 0 && max_pos <= WinoCfg::NPOS && max_sub <= kMaxSub;
-    return wg;
+    max_pos = std::max(max_pos, pk.pos);
+    ++bp.ntiles;
+    bp.npos = round_up(max_pos, 64);
+    bp.fill = (double)geom.total / ((double)bp.ntiles * kBoardPT);
+    bp.ok = true;
+    return bp;
 }
-// U = G g G^T per (output channel, input channel), in the fragment order conv_wino_kernel loads:
-// [kt][chunk][xi][nu][m][lane][8] with ko = kt*64 + m*16 + (lane & 15), c = chunk*32 + (lane >> 4)*8 + e.
-static std::vector<f16> wino_image(const float* w, int cin, int cout, int cin_s, int ko_pad) {
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    const int nch = cin_s / 32, kts = ko_pad / WinoCfg::KO_T;
-    std::vector<f16> img((size_t)ko_pad * cin_s * 16, (f16)0.f);
-    for (int ko = 0; ko < cout; ++ko)
-        for (int c = 0; c < cin; ++c) {
-            const float* g = w + ((size_t)ko * cin + c) * 9;
-            double tmp[4][3];
-            for (int x = 0; x < 4; ++x)
-                for (int sct = 0; sct < 3; ++sct)
-                    tmp[x][sct] = G[x][0] * g[0 * 3 + sct] + G[x][1] * g[1 * 3 + sct] + G[x][2] * g[2 * 3 + sct];
-            const int kt = ko / WinoCfg::KO_T, m = (ko % WinoCfg::KO_T) / 16, row = ko % 16;
-            const int chunk = c / 32, kgq = (c % 32) / 8, e = c % 8;
-            const int lane = kgq * 16 + row;
-            for (int x = 0; x < 4; ++x)
-                for (int nu = 0; nu < 4; ++nu) {
-                    const double u = tmp[x][0] * G[nu][0] + tmp[x][1] * G[nu][1] + tmp[x][2] * G[nu][2];
-                    const size_t frag = ((((size_t)kt * nch + chunk) * 4 + x) * 4 + nu) * 4 + m;
-                    img[frag * 512 + (size_t)lane * 8 + e] = (f16)(float)u;
-                }
+static const BoardEntry* pick_board(const BoardPlan& bp, int ko_pad, int* kot_tiles) {
+    if (!bp.ok) return nullptr;
+    for (const auto& e : kBoardEntries)
+        if (ko_pad % e.kot == 0 && e.lds(bp.npos) <= kMaxLds) {
+            *kot_tiles = ko_pad / e.kot;
+            return &e;
         }
-    (void)kts;
-    return img;
-}
-typedef void (*WinoFn)(const WinoParams);
-// the kernel is instantiated per input width (cin_s / 32 chunks, K loop fully unrolled) and per raw-image size
-// (6 or 8 DMA instructions of 64 positions per wave and chunk)
-template <int BI> static WinoFn wino_kernel_bi(int nchunks) {
-    switch (nchunks) {
-    case 2: return &conv_wino_kernel<2, BI>;
-    case 3: return &conv_wino_kernel<3, BI>;
-    case 4: return &conv_wino_kernel<4, BI>;
-    case 6: return &conv_wino_kernel<6, BI>;
-    case 8: return &conv_wino_kernel<8, BI>;
-    case 12: return &conv_wino_kernel<12, BI>;
-    default: return nullptr;
-    }
-}
-template <int DI> static WinoFn wino8_kernel_di(int nchunks) {
-    switch (nchunks) {
-    case 2: return &conv_wino8_kernel<2, DI>;
-    case 3: return &conv_wino8_kernel<3, DI>;
-    case 4: return &conv_wino8_kernel<4, DI>;
-    case 6: return &conv_wino8_kernel<6, DI>;
-    case 8: return &conv_wino8_kernel<8, DI>;
-    case 12: return &conv_wino8_kernel<12, DI>;
-    default: return nullptr;
-    }
-}
-// SAYURI_CONV=wino8: the eight-wave variant (two waves per SIMD)
-static bool wino_eight() {
-    const char* e = getenv("SAYURI_CONV");
-    return e && !strncmp(e, "wino8", 5);
-}
-struct WinoLaunch { WinoFn fn; int threads; size_t lds; };
-static WinoLaunch wino_kernel_for(int nchunks, int max_pos = WinoCfg::NPOS, bool eight = false) {
-    if (eight)
-        return {max_pos <= 6 * 64 ? wino8_kernel_di<3>(nchunks) : wino8_kernel_di<4>(nchunks), Wino8Cfg::NT, Wino8Cfg::lds_bytes()};
-    return {max_pos <= 6 * 64 ? wino_kernel_bi<6>(nchunks) : wino_kernel_bi<8>(nchunks), WinoCfg::NT, WinoCfg::lds_bytes()};
-}
-static void enable_big_lds_wino() {
-    for (int nch : {2, 3, 4, 6, 8, 12})
-        for (int mp : {6 * 64, 8 * 64})
-            for (bool eight : {false, true})
-                (void)hipFuncSetAttribute((const void*)wino_kernel_for(nch, mp, eight).fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)kMaxLds);
+    return nullptr;
 }
 
 struct Stat {
@@ -356,8 +260,6 @@ struct ConvLayerDev {
     void* w = nullptr;      // MFMA image, or [k*k][cs] fp32 for depthwise
     float* bias = nullptr;  // [ko_pad] / [cs]
     float* w32 = nullptr;   // plain fp32 copy [cout][cin] for the tiny head convs
-    void* wino = nullptr;   // Winograd image (conv_wino.h) of an fp16 3x3 layer, when that kernel is enabled
-    int wino_ko_pad = 0;
 };
 struct FcLayerDev {
     int in = 0, out = 0;
@@ -389,7 +291,7 @@ public:
 template <typename T> class Engine : public EngineBase {
 public:
     struct TileTabs { int* src = nullptr; int2* pix = nullptr; bool fresh = false; };
-    struct WinoTabs { int *tile_off = nullptr, *src = nullptr, *tile = nullptr, *out = nullptr; bool fresh = false; };
+    struct BoardTabs { int* src = nullptr; int2* pix = nullptr; int* cols = nullptr; int npos_built = 0; bool fresh = false; };
     Engine(int device, const sayuri_hip_netdesc& d, int max_batch, int board)
         : device_(device), desc_(d), max_batch_(max_batch), board_(board) {
         blocks_.assign(d.blocks, d.blocks + d.residual_blocks);
@@ -417,7 +319,7 @@ public:
         HIP_OK(hipEventCreate(&ev0_));
         HIP_OK(hipEventCreate(&ev1_));
         enable_big_lds<T>();
-        if (sizeof(T) == 2) { enable_big_lds_glds(); enable_big_lds_wino(); }
+        if (sizeof(T) == 2) enable_big_lds_glds();
         return describe_layers();
     }
 
@@ -525,12 +427,12 @@ public:
         if (geom_.bsz != prev_bsz_) {  // tile choices and index tables depend on the geometry only
             tile_cache_.clear();
             glds_cache_.clear();
-            wino_geom_valid_ = false;
+            board_plan_valid_ = false;
         }
         IoSlot& slot = io_[cur_slot_];
         if (slot.tabs_bsz != geom_.bsz) {  // this slot's tables were built for another geometry
             for (auto& kv : slot.tabs) kv.second.fresh = false;
-            slot.wino.fresh = false;
+            slot.board.fresh = false;
             slot.tabs_bsz = geom_.bsz;
         }
         int* hg = h_geom_ + (size_t)geom_slot_ * (2 * max_batch_ + 1);
@@ -614,56 +516,6 @@ public:
         const int rc = forward();
         profiling_ = false;
         if (rc) return -1;
-        if (d_wdbg_) {  // SAYURI_WINO_DBG: s_memtime timeline of the last tower conv (first 64 workgroups)
-            std::vector<unsigned long long> h(64 * 4 * 16);
-            HIP_OK(hipMemcpy(h.data(), d_wdbg_, h.size() * 8, hipMemcpyDeviceToHost));
-            double sum[16] = {};
-            for (int wg = 0; wg < 64; ++wg) {
-                const unsigned long long* d = &h[(size_t)wg * 4 * 16];
-                for (int k = 1; k <= 12; ++k) sum[k] += (double)(d[k] - d[0]);
-            }
-            fprintf(stderr, "[wino timeline, mean over 64 wgs, wave 0, cycles since start]\n");
-            const char* nm[13] = {"", "tables+first issue", "first barrier", "chunk1", "chunk2", "chunk3", "chunk4", "chunk5",
-                                  "chunk6", "sum of weight waits", "loop end", "Z staged (wino8: b=1 staged)", "end"};
-            for (int k = 1; k <= 12; ++k) fprintf(stderr, "  %-20s %9.0f\n", nm[k], sum[k] / 64);
-            {
-                double a = 0, b = 0, c = 0;
-                for (int wg = 0; wg < 64; ++wg) {
-                    const unsigned long long* d = &h[(size_t)wg * 4 * 16];
-                    a += (double)(d[13] - d[5]); b += (double)(d[14] - d[13]); c += (double)(d[15] - d[14]);
-                }
-                fprintf(stderr, "  chunk3->4: compute %.0f, vmcnt wait %.0f, barrier %.0f\n", a / 64, b / 64, c / 64);
-            }
-            if (wino_eight_) {  // wino8: slots 9, 13, 14, 15, 8 hold per-wave sums of wait cycles
-                double w[5] = {};
-                for (int wg = 0; wg < 64; ++wg) {
-                    const unsigned long long* d = &h[(size_t)wg * 4 * 16];
-                    w[0] += (double)d[9]; w[1] += (double)d[13]; w[2] += (double)d[14]; w[3] += (double)d[15]; w[4] += (double)d[8];
-                }
-                fprintf(stderr, "  wino8 K-loop sums per wave: DMA wait %.0f, barrier %.0f, issue next loads %.0f, weight wait %.0f, patch waits %.0f\n",
-                        w[0] / 64, w[1] / 64, w[2] / 64, w[3] / 64, w[4] / 64);
-            }
-            const unsigned long long* d0 = &h[0];
-            fprintf(stderr, "  wg0 waves end: %llu %llu %llu %llu\n", d0[12] - d0[0], d0[16 + 12] - d0[0], d0[32 + 12] - d0[0], d0[48 + 12] - d0[0]);
-        }
-        if (d_dbg_) {  // SAYURI_ABL=16: print the s_memtime timeline of the last tower conv
-            std::vector<unsigned long long> h(2 * 8 * 32 * 4);
-            HIP_OK(hipMemcpy(h.data(), d_dbg_, h.size() * 8, hipMemcpyDeviceToHost));
-            for (int wg = 0; wg < 2; ++wg)
-                for (int w = 0; w < 8; w += 4) {
-                    const unsigned long long* d = &h[((size_t)wg * 8 + w) * 32 * 4];
-                    const unsigned long long base = d[31 * 4 + 0];
-                    fprintf(stderr, "[timeline wg%d wave%d] loop_end=%llu epi_end=%llu\n", wg, w, d[31 * 4 + 1] - base,
-                            d[31 * 4 + 2] - base);
-                    for (int ph = 0; ph < 2; ++ph)
-                        fprintf(stderr, "  epilogue phase %d: sync0 @%llu  staged+sync1 +%llu  rows done +%llu\n", ph,
-                                d[(28 + ph) * 4] - base, d[(28 + ph) * 4 + 1] - d[(28 + ph) * 4],
-                                d[(28 + ph) * 4 + 2] - d[(28 + ph) * 4 + 1]);
-                    for (int G = 0; G < 24; ++G)
-                        fprintf(stderr, "  G%02d start=%7llu vmwait=%5llu barrier=%5llu body=%5llu\n", G, d[G * 4] - base,
-                                d[G * 4 + 1] - d[G * 4], d[G * 4 + 2] - d[G * 4 + 1], d[G * 4 + 3] - d[G * 4 + 2]);
-                }
-        }
         int i = 0;
         for (auto& kv : stats_) {
             if (i >= cap) break;
@@ -815,14 +667,6 @@ private:
                 T* w = nullptr;
                 if (dev_upload(&w, img) || dev_upload(&L.bias, b)) return -1;
                 L.w = w;
-                if (sizeof(T) == 2 && L.k == 3 && wino_enabled() && wino_kernel_for(L.cin_s / 32).fn) {
-                    L.wino_ko_pad = round_up(L.cout_s, WinoCfg::KO_T);
-                    if ((int)b.size() < L.wino_ko_pad) return fail("winograd: bias image shorter than the channel tiles");
-                    const std::vector<f16> wimg = wino_image(L.hw.data(), L.cin, L.cout, L.cin_s, L.wino_ko_pad);
-                    f16* dw = nullptr;
-                    if (dev_upload(&dw, wimg)) return -1;
-                    L.wino = dw;
-                }
             }
             std::vector<float>().swap(L.hw);
             std::vector<float>().swap(L.hb);
@@ -842,8 +686,8 @@ private:
         const size_t act_elems = (size_t)max_batch_ * slot_pix_ * cs_max_;
         for (IoSlot& io : io_)
             for (int i = 0; i < kNumBufs; ++i)
-                // every activation buffer starts kZeroPrefix bytes into its (zero-filled) allocation: conv_wino.h reads
-                // its halo from that prefix
+                // every activation buffer starts kZeroPrefix bytes into its (zero-filled) allocation: conv_board.h reads
+                // its halo cells from that prefix
                 if (dev_alloc(&io.bufs[i], act_elems + kZeroPrefix / sizeof(T))) return -1;
                 else io.bufs[i] += kZeroPrefix / sizeof(T);
         const size_t B2 = (size_t)board_ * board_;
@@ -989,58 +833,53 @@ private:
         return it->second.e ? &it->second : nullptr;
     }
 
-    // index tables of the current batch geometry for conv_wino_kernel (built on first use)
-    int wino_tabs(const WinoTabs** out) {
-        WinoTabs& t = io_[cur_slot_].wino;
+    // index tables of the current batch geometry for conv_board_kernel (built on first use)
+    int board_tabs(const BoardTabs** out) {
+        BoardTabs& t = io_[cur_slot_].board;
         if (!t.src) {
-            const int tw = wino_tiles_per_side(board_);
-            const size_t max_blocks = ((size_t)max_batch_ * tw * tw + WinoCfg::NTL - 1) / WinoCfg::NTL;
-            if (dev_alloc(&t.tile_off, max_batch_ + 1) || dev_alloc(&t.src, max_blocks * WinoCfg::NPOS) ||
-                dev_alloc(&t.tile, max_blocks * WinoCfg::NTL) || dev_alloc(&t.out, max_blocks * WinoCfg::NTL * 4))
+            // a tile holds at least one sample
+            if (dev_alloc(&t.src, (size_t)max_batch_ * kBoardMaxPos) || dev_alloc(&t.pix, (size_t)max_batch_ * kBoardPT) ||
+                dev_alloc(&t.cols, max_batch_))
                 return -1;
         }
-        if (!t.fresh) {
-            hipLaunchKernelGGL(wino_prefix_kernel, dim3(1), dim3(1024), 0, stream_, dgeom(), t.tile_off);
-            hipLaunchKernelGGL(wino_setup_kernel, dim3(wino_geom_.blocks), dim3(256), 0, stream_, dgeom(),
-                               (const int*)t.tile_off, wino_geom_.total_tiles, t.src, t.tile, t.out);
+        if (!t.fresh || t.npos_built != board_plan_.npos) {
+            hipLaunchKernelGGL(board_setup_kernel, dim3(board_plan_.ntiles), dim3(256), 0, stream_, dgeom(), board_plan_.npos, t.src,
+                               t.pix, t.cols);
             HIP_OK(hipGetLastError());
             t.fresh = true;
+            t.npos_built = board_plan_.npos;
         }
         *out = &t;
         return 0;
     }
-    bool use_wino(const ConvLayerDev& L) {
-        if (!L.wino) return false;
-        if (!wino_geom_valid_) { wino_geom_ = wino_geom(geom_); wino_geom_valid_ = true; }
-        return wino_geom_.fits;
+    // the one-workgroup-per-board kernel applies to fp16 3x3 layers whose boards fit a tile and fill it reasonably
+    const BoardEntry* choose_board(const ConvLayerDev& L, int* kot_tiles) {
+        if (sizeof(T) != 2 || L.k != 3) return nullptr;
+        if (!board_plan_valid_) { board_plan_ = board_plan(geom_); board_plan_valid_ = true; }
+        if (!board_plan_.ok || board_plan_.fill < 0.55) return nullptr;
+        return pick_board(board_plan_, L.ko_pad, kot_tiles);
     }
 
     int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
-        if (use_wino(L)) {
-            const WinoTabs* tabs = nullptr;
-            if (wino_tabs(&tabs)) return -1;
-            WinoParams wp;
-            wp.tab_src = tabs->src; wp.tab_tile = tabs->tile; wp.tab_out = tabs->out;
-            wp.num_blocks = wino_geom_.blocks;
-            wp.zeros = d_zeros_;
-            wp.dbg = nullptr;
-            if (getenv("SAYURI_WINO_DBG") && !strcmp(name, "conv3x3_tower")) {
-                if (!d_wdbg_ && dev_alloc(&d_wdbg_, 64 * 4 * 16)) return -1;
-                wp.dbg = d_wdbg_;
-            }
-            ConvParams& p = wp.c;
-            p.in = in; p.w = L.wino; p.bias = L.bias; p.res = res; p.out = out;
+        int bkt = 0;
+        if (const BoardEntry* be = choose_board(L, &bkt)) {
+            const BoardTabs* tabs = nullptr;
+            if (board_tabs(&tabs)) return -1;
+            BoardParams bp;
+            bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos;
+            ConvParams& p = bp.c;
+            p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
             p.g = dgeom();
-            p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.wino_ko_pad;
-            p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = wino_geom_.blocks;
+            p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
+            p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = board_plan_.ntiles;
+            { static const char* na = getenv("SAYURI_ACT_OVERRIDE"); if (na) p.act = atoi(na); }  // timing experiments only
             const double px = geom_.total;
-            const double flops = 2.0 * px * L.cin * L.cout * 9;  // algorithmic (direct-form) count
-            const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 16);
-            const int grid = round_up(wino_geom_.blocks, 8) * (L.wino_ko_pad / WinoCfg::KO_T);
-            const WinoLaunch wl = wino_kernel_for(L.cin_s / 32, wino_geom_.max_pos, wino_eight_);
-            return timed(name, flops, bytes, [&] {
-                hipLaunchKernelGGL(wl.fn, dim3(grid), dim3(wl.threads), wl.lds, stream_, wp);
-            });
+            const double flops = 2.0 * px * L.cin * L.cout * 9;
+            const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
+            const auto fn = be->fn;
+            const size_t lds = be->lds(board_plan_.npos);
+            const int grid = board_plan_.ntiles * bkt;
+            return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, bp); });
         }
         if (const GldsChoice* gc = choose_glds(L)) {
             const TileTabs* tabs = nullptr;
@@ -1048,11 +887,6 @@ private:
             GldsParams gp;
             gp.tab_src = tabs->src;
             gp.tab_pix = tabs->pix;
-            gp.dbg = nullptr;
-            if (getenv("SAYURI_ABL") && atoi(getenv("SAYURI_ABL")) == 16 && !strcmp(name, "conv3x3_tower")) {
-                if (!d_dbg_ && dev_alloc(&d_dbg_, 2 * 8 * 32 * 4)) return -1;
-                gp.dbg = d_dbg_;
-            }
             ConvParams& p = gp.c;
             p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
             p.g = dgeom();
@@ -1065,9 +899,8 @@ private:
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
             const auto fn = gc->e->fn;
             const size_t lds = gc->e->lds;
-            const int threads = gc->e->threads;
             const int grid = gc->ntiles * (L.ko_pad / (gc->e->wmt * 32));
-            return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, stream_, gp); });
+            return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, gp); });
         }
         const int kot = L.wmt * 32, kot_tiles = L.ko_pad / kot;
         TileChoice tc;
@@ -1256,7 +1089,7 @@ private:
         T* bufs[kNumBufs] = {};
         float *gate = nullptr, *separt = nullptr;
         std::map<int, TileTabs> tabs;   // index tables of the geometry this slot last ran (keyed by tile variant)
-        WinoTabs wino;
+        BoardTabs board;
         std::vector<int> tabs_bsz;
     };
     IoSlot io_[2];
@@ -1279,17 +1112,14 @@ private:
           *d_own_ = nullptr;
     int *d_off_ = nullptr, *d_bsz_ = nullptr;
     float* d_zeros_ = nullptr;
-    unsigned long long* d_dbg_ = nullptr;
-    unsigned long long* d_wdbg_ = nullptr;
     int* h_geom_ = nullptr;  // pinned 2-slot ring: [slot][off(max_batch+1) | bsz(max_batch)]
     int geom_slot_ = 0, next_ticket_ = 0;
     hipEvent_t tick_ev_[2] = {nullptr, nullptr};
     HostGeom geom_;
     std::vector<int> prev_bsz_;
     std::map<int, GldsChoice> glds_cache_;
-    WinoGeom wino_geom_;
-    bool wino_geom_valid_ = false;
-    const bool wino_eight_ = wino_eight();
+    BoardPlan board_plan_;
+    bool board_plan_valid_ = false;
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;
     // light per-launch timing of one kernel class inside time_runs()
@@ -1461,7 +1291,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
     const int xin_c = depthwise ? cout : cin;
     std::vector<T> hx = to_nhwc(x, xin_c, cin_s);
     T* dx = (T*)dalloc(hx.size() * sizeof(T) + kZeroPrefix);
-    if (dx) dx += kZeroPrefix / sizeof(T);  // conv_wino.h reads its halo from a zero prefix in front of the activations
+    if (dx) dx += kZeroPrefix / sizeof(T);  // conv_board.h reads its halo cells from a zero prefix in front of the activations
     T* dy = (T*)dalloc((size_t)n * slot * cout_s * sizeof(T));
     T* dres = nullptr;
     if (!dx || !dy) { cleanup(); return fail("test_conv: hipMalloc failed"); }
@@ -1479,6 +1309,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
     const BatchGeom g{d_off, d_bsz, n, hg.total, slot};
 
     if (depthwise) {
+        g_test_conv_kind = 3;
         const int kk = k * k;
         std::vector<float> wt((size_t)kk * cout_s, 0.f), b(cout_s, 0.f);
         for (int c = 0; c < cout; ++c) {
@@ -1516,42 +1347,32 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         HIP_OK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
         int g_ntiles = 0;
         const GldsEntry* ge = nullptr;
-        bool wino_done = false;
-        if (sizeof(T) == 2 && k == 3 && wino_enabled() && wino_kernel_for(cin_s / 32).fn) {
-            const WinoGeom wg = wino_geom(hg);
-            if (wg.fits) {
-                enable_big_lds_wino();
-                const int wko = round_up(cout_s, WinoCfg::KO_T);
-                const std::vector<f16> wimg = wino_image(w, cin, cout, cin_s, wko);
-                std::vector<float> wb(wko, 0.f);
-                if (bias) std::copy(bias, bias + cout, wb.begin());
-                f16* dwi = (f16*)dalloc(wimg.size() * 2);
-                float* dwb = (float*)dalloc(wb.size() * 4);
-                float* dz = (float*)dalloc(256);
-                int* toff = (int*)dalloc(sizeof(int) * (n + 1));
-                int* tsrc = (int*)dalloc(sizeof(int) * (size_t)wg.blocks * WinoCfg::NPOS);
-                int* ttile = (int*)dalloc(sizeof(int) * (size_t)wg.blocks * WinoCfg::NTL);
-                int* tout = (int*)dalloc(sizeof(int) * (size_t)wg.blocks * WinoCfg::NTL * 4);
-                if (!dwi || !dwb || !dz || !toff || !tsrc || !ttile || !tout) { cleanup(); return fail("test_conv: hipMalloc failed"); }
-                HIP_OK(hipMemcpy(dwi, wimg.data(), wimg.size() * 2, hipMemcpyHostToDevice));
-                HIP_OK(hipMemcpy(dwb, wb.data(), wb.size() * 4, hipMemcpyHostToDevice));
-                hipLaunchKernelGGL(wino_prefix_kernel, dim3(1), dim3(1024), 0, 0, g, toff);
-                hipLaunchKernelGGL(wino_setup_kernel, dim3(wg.blocks), dim3(256), 0, 0, g, (const int*)toff, wg.total_tiles,
-                                   tsrc, ttile, tout);
-                WinoParams wp;
-                wp.tab_src = tsrc; wp.tab_tile = ttile; wp.tab_out = tout; wp.num_blocks = wg.blocks; wp.zeros = dz; wp.dbg = nullptr;
-                ConvParams& p = wp.c;
-                p.in = dx; p.w = dwi; p.bias = dwb; p.res = dres; p.out = dy; p.g = g;
-                p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = wko; p.taps = 9; p.act = act; p.npos = 0;
-                p.num_pix_tiles = wg.blocks;
-                const WinoLaunch wl = wino_kernel_for(cin_s / 32, wg.max_pos, wino_eight());
-                hipLaunchKernelGGL(wl.fn, dim3(round_up(wg.blocks, 8) * (wko / WinoCfg::KO_T)), dim3(wl.threads), wl.lds, 0, wp);
+        bool board_done = false;
+        if (sizeof(T) == 2 && k == 3) {
+            enable_big_lds_glds();
+            const BoardPlan plan = board_plan(hg);
+            int kot_tiles = 0;
+            const BoardEntry* be = plan.fill >= 0.55 ? pick_board(plan, ko_pad, &kot_tiles) : nullptr;
+            if (be) {
+                int* tsrc = (int*)dalloc(sizeof(int) * (size_t)plan.ntiles * plan.npos);
+                int2* tpix = (int2*)dalloc(sizeof(int2) * (size_t)plan.ntiles * kBoardPT);
+                int* tcols = (int*)dalloc(sizeof(int) * (size_t)plan.ntiles);
+                if (!tsrc || !tpix || !tcols) { cleanup(); return fail("test_conv: hipMalloc failed"); }
+                hipLaunchKernelGGL(board_setup_kernel, dim3(plan.ntiles), dim3(256), 0, 0, g, plan.npos, tsrc, tpix, tcols);
+                BoardParams bp;
+                bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos;
+                ConvParams& p = bp.c;
+                p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
+                p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;
+                p.num_pix_tiles = plan.ntiles;
+                hipLaunchKernelGGL(be->fn, dim3(plan.ntiles * kot_tiles), dim3(512), be->lds(plan.npos), 0, bp);
                 HIP_OK(hipGetLastError());
                 HIP_OK(hipDeviceSynchronize());
-                wino_done = true;
+                board_done = true;
+                g_test_conv_kind = 2;
             }
         }
-        if (sizeof(T) == 2 && k == 3 && !wino_done) {
+        if (sizeof(T) == 2 && k == 3 && !board_done) {
             enable_big_lds_glds();
             ge = pick_glds(hg, ko_pad, &g_ntiles);
         }
@@ -1564,28 +1385,29 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
             GldsParams gp;
             gp.tab_src = tsrc;
             gp.tab_pix = tpix;
-            gp.dbg = nullptr;
             ConvParams& p = gp.c;
             p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
             p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;
             p.num_pix_tiles = g_ntiles;
             gp.zeros = dz;
-            hipLaunchKernelGGL(ge->fn, dim3(g_ntiles * (ko_pad / (ge->wmt * 32))), dim3(ge->threads), ge->lds, 0, gp);
+            hipLaunchKernelGGL(ge->fn, dim3(g_ntiles * (ko_pad / (ge->wmt * 32))), dim3(512), ge->lds, 0, gp);
+            g_test_conv_kind = 1;
             HIP_OK(hipGetLastError());
             HIP_OK(hipDeviceSynchronize());
         }
         const typename ConvKernelTable<T>::Entry* best = nullptr;
         int best_npos = 0;
         for (const auto& e : ConvKernelTable<T>::entries()) {
-            if (ge || wino_done) break;
+            if (ge || board_done) break;
             if (e.wmt != wmt) continue;
             int npos, nsub;
             hg.tile_bounds(64 * e.wnt, &npos, &nsub);
             if (npos > e.npos_cap || nsub > kMaxSub || e.lds(npos) > kMaxLds) continue;
             if (!best || e.wnt > best->wnt) { best = &e; best_npos = npos; }
         }
-        if (!best && !ge && !wino_done) { cleanup(); return fail("test_conv: no tile configuration fits"); }
+        if (!best && !ge && !board_done) { cleanup(); return fail("test_conv: no tile configuration fits"); }
         if (best) {
+        g_test_conv_kind = 0;
         ConvParams p;
         p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
         p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = taps; p.act = act;
@@ -1611,6 +1433,8 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
 }
 
 }  // namespace sayuri
+
+extern "C" int sayuri_hip_test_last_conv_kind(void) { return sayuri::g_test_conv_kind; }
 
 extern "C" int sayuri_hip_test_conv(int device, int use_fp16, int n, const int* board_sizes, int max_board, int cin,
                                     int cout, int k, int depthwise, int act, int post_residual, const float* x,

@@ -166,6 +166,7 @@ void HipForwardPipe::Construct(ForwardPipeOption option, std::shared_ptr<DNNWeig
     if (board <= 0 || batch <= 0) return;
     if (board > kBoardSize) throw std::runtime_error("NN board size exceeds MAX_BOARD_SIZE");
     cfg_.batch_size = batch;  // forwarding size of the collector (SetForwardingSize)
+    forward_size_.store(batch, std::memory_order_release);  // the pump and Reserve() read this one (the pump may be running)
     if (board_size_ == board && batch <= max_batch_ && !graphs_.empty() && !weights) return;
     Release();
     board_size_ = board;
@@ -375,7 +376,8 @@ void HipForwardPipe::PumpLoop(Graph* g) {
     constexpr int K = Graph::kSets;
     auto count = [](const Staging& s) { return s.reserved.load(std::memory_order_acquire) & ~Staging::kClosed; };
     auto closed = [](const Staging& s) { return (s.reserved.load(std::memory_order_acquire) & Staging::kClosed) != 0; };
-    const unsigned want = static_cast<unsigned>(std::min(cfg_.batch_size, max_batch_));
+    // forwarding size, read live: Construct() may lower it while the pump runs (no rebuild)
+    auto want_now = [this] { return static_cast<unsigned>(std::min(forward_size_.load(std::memory_order_acquire), max_batch_)); };
     int cur = 0;              // set currently filling
     int pending[K], n_pending = 0, pending_n[K];  // closed sets (and their sizes) waiting for a GPU slot, FIFO
     int inflight[2], n_in = 0;                    // FIFO of sets on the GPU
@@ -401,12 +403,33 @@ void HipForwardPipe::PumpLoop(Graph* g) {
             s.reserved.store(0, std::memory_order_release);
             return;
         }
-        if (static_cast<unsigned>(n) < want) pump_ns_[5] += 1000;  // counts partial batches (reported /1000)
+        if (static_cast<unsigned>(n) < want_now()) pump_ns_[5] += 1000;  // counts partial batches (reported /1000)
         pending[n_pending] = cur;
         pending_n[n_pending++] = n;
         cur = (cur + 1) % K;
         g->fill.store(cur, std::memory_order_release);
         wake_callers();
+    };
+    // A caller that read `fill`, was preempted, and resumed after that set had been closed, evaluated and re-opened
+    // finds `reserved` == 0 there and takes a slot in a set that is no longer the fill set.  Such a set is open, not
+    // `cur`, and holds requests: close it where it stands and queue it like any other batch (the fill index does not
+    // move).  Without this the request would wait until the ring wraps around to its set -- forever once traffic stops.
+    auto close_strays = [&] {
+        bool any = false;
+        for (int k = 0; k < K && n_pending < K; ++k) {
+            if (k == cur) continue;
+            Staging& s = g->st[k];
+            const unsigned seen = s.reserved.load(std::memory_order_acquire);
+            if ((seen & Staging::kClosed) || seen == 0) continue;
+            const unsigned prev = s.reserved.fetch_or(Staging::kClosed, std::memory_order_acq_rel);
+            const int n = static_cast<int>(std::min<unsigned>(prev & ~Staging::kClosed, static_cast<unsigned>(max_batch_)));
+            if (n == 0) { s.reserved.store(0, std::memory_order_release); continue; }
+            pump_ns_[5] += 1000;
+            pending[n_pending] = k;
+            pending_n[n_pending++] = n;
+            any = true;
+        }
+        return any;
     };
     // wait for the callers' plane copies of the oldest pending set, then enqueue it
     auto submit_pending = [&] {
@@ -452,6 +475,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
     };
 
     while (true) {
+        if (close_strays()) continue;
         if (!running_.load() && n_in == 0 && n_pending == 0) {
             bool idle = true;
             for (const Staging& s : g->st) idle &= count(s) == 0;
@@ -469,7 +493,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
             continue;
         }
         const unsigned c = count(s);
-        if (c >= want || (c > 0 && (cfg_.gpu_waittime_ms <= 0 || !running_.load()))) {
+        if (c >= want_now() || (c > 0 && (cfg_.gpu_waittime_ms <= 0 || !running_.load()))) {
             close_and_rotate();
             timing = false;
             continue;
@@ -522,7 +546,7 @@ HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputRes
     done->store(0, std::memory_order_relaxed);
     Graph* g = graphs_[next_graph_.fetch_add(1, std::memory_order_relaxed) % graphs_.size()].get();
     const unsigned cap = static_cast<unsigned>(max_batch_);
-    const unsigned want = static_cast<unsigned>(std::min(cfg_.batch_size, max_batch_));
+    const unsigned want = static_cast<unsigned>(std::min(forward_size_.load(std::memory_order_acquire), max_batch_));
     for (;;) {
         const int epoch = g->epoch.load(std::memory_order_acquire);
         Staging& s = g->st[g->fill.load(std::memory_order_acquire)];

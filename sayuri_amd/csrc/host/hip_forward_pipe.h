@@ -150,6 +150,7 @@ private:
     HipPipeConfig cfg_;
     int board_size_{0};
     int max_batch_{0};
+    std::atomic<int> forward_size_{0};  // batch size the collector forwards at (<= max_batch_); Construct() may lower it live
     std::vector<std::unique_ptr<Graph>> graphs_;
     std::atomic<bool> running_{false};
     std::atomic<unsigned> next_graph_{0};

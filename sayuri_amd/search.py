@@ -146,8 +146,11 @@ class Search:
         lib().sayuri_engine_search_update_territory_helper(self._h)
 
     def gather_training_text(self) -> bytes:
-        buf = ctypes.create_string_buffer(64 << 20)
+        buf = ctypes.create_string_buffer(4 << 20)
         n = lib().sayuri_engine_search_gather(self._h, buf, len(buf))
+        if n > len(buf):  # the text stays parked on the C side until a large enough buffer comes
+            buf = ctypes.create_string_buffer(n)
+            n = lib().sayuri_engine_search_gather(self._h, buf, len(buf))
         return buf.raw[:n]
 
 
@@ -155,19 +158,44 @@ STAT_NAMES = ("games_started", "games_done", "moves", "playouts", "nn_queries", 
               "chunks_saved")
 
 
+STATS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_double, ctypes.c_int, ctypes.c_void_p)
+
+
 def selfplay(pipe=None, options: dict | None = None, seconds: float = 0.0, move_cap: int = 0, name_suffix: str = "",
-             weights_version: int = 4) -> dict:
+             weights_version: int = 4, on_stats=None, stats_interval: float = 2.0) -> dict:
     """Run the self-play loop (csrc/engine/selfplay.cc).  `pipe` = sayuri_amd.pipe.HipForwardPipe, or None for the
-    dummy backend.  Returns the counters plus `elapsed` seconds."""
+    dummy backend.  Returns the counters plus `elapsed` seconds.
+
+    on_stats(stats: dict, local_halt: bool) -> bool is called every `stats_interval` seconds on the calling thread with a
+    snapshot of the counters and this process's own halt wish (newer weights appeared in options["weights_dir"]); a
+    true return winds the loop down (reference pipe.cc:246-258).  The multi-GPU driver all-gathers there
+    (sayuri_amd.shard.PeriodicGather)."""
     h = lib()
     raw, version = None, weights_version
     if pipe is not None:
         raw = h.sayuri_pipe_raw(pipe._h)
         version = h.sayuri_pipe_weights_version(pipe._h)
     stats, el = np.zeros(10, np.uint64), ctypes.c_double(0)
-    if h.sayuri_selfplay_run(raw, version, options_text(options or {}), name_suffix.encode(), seconds, move_cap,
-                             stats.ctypes.data, ctypes.byref(el)):
+    failure = []
+
+    def hook(st, elapsed, local_halt, _user):
+        try:
+            snap = {k: int(st[i]) for i, k in enumerate(STAT_NAMES)}
+            snap["elapsed"] = float(elapsed)
+            return 1 if on_stats(snap, bool(local_halt)) else 0
+        except BaseException as e:  # an exception must not unwind through the C frames
+            failure.append(e)
+            return 1
+
+    cb = STATS_FN(hook) if on_stats is not None else ctypes.cast(None, STATS_FN)
+    h.sayuri_selfplay_run_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_double, ctypes.c_int,
+                                         STATS_FN, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    if h.sayuri_selfplay_run_ex(raw, version, options_text(options or {}), name_suffix.encode(), seconds, move_cap, cb, None,
+                                float(stats_interval), stats.ctypes.data, ctypes.byref(el)):
         raise RuntimeError(h.sayuri_engine_last_error().decode())
+    if failure:
+        raise failure[0]
     out = {k: int(stats[i]) for i, k in enumerate(STAT_NAMES)}
+    out["max_games"] = int(stats[9])
     out["elapsed"] = el.value
     return out

@@ -10,7 +10,7 @@ from typing import Dict, Tuple
 import torch
 import torch.distributed as dist
 
-STAT_KEYS = ("games_done", "nn_queries", "nn_batches", "cache_hits", "moves", "playouts", "records", "elapsed")
+STAT_KEYS = ("games_done", "nn_queries", "nn_batches", "cache_hits", "moves", "playouts", "records", "elapsed", "halt", "done")
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -38,3 +38,38 @@ def gather_stats(local: Dict[str, float]) -> Dict:
     total["elapsed_max"] = max(r["elapsed"] for r in per_rank)
     total["per_rank"] = per_rank
     return total
+
+
+class PeriodicGather:
+    """The periodic exchange of the games-parallel path: every couple of seconds each rank contributes
+    its counters, its halt wish (newer weights seen, reference Engine::ShouldHalt) and whether its own loop has ended.
+
+    Every rank must take part in every round, so a rank whose self-play loop has returned keeps calling `tick(...,
+    done=True)` (see `drain`) until all ranks report done -- the rounds are collective calls, ranks that are ahead wait
+    for the slowest one there (a few round trips of ~100 bytes per rank)."""
+
+    def __init__(self):
+        self.rounds = 0
+        self.history = []   # (elapsed_max, total games_done, total nn_queries) per round, rank-agnostic
+        self.any_halt = False
+        self.all_done = False
+        self.last = None
+
+    def tick(self, local: Dict[str, float], halt: bool = False, done: bool = False) -> bool:
+        rec = dict(local)
+        rec["halt"] = 1.0 if halt else 0.0
+        rec["done"] = 1.0 if done else 0.0
+        tot = gather_stats(rec)
+        world = len(tot["per_rank"])
+        self.rounds += 1
+        self.any_halt = self.any_halt or tot["halt"] > 0
+        self.all_done = tot["done"] >= world
+        self.history.append((tot["elapsed_max"], tot["games_done"], tot["nn_queries"]))
+        self.last = tot
+        return self.any_halt
+
+    def drain(self, final: Dict[str, float]) -> Dict:
+        """After the local loop has ended: keep answering rounds until every rank has ended too; returns the last totals."""
+        while not self.all_done:
+            self.tick(final, halt=self.any_halt, done=True)
+        return self.last

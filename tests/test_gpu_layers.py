@@ -20,14 +20,23 @@ def _fp(a):
 
 
 def act_np(x, act):
+    """The eight activations of the reference (src/neural/activation.h:36-81), float64."""
     if act == 0:
         return x
     if act == 1:
         return np.maximum(x, 0)
+    if act == 2:  # ELU
+        return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+    if act == 3:  # SELU
+        return np.where(x > 0, 1.05070098 * x, 1.05070098 * 1.67326324 * np.expm1(np.minimum(x, 0)))
+    if act == 4:  # GELU, tanh form
+        return 0.5 * x * (1 + np.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
     if act == 5:
         return x * np.tanh(np.log1p(np.exp(x)))
     if act == 6:
         return x / (1 + np.exp(-x))
+    if act == 7:  # HardSwish
+        return np.where(x >= 3, x, np.where(x <= -3, 0.0, x * (x + 3) / 6))
     raise ValueError(act)
 
 
@@ -63,7 +72,7 @@ def conv_ref(xs, bsz, w, bias, res, k, depthwise, act, post):
     return outs
 
 
-def run_case(fp16, bsz, cin, cout, k, depthwise=False, act=5, with_res=True, post=False, seed=0, max_board=19):
+def run_case(fp16, bsz, cin, cout, k, depthwise=False, act=5, with_res=True, post=False, seed=0, max_board=19, kind=None):
     rng = np.random.default_rng(seed)
     n = len(bsz)
     xc = cout if depthwise else cin
@@ -99,6 +108,8 @@ def run_case(fp16, bsz, cin, cout, k, depthwise=False, act=5, with_res=True, pos
         worst = max(worst, float(np.abs(got - ref[i]).max()))
     tol = 4e-3 * scale if fp16 else 2e-5 * max(scale, 1.0)
     assert worst <= tol, (worst, tol, scale)
+    if kind is not None:
+        assert _lib.hip().sayuri_hip_test_last_conv_kind() == kind, "the layer ran on another kernel family than the test is about"
     return worst
 
 
@@ -126,10 +137,66 @@ def test_conv_mfma(case, fp16):
 
 
 @pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
-@pytest.mark.parametrize("act", [0, 1, 5, 6])
+@pytest.mark.parametrize("act", range(8))
 def test_conv_epilogue_variants(act, fp16):
     run_case(fp16, [19, 9], 32, 32, 3, act=act, with_res=False, seed=act)
     run_case(fp16, [19, 9], 32, 32, 3, act=act, with_res=True, seed=act + 10)
+
+
+KIND_BOARD = 2
+BOARD_CASES = [
+    # bsz, cin, cout: fp16 3x3 layers the one-workgroup-per-board kernel (conv_board.h) takes
+    ([19] * 3, 256, 256),                         # the tower conv of the 20b256 net, one board per tile (12 + 11 column tiles)
+    ([19] * 4, 43, 256),                          # its input conv (cin padded to 64: two chunks)
+    ([19] * 2, 384, 384),                         # 40b384: two 192-channel tiles per board (odd row-tile count per wave)
+    ([13] * 5, 128, 192),                         # two boards per tile + a half-empty last tile
+    ([9] * 9, 64, 128),                           # four boards per tile, 128-channel tile (two row tiles per wave)
+    ([19, 19, 13, 13, 9, 9, 9, 9, 19, 13], 256, 256),   # mixed sizes: one size per tile
+    ([7] * 13, 32, 128),                          # seven boards per tile
+    ([19], 256, 256),                             # a batch of one
+]
+
+
+@pytest.mark.parametrize("case", BOARD_CASES, ids=[f"{c[1]}x{c[2]}n{len(c[0])}b{min(c[0])}" for c in BOARD_CASES])
+def test_conv_board(case):
+    bsz, cin, cout = case
+    run_case(True, bsz, cin, cout, 3, act=5, with_res=True, seed=cin + cout, kind=KIND_BOARD)
+    run_case(True, bsz, cin, cout, 3, act=0, with_res=False, seed=cin + cout + 1, kind=KIND_BOARD)
+
+
+@pytest.mark.parametrize("act", range(8))
+def test_conv_board_activations(act):
+    run_case(True, [19, 19], 64, 128, 3, act=act, with_res=True, seed=40 + act, kind=KIND_BOARD)
+    run_case(True, [13, 13, 13], 64, 192, 3, act=act, with_res=False, seed=50 + act, kind=KIND_BOARD)
+
+
+def test_conv_board_batch256():
+    """Full bench geometry (256 x 19x19 = 256 board tiles = one workgroup per CU): a subset of samples against the float64
+    reference, and sample independence -- permuting the batch permutes the outputs bit for bit."""
+    rng = np.random.default_rng(17)
+    n, cin, cout = 256, 64, 256
+    x = rng.standard_normal((n, cin, 361)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    bias = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    bs_arr = np.full(n, 19, np.int32)
+    lib = _lib.hip()
+
+    def run(xx):
+        y = np.zeros((n, cout, 361), np.float32)
+        rc = lib.sayuri_hip_test_conv(0, 1, n, bs_arr.ctypes.data_as(_lib.c_int_p), 19, cin, cout, 3, 0, 5, 0,
+                                      _fp(np.ascontiguousarray(xx).ravel()), _fp(w.ravel()), _fp(bias), None, _fp(y.ravel()))
+        assert rc == 0, lib.sayuri_hip_last_error().decode()
+        assert lib.sayuri_hip_test_last_conv_kind() == KIND_BOARD
+        return y
+
+    y = run(x)
+    w16 = w.astype(np.float16).astype(np.float64)
+    for i in (0, 1, 99, 100, 177, 255):
+        ref = conv_ref([x[i].astype(np.float16).astype(np.float64)], [19], w16, bias.astype(np.float64), None, 3, False, 5,
+                       False)[0]
+        assert np.abs(y[i] - ref).max() <= 4e-3 * np.abs(ref).max()
+    perm = rng.permutation(n)
+    np.testing.assert_array_equal(run(x[perm]), y[perm])
 
 
 @pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
@@ -165,32 +232,10 @@ def test_conv_batch256_tile_seams():
     np.testing.assert_array_equal(y2, y[perm])
 
 
-WINO_CASES = [
-    ([19] * 3, 256, 256),                    # the tower conv of the 20b256 net (8 chunks, 4 channel tiles)
-    ([19] * 7, 64, 64),                      # several tile blocks, blocks crossing samples
-    ([9, 13, 19, 7, 19, 5], 32 * 3, 64),     # mixed boards: odd and even sizes, ragged last tiles
-    ([19] * 2, 384, 384),                    # 40b384 tower conv (12 chunks, 6 channel tiles)
-    ([13] * 5, 128, 192),
-    ([19] * 4, 43, 96),                      # input conv shape (cin padded to 64, cout padded to 128)
-]
-
-
-@pytest.mark.parametrize("variant", ["wino", "wino8"])
-@pytest.mark.parametrize("case", WINO_CASES, ids=[f"{c[1]}x{c[2]}n{len(c[0])}b{min(c[0])}" for c in WINO_CASES])
-def test_conv_winograd_fused(case, variant, monkeypatch):
-    """SAYURI_CONV=wino | wino8: the fused Winograd F(2x2,3x3) kernels (csrc/hip/conv_wino.h, four / eight waves)
-    against the same float64 direct-convolution reference and tolerance as the implicit-GEMM kernels."""
-    monkeypatch.setenv("SAYURI_CONV", variant)
-    bsz, cin, cout = case
-    run_case(True, bsz, cin, cout, 3, act=5, with_res=True, seed=cin + cout)
-    run_case(True, bsz, cin, cout, 3, act=0, with_res=False, seed=cin + cout + 1)
-
-
-@pytest.mark.parametrize("env", [("SAYURI_CONV", "glds2x"), ("SAYURI_CONV", "glds4"), ("SAYURI_CONV", "v0"), ("SAYURI_EPI", "2")],
-                         ids=lambda e: f"{e[0]}={e[1]}")
+@pytest.mark.parametrize("env", [("SAYURI_CONV", "glds"), ("SAYURI_CONV", "v0")], ids=lambda e: f"{e[0]}={e[1]}")
 def test_conv_kernel_variants(env):
-    """The A/B switches of the implicit-GEMM kernel (two workgroups per CU, four-wave tiles, the generic kernel, the
-    register-form epilogue) are read once per process, so each runs the fp16 layer cases in a process of its own."""
+    """The A/B switch of the fp16 3x3 kernels (glds: tiles across samples instead of one workgroup per board; v0: the
+    generic register-staged kernel) is read once per process, so each runs the fp16 layer cases in a process of its own."""
     import os
     import subprocess
     import sys
@@ -200,34 +245,3 @@ def test_conv_kernel_variants(env):
                         "(test_conv_mfma or test_conv_epilogue_variants or test_conv_batch256) and not fp32"],
                        env=e, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-@pytest.mark.parametrize("variant", ["wino", "wino8"])
-def test_conv_winograd_batch256_blocks(variant, monkeypatch):
-    """Full bench geometry (256 x 19x19 = 25 600 Winograd tiles, 534 tile blocks, every block seam and sample crossing):
-    a subset of samples against the float64 reference, and sample independence -- permuting the batch permutes the
-    outputs bit for bit, although every sample then sits in other tile blocks / fragment columns."""
-    monkeypatch.setenv("SAYURI_CONV", variant)
-    rng = np.random.default_rng(17)
-    n, cin, cout = 256, 64, 64
-    x = rng.standard_normal((n, cin, 361)).astype(np.float32)
-    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
-    bias = (rng.standard_normal(cout) * 0.1).astype(np.float32)
-    bs_arr = np.full(n, 19, np.int32)
-    lib = _lib.hip()
-
-    def run(xx):
-        y = np.zeros((n, cout, 361), np.float32)
-        rc = lib.sayuri_hip_test_conv(0, 1, n, bs_arr.ctypes.data_as(_lib.c_int_p), 19, cin, cout, 3, 0, 5, 0,
-                                      _fp(np.ascontiguousarray(xx).ravel()), _fp(w.ravel()), _fp(bias), None, _fp(y.ravel()))
-        assert rc == 0, lib.sayuri_hip_last_error().decode()
-        return y
-
-    y = run(x)
-    w16 = w.astype(np.float16).astype(np.float64)
-    for i in (0, 1, 99, 100, 177, 255):
-        ref = conv_ref([x[i].astype(np.float16).astype(np.float64)], [19], w16, bias.astype(np.float64), None, 3, False, 5,
-                       False)[0]
-        assert np.abs(y[i] - ref).max() <= 4e-3 * np.abs(ref).max()
-    perm = rng.permutation(n)
-    np.testing.assert_array_equal(run(x[perm]), y[perm])

@@ -57,15 +57,16 @@ def test_golden_parity(name, fp16, tmp_weights_dir):
         pipe.Destroy()
 
 
-@pytest.mark.parametrize("variant", ["wino", "wino8"])
-def test_20b256_winograd_path(variant, tmp_weights_dir, monkeypatch):
-    """The same network through the opt-in fused Winograd convolutions (SAYURI_CONV=wino | wino8, conv_wino.h)."""
+@pytest.mark.parametrize("variant", ["glds", "v0"])
+def test_20b256_fallback_conv_paths(variant, tmp_weights_dir, monkeypatch):
+    """The same network with the one-workgroup-per-board convolution switched off: SAYURI_CONV=glds (LDS-DMA tiles across
+    samples, conv_glds.h -- what batches of boards that do not fit a board tile use) and v0 (the generic kernel)."""
     monkeypatch.setenv("SAYURI_CONV", variant)
     g = Golden("net_20b256", tmp_weights_dir)
     cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
     pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=True)
     try:
-        check(pipe, cases, FP16_ATOL, "20b256-wino")
+        check(pipe, cases, FP16_ATOL, "20b256-" + variant)
     finally:
         pipe.Destroy()
 

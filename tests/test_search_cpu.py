@@ -111,11 +111,13 @@ def test_selfplay_pipe_dummy_backend(tmp_path):
     assert (len(lines) - 1) % 53 == 0 and lines[0] == "2" and lines[1] == "0"
     sgf = open(glob.glob(str(tmp_path / "sgf" / "*.sgf"))[0]).read()
     assert sgf.count("(;GM[1]FF[4]") == 8 and "RE[" in sgf
-    # one game per worker: a seed fixes every game (with more games than workers, which worker picks up the next
-    # game depends on timing, as in the reference)
-    once = dict(opts, target_directory="", num_games=4)
+    # A seed fixes a game only when nothing is shared between concurrently running games: the games of one pipe share the
+    # NN result cache (network.cc Insert / Lookup), and with the dummy backend + random symmetry whichever game inserts a
+    # position first decides what the others read.  So the reproducibility claim is for ONE game at a time; parallel
+    # self-play is reproducible in distribution only (as in the reference, whose generators are seeded from thread ids).
+    once = dict(opts, target_directory="", num_games=2, parallel_games=1)
     a, b = S.selfplay(None, once), S.selfplay(None, once)
-    assert (a["moves"], a["playouts"], a["records"]) == (b["moves"], b["playouts"], b["records"]) and a["games_done"] == 4
+    assert (a["moves"], a["playouts"], a["records"]) == (b["moves"], b["playouts"], b["records"]) and a["games_done"] == 2
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/train/torch"), reason="reference trainer only in the dev container")
