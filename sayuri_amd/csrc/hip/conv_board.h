@@ -24,6 +24,7 @@
 #include "common.h"
 #include "conv_glds.h"
 #include "conv_mfma.h"
+#include "small_ops.h"
 
 namespace sayuri {
 
@@ -39,6 +40,7 @@ struct BoardParams {
     const int2* tab_pix;   // [tile][384]    x = lpos | lstr << 16, y = output activation row (-1 = none)
     const int* tab_cols;   // [tile]         column tiles in use (1..24) | board size << 8
     int npos;              // halo positions per tile of this launch (multiple of 64, <= 512)
+    unsigned long long* dbg;  // DBG kernels only: s_memtime timeline [workgroup < 4][wave][8]
 };
 
 // Which samples share a tile: consecutive samples OF ONE BOARD SIZE, greedily, while pixels <= 384, halo positions
@@ -122,7 +124,10 @@ template <int WMT_> struct BoardCfg {
     static constexpr int A_INSTR = KO_T / 16;       // 1 KiB DMA instructions per tap tile
     static constexpr int AI = (A_INSTR + NWAVE - 1) / NWAVE;
     static constexpr int KO_PARTS = KO_T / 64;      // 64-row pieces per k-group plane
-    static constexpr size_t lds_bytes(int npos) { return 2 * (size_t)A_BYTES + 2 * (size_t)npos * 64; }
+    // K-loop rings; the launch always asks for the whole 160 KiB (one workgroup per CU either way): the epilogue hands
+    // each wave 20 KiB of it for its residual rows
+    static constexpr size_t ring_bytes(int npos) { return 2 * (size_t)A_BYTES + 2 * (size_t)npos * 64; }
+    static constexpr size_t lds_bytes(int npos) { return ring_bytes(npos) <= 160 * 1024 ? 160 * 1024 : ring_bytes(npos); }
 };
 
 namespace board_sched {
@@ -160,13 +165,27 @@ __device__ __forceinline__ void swap16(f32x4& a, f32x4& b) {
     // __builtin_amdgcn_permlane16_swap loses its second result here (the code that follows reads the first result for
     // both halves -- seen in the .s, and as wrong channels 4-7 / 12-15 of every row tile on the GPU); s_nop 1 = the
     // two wait states a VALU write of either operand needs before the swap reads it.
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float x = a[q], y = b[q];
-        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-        a[q] = x;
-        b[q] = y;
-    }
+    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+        "v_permlane16_swap_b32 %3, %7"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+    a = f32x4{a0, a1, a2, a3};
+    b = f32x4{b0, b1, b2, b3};
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Mish on two values with packed fp32 arithmetic (v_pk_mul / v_pk_add / v_pk_fma): x * (1 - 2 / (e^2 + 2e + 2)).
+// Same values as activate(x, kMish): its x > 20 guard only fixes the code shape, e = inf gives rcp = 0 and the result x.
+__device__ __forceinline__ f32x2 mish2(f32x2 x) {
+    const f32x2 xl = x * 1.4426950408889634f;
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(xl[0]);
+    e[1] = __builtin_amdgcn_exp2f(xl[1]);
+    const f32x2 t = __builtin_elementwise_fma(e, e + 2.f, f32x2{2.f, 2.f});
+    f32x2 r;
+    r[0] = __builtin_amdgcn_rcpf(t[0]);
+    r[1] = __builtin_amdgcn_rcpf(t[1]);
+    return x * __builtin_elementwise_fma(r, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f});
 }
 
 // The accumulators live in the AGPR half of the register file for the whole kernel ("+a"): as compiler-allocated
@@ -201,9 +220,10 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint3
 // The main loop: returns with the accumulators (bias included) of this wave's (WMT x 12) output tiles.
 // `full` = the wave's 12th column tile is in use (else its MFMAs are skipped; other unused tiles are computed on
 // whatever the padded pixel slots point at and never stored).
-template <int WMT>
+template <int WMT, bool DBG = false, int PRIO = 0>
 __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
-                                               int kt, int wave, int lane, int col0, bool full, int bs) {
+                                               int kt, int wave, int lane, int col0, bool full, int bs,
+                                               unsigned long long* dbg = nullptr) {
     using Cfg = BoardCfg<WMT>;
     using namespace board_sched;
     constexpr int KO_T = Cfg::KO_T, NJ = Cfg::NJ, AI = Cfg::AI, NA = WMT;
@@ -221,22 +241,6 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
     const unsigned char* gin0 = (const unsigned char*)p.in - kZeroPrefix;
     const unsigned char* gw = (const unsigned char*)p.w;
     const int nbinstr = npos / 64 * 4;
-    uint32_t boff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave + 8 * i, kgq = q & 3, blk = q >> 2;
-        int src = -1;
-        if (q < nbinstr) src = bp.tab_src[(size_t)tile * npos + blk * 64 + lane];
-        boff[i] = (src >= 0 ? (uint32_t)kZeroPrefix + (uint32_t)src * (uint32_t)(p.cin_s * 2) : 0u) + kgq * 16;
-    }
-    // per-lane B fragment addresses of the current (halo slot, kernel row); moved by scalars from group to group
-    uint32_t bb[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int2 e = bp.tab_pix[(size_t)tile * kBoardPT + (col0 + j) * 16 + (lane & 15)];
-        const uint32_t lp = e.x & 0xffff;
-        bb[j] = b_ring + (lp - 1) * 16 + (uint32_t)kg * npos * 16 - ls16;  // kernel row 0 (dy = -1) in slot 0
-    }
     const int nchunks = p.cin_s / kChunk;
     const int ngroups = nchunks * 3;
     const uint32_t lane16 = lane * 16;
@@ -252,12 +256,36 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
                                     (size_t)((kgq * p.ko_pad + kt * KO_T + part * 64) * 16);
         glds16_s(lane16, base, a_ring + (G & 1) * Cfg::A_BYTES + dx * Cfg::A_TAP_BYTES + (kgq * KO_T + part * 64) * 16);
     };
+    // the first weight group needs no table: it goes out first and lands while the tables are being read
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int i = 0; i < AI; ++i) issue_a(0, dx, i);
+
+    uint32_t boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave + 8 * i, kgq = q & 3, blk = q >> 2;
+        int src = -1;
+        if (q < nbinstr) src = bp.tab_src[(size_t)tile * npos + blk * 64 + lane];
+        boff[i] = (src >= 0 ? (uint32_t)kZeroPrefix + (uint32_t)src * (uint32_t)(p.cin_s * 2) : 0u) + kgq * 16;
+    }
     auto issue_b = [&](int chunk, int i) {
         const int q = wave + 8 * i;
         if (q >= nbinstr) return;
         glds16_s(boff[i], gin0 + chunk * (kChunk * 2), b_ring + (chunk & 1) * b_bytes + ((q & 3) * npos + (q >> 2) * 64) * 16);
     };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_b(0, i);  // the first halo tile, as soon as its source rows are known
 
+    // per-lane B fragment addresses of the current (halo slot, kernel row); moved by scalars from group to group
+    uint32_t bb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int2 e = bp.tab_pix[(size_t)tile * kBoardPT + (col0 + j) * 16 + (lane & 15)];
+        const uint32_t lp = e.x & 0xffff;
+        bb[j] = b_ring + (lp - 1) * 16 + (uint32_t)kg * npos * 16 - ls16;  // kernel row 0 (dy = -1) in slot 0
+    }
     // accumulators start at the bias: D rows 4*(lane>>4)+r of row tile i are 4 consecutive output channels
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
@@ -265,16 +293,13 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = b4;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table / bias loads are done before the first DMA goes out
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_b(0, i);
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int i = 0; i < AI; ++i) issue_a(0, dx, i);
 
     const uint32_t arow_off = (uint32_t)((kg * KO_T + wave_m * WMT * 16 + (lane & 15)) * 16);
+    if constexpr (PRIO == 1) {  // experiment: the younger SIMD partner always wins the arbitration
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
+    unsigned long long t_sync = 0;  // DBG: cycles spent in vmcnt(0) + s_barrier at the group boundaries
+    if constexpr (DBG) { if (dbg) dbg[1] = __builtin_amdgcn_s_memtime(); }
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more_b = chunk + 1 < nchunks;
@@ -282,8 +307,15 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
             constexpr int row = decltype(rowc)::value;
             const int G = chunk * 3 + row;
             // A(G) and B(chunk) were issued during earlier groups and nothing after them
+            unsigned long long t0 = 0;
+            if constexpr (DBG) t0 = __builtin_amdgcn_s_memtime();
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
+            if constexpr (DBG) {
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                t_sync += t1 - t0;
+                if (dbg && G == 0) dbg[2] = t1;
+            }
             const bool more_a = G + 1 < ngroups;
             const uint32_t abase = a_ring + (G & 1) * Cfg::A_BYTES + arow_off;
             f16x8 afr[NA], bfr[3];
@@ -296,6 +328,16 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
             static_for<kNB>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
                 constexpr int dx = b / NJ, j = b % NJ;
+                if constexpr (PRIO == 2) {  // experiment: the SIMD partners take turns block by block
+                    if (((b & 1) != 0) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                if constexpr (PRIO == 3) {  // experiment: turns of four blocks
+                    if constexpr (b % 4 == 0) {
+                        if ((((b >> 2) & 1) != 0) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                }
                 // DMA of the next group / chunk, front-loaded: weights at blocks 0, 3, 6, ..., halo pieces at blocks 1
                 // and 4 of rows 0 and 1 (the next chunk's slot is free from the start of this chunk)
                 if constexpr (b % 3 == 0 && b / 3 < 3 * AI) {
@@ -331,19 +373,49 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
     }
     // the last MFMAs retire before the epilogue reads the accumulators (hipcc pads nothing after an asm statement)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    if constexpr (DBG) { if (dbg) { dbg[3] = __builtin_amdgcn_s_memtime(); dbg[5] = t_sync; } }
 }
 
 template <int ACT> __device__ __forceinline__ f16x8 board_act8(const float (&v)[8]) {
     f16x8 h;
+    if constexpr (ACT == kMish) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) h[q] = (f16)activate(v[q], ACT);
+        for (int q = 0; q < 8; q += 2) {
+            const f32x2 y = mish2(f32x2{v[q], v[q + 1]});
+            h[q] = (f16)y[0];
+            h[q + 1] = (f16)y[1];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) h[q] = (f16)activate(v[q], ACT);
+    }
     return h;
 }
 
-// Plain epilogue: optional residual, activation, fp16 NHWC store -- straight from the accumulators (bias is in).
+// One (column tile, row-tile pair) of the epilogue: swap, + residual, activation, 16-byte store.
+template <int ACT>
+__device__ __forceinline__ void board_store_pair(f32x4 a, f32x4 b, bool with_res, const f16x8& rr, f16* __restrict__ dst, bool ok) {
+    swap16(a, b);
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (with_res) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += (float)rr[q];
+    }
+    const f16x8 h = board_act8<ACT>(v);
+    if (ok) *(f16x8*)dst = h;
+}
+
+// Epilogue: optional residual, activation, fp16 NHWC store -- straight from the accumulators (bias is in).
+// The residual rows are what bounds it when done naively: one load per (column tile, pair) and lane, consumed one
+// column tile later, is a chain of twelve memory latencies per wave (36 k cycles per tile measured, unchanged by
+// halving the VALU work or the number of active CUs).  So all residual rows of a wave are requested AT ONCE: the
+// K loop's LDS rings are dead by now, each wave owns 20 KiB of them and has its residual pieces (1 KiB = 64 lanes x
+// 16 bytes, lane-linear: the lane that reads a piece back is the lane that fetched it) delivered there by LDS-DMA,
+// the few that do not fit go to registers; one wait covers all of them.
 template <int WMT, int ACT>
-__device__ __forceinline__ void board_epilogue(const BoardParams& bp, f32x4 (&acc)[WMT][kBoardNJ], int tile, int kt, int wave,
-                                               int lane, int col0, int nj) {
+__device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile, int kt,
+                                               int wave, int lane, int col0, int nj) {
     using Cfg = BoardCfg<WMT>;
     constexpr int NJ = Cfg::NJ, NPAIR = WMT / 2;
     constexpr bool LONE = (WMT & 1) != 0;
@@ -357,8 +429,60 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, f32x4 (&ac
     int cb[NPAIR > 0 ? NPAIR : 1];
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) cb[pr] = ko_w + (2 * pr + (R & 1)) * 16 + (R >> 1) * 8;
-    const int cl = ko_w + (WMT - 1) * 16 + 4 * R;  // lone row tile: accumulator layout, 4 channels per lane
 
+    if constexpr (!LONE) {
+        // ---- even row-tile counts: residual through the dead LDS rings
+        constexpr int kWaveLds = 20 * 1024;                     // 160 KiB / 8 waves (the launch asks for all of the LDS)
+        constexpr int kPieces = NJ * NPAIR;                      // residual pieces of a wave
+        constexpr int ND = kPieces > 20 ? kPieces - 20 : 0;      // pieces that go to registers instead (the first ones)
+        static_assert(ND % (NPAIR > 0 ? NPAIR : 1) == 0, "whole column tiles");
+        int orow[NJ];
+        f16x8 rrd[ND > 0 ? ND : 1];
+        const bool with_res = gres != nullptr;
+        const uint32_t my_lds = (uint32_t)(uintptr_t)smem + wave * kWaveLds;
+        if (with_res) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave is done with the rings
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) orow[j] = j < nj ? pix[j * 16].y : -1;
+            auto roff = [&](int j, int pr) -> uint32_t {  // byte offset of this lane's 8 residual channels
+                return (orow[j] >= 0 && cb[pr] < p.cout_s) ? ((uint32_t)orow[j] * (uint32_t)p.cout_s + (uint32_t)cb[pr]) * 2u : 0u;
+            };
+#pragma unroll
+            for (int k = 0; k < ND; ++k) rrd[k] = *(const f16x8*)((const unsigned char*)gres + roff(k / NPAIR, k % NPAIR));
+            static_for<kPieces - ND>([&](auto kc) {
+                constexpr int k = decltype(kc)::value + ND;
+                if (k / NPAIR < nj) glds16_s(roff(k / NPAIR, k % NPAIR), gres, my_lds + (k - ND) * 1024);
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // one wait: every residual piece of this wave has landed
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) orow[j] = j < nj ? pix[j * 16].y : -1;
+        }
+        static_for<NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j < nj) {  // wave-uniform
+#pragma unroll
+                for (int pr = 0; pr < NPAIR; ++pr) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int k = j * NPAIR + pr;
+                    f16x8 rr = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (with_res) {
+                        if (k < ND) rr = rrd[k < ND ? k : 0];
+                        else rr = *(const f16x8*)(smem + wave * kWaveLds + (k - ND) * 1024 + lane * 16);
+                    }
+                    const bool ok = orow[j] >= 0 && cb[pr] < p.cout_s;
+                    board_store_pair<ACT>(acc[2 * pr][j], acc[2 * pr + 1][j], with_res, rr,
+                                          gout + ((size_t)(ok ? orow[j] : 0) * p.cout_s + cb[pr]), ok);
+                }
+            }
+        });
+        return;
+    }
+
+    // ---- odd row-tile count (192-channel tiles): pairs + a lone row tile, residual rows one column tile ahead
+    const int cl = ko_w + (WMT - 1) * 16 + 4 * R;  // lone row tile: accumulator layout, 4 channels per lane
     auto res8 = [&](int orow, int pr) -> f16x8 {
         if (gres && orow >= 0 && cb[pr] < p.cout_s) return *(const f16x8*)(gres + (size_t)orow * p.cout_s + cb[pr]);
         return f16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -367,7 +491,6 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, f32x4 (&ac
         if (gres && orow >= 0 && cl < p.cout_s) return *(const f16x4*)(gres + (size_t)orow * p.cout_s + cl);
         return f16x4{0, 0, 0, 0};
     };
-    // output rows two column tiles ahead, residual rows one column tile ahead of the arithmetic
     int orow[3];
     f16x8 rr[2][NPAIR > 0 ? NPAIR : 1];
     f16x4 rl[2];
@@ -375,7 +498,7 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, f32x4 (&ac
     orow[1] = nj > 1 ? pix[16].y : -1;
 #pragma unroll
     for (int pr = 0; pr < NPAIR; ++pr) rr[0][pr] = res8(orow[0], pr);
-    if constexpr (LONE) rl[0] = res4(orow[0]);
+    rl[0] = res4(orow[0]);
     static_for<NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nj) {  // wave-uniform
@@ -383,39 +506,215 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, f32x4 (&ac
             if constexpr (j + 1 < NJ) {
 #pragma unroll
                 for (int pr = 0; pr < NPAIR; ++pr) rr[(j + 1) & 1][pr] = res8(orow[(j + 1) % 3], pr);
-                if constexpr (LONE) rl[(j + 1) & 1] = res4(orow[(j + 1) % 3]);
+                rl[(j + 1) & 1] = res4(orow[(j + 1) % 3]);
             }
             const int my = orow[j % 3];
 #pragma unroll
             for (int pr = 0; pr < NPAIR; ++pr) {
-                f32x4 a = acc[2 * pr][j], b = acc[2 * pr + 1][j];
-                swap16(a, b);
-                float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                if (gres) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] += (float)rr[j & 1][pr][q];
-                }
-                const f16x8 h = board_act8<ACT>(v);
-                if (my >= 0 && cb[pr] < p.cout_s) *(f16x8*)(gout + (size_t)my * p.cout_s + cb[pr]) = h;
+                const bool ok = my >= 0 && cb[pr] < p.cout_s;
+                board_store_pair<ACT>(acc[2 * pr][j], acc[2 * pr + 1][j], gres != nullptr, rr[j & 1][pr],
+                                      gout + ((size_t)(ok ? my : 0) * p.cout_s + cb[pr]), ok);
             }
-            if constexpr (LONE) {
-                f32x4 v = acc[WMT - 1][j];
-                if (gres) {
+            f32x4 v = acc[WMT - 1][j];
+            if (gres) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += (float)rl[j & 1][q];
-                }
-                f16x4 h;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) h[q] = (f16)activate(v[q], ACT);
-                if (my >= 0 && cl < p.cout_s) *(f16x4*)(gout + (size_t)my * p.cout_s + cl) = h;
+                for (int q = 0; q < 4; ++q) v[q] += (float)rl[j & 1][q];
             }
+            f16x4 h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[q] = (f16)activate(v[q], ACT);
+            if (my >= 0 && cl < p.cout_s) *(f16x4*)(gout + (size_t)my * p.cout_s + cl) = h;
         }
     });
 }
 
+// ---- the squeeze-and-excitation unit inside the convolution (reference SEUnit::Forward, se_unit.cc:70-128) -----------
+// A block's last 3x3 convolution is followed by  pool -> FC(3C -> se, act) -> FC(se -> 2C) -> act(sigmoid(g) x + b + res).
+// When the workgroup holds one whole sample and every channel (KO_T == padded C), x is sitting in its accumulators:
+// pooling is a reduction over registers, the two FCs read their weights from L2 (196 + 128 KB at C = 256, the same
+// bytes for every workgroup), the gate is applied to the accumulators and the ordinary epilogue (residual, activation,
+// store) follows -- no se_pool / se_fc / se_scale launches, x never makes the round trip through HBM.
+struct BoardSeParams {
+    BoardParams b;
+    FcDev squeeze, excite;  // transposed [in][out] fp32 weights (small_ops.h)
+    int C;                  // real channel count of the block
+};
+
+// rotate by `n` lanes inside each row of 16 lanes (DPP row_ror) -- four of them make an all-reduce over a row
+template <int N> __device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+
+// Partial sums of y = W^T x for a block of 512 threads: thread = (4 consecutive outputs, slice of the inputs), all of a
+// thread's 16-byte weight loads are independent and go out eight at a time (these FCs are latency-bound: every
+// workgroup of the launch reads the same few hundred KB from L2); red[slice][out] is folded by the caller.
+// Needs out % 4 == 0 and out / 4 <= 512.
+__device__ __forceinline__ void se_fc4(const FcDev fc, const float* x, float* red, int tid) {
+    const int quads = fc.out / 4, parts = 512 / quads;
+    const int oq = tid % quads, part = tid / quads;
+    if (part >= parts) return;
+    const int per = (fc.in + parts - 1) / parts;
+    const int i0 = part * per, i1 = min(fc.in, i0 + per);
+    const float* w = fc.wt + oq * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int i = i0; i < i1; i += 8) {
+        f32x4 wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = i + u < i1 ? *(const f32x4*)(w + (size_t)(i + u) * fc.out) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += (i + u < i1 ? x[i + u] : 0.f) * wv[u];
+    }
+    *(f32x4*)(red + part * fc.out + oq * 4) = a;
+}
+
 template <int WMT>
+__device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
+                                               int wave, int lane, int col0, int nj, int bs) {
+    using Cfg = BoardCfg<WMT>;
+    constexpr int NJ = Cfg::NJ, KO_T = Cfg::KO_T;
+    const ConvParams& p = sp.b.c;
+    const int tid = wave * 64 + lane, q = lane >> 4, px = lane & 15, wave_m = wave & 3, wave_n = wave >> 2;
+    const int C = sp.C, so = sp.squeeze.out;
+    // LDS (the K loop's rings are dead): [2][KO_T] sums, [2][KO_T] maxima, pool[3C], red[2048], mid[so], gate[2*KO_T]
+    float* psum = (float*)smem;
+    float* pmax = psum + 2 * KO_T;
+    float* pool = pmax + 2 * KO_T;
+    float* red = pool + 3 * KO_T;  // [slices][outputs] of an FC: 512 threads x 4 floats
+    float* mid = red + 2048;
+    float* gate = mid + 512;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the rings
+
+    // ---- pooling: per lane over its column tiles (valid pixels only), then over the 16 pixel lanes of a row
+    const int2* pix = sp.b.tab_pix + (size_t)tile * kBoardPT + col0 * 16 + px;
+    f32x4 s4[WMT], m4[WMT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) { s4[i] = f32x4{0.f, 0.f, 0.f, 0.f}; m4[i] = f32x4{-5000.f, -5000.f, -5000.f, -5000.f}; }
+    static_for<NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (j < nj) {
+            const bool valid = pix[j * 16].y >= 0;
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) {
+                const f32x4 v = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s4[i][r] += valid ? v[r] : 0.f;
+                    m4[i][r] = valid ? fmaxf(m4[i][r], v[r]) : m4[i][r];
+                }
+            }
+        }
+    });
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = s4[i][r], b = m4[i][r];
+            a += row_ror<8>(a); b = fmaxf(b, row_ror<8>(b));
+            a += row_ror<4>(a); b = fmaxf(b, row_ror<4>(b));
+            a += row_ror<2>(a); b = fmaxf(b, row_ror<2>(b));
+            a += row_ror<1>(a); b = fmaxf(b, row_ror<1>(b));
+            s4[i][r] = a; m4[i][r] = b;
+        }
+    if (px == 0) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) {
+            const int c0 = wave_m * WMT * 16 + i * 16 + 4 * q;
+            *(f32x4*)(psum + wave_n * KO_T + c0) = s4[i];
+            *(f32x4*)(pmax + wave_n * KO_T + c0) = m4[i];
+        }
+    }
+    __syncthreads();
+    const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
+    for (int c = tid; c < C; c += 512) {
+        const float mean = (psum[c] + psum[KO_T + c]) / npix;
+        pool[c] = mean;
+        pool[C + c] = mean * (bd / 10.f);
+        pool[2 * C + c] = fmaxf(pmax[c], pmax[KO_T + c]);
+    }
+    __syncthreads();
+    // ---- the two FCs (se_fc4 above): squeeze with the unit's activation, excite into the gate
+    se_fc4(sp.squeeze, pool, red, tid);
+    __syncthreads();
+    for (int o = tid; o < so; o += 512) {
+        float a = sp.squeeze.b[o];
+        const int parts = 512 / (so / 4);
+        for (int k = 0; k < parts; ++k) a += red[k * so + o];
+        mid[o] = activate(a, p.act);
+    }
+    __syncthreads();
+    se_fc4(sp.excite, mid, red, tid);
+    __syncthreads();
+    {
+        const int eo = sp.excite.out, parts = 512 / (eo / 4);
+        for (int o = tid; o < eo; o += 512) {
+            float a = sp.excite.b[o];
+            for (int k = 0; k < parts; ++k) a += red[k * eo + o];
+            // gate[c] = sigmoid(gamma_c), gate[KO_T + c] = beta_c
+            gate[o < C ? o : KO_T + (o - C)] = o < C ? 1.0f / (1.0f + fast_exp(-a)) : a;
+        }
+    }
+    __syncthreads();
+    // ---- x <- sigmoid(gamma) x + beta on the accumulators (pad channels: weights and bias are 0, x stays 0 * g + b:
+    // their gate entries are never written, so they are masked here)
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+        const int c0 = wave_m * WMT * 16 + i * 16 + 4 * q;
+        f32x4 g = *(const f32x4*)(gate + c0), be = *(const f32x4*)(gate + KO_T + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c0 + r >= C) { g[r] = 0.f; be[r] = 0.f; }
+        static_for<NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            acc[i][j] = g * acc[i][j] + be;
+        });
+    }
+    // the epilogue starts with a barrier before it reuses the LDS
+}
+
+template <int WMT>
+__global__ __launch_bounds__(512, 2) void conv_board_se_kernel(const BoardSeParams sp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const BoardParams& bp = sp.b;
+    const ConvParams& p = bp.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;  // one output-channel tile: KO_T covers the layer
+    const int info = __builtin_amdgcn_readfirstlane(bp.tab_cols[tile]);
+    const int ncols = info & 0xff, bs = info >> 8;
+    const int nj0 = (ncols + 1) >> 1;
+    const int wave_n = wave >> 2;
+    const int col0 = wave_n ? nj0 : 0;
+    const int nj = wave_n ? ncols - nj0 : nj0;
+
+    f32x4 acc[WMT][kBoardNJ];
+    board_mainloop<WMT>(bp, smem, acc, tile, 0, wave, lane, col0, nj == kBoardNJ, bs);
+    board_se_stage<WMT>(sp, smem, acc, tile, wave, lane, col0, nj, bs);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // gate fully read before the epilogue's residual pieces land in the same LDS
+
+    switch (p.act) {
+    case kMish: board_epilogue<WMT, kMish>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    case kIdentity: board_epilogue<WMT, kIdentity>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    case kReLU: board_epilogue<WMT, kReLU>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    case kSwish: board_epilogue<WMT, kSwish>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    case kELU: board_epilogue<WMT, kELU>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    case kSELU: board_epilogue<WMT, kSELU>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    case kGELU: board_epilogue<WMT, kGELU>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    default: board_epilogue<WMT, kHardSwish>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    }
+}
+
+template <int WMT, bool DBG = false, int PRIO = 0>
 __global__ __launch_bounds__(512, 2) void conv_board_kernel(const BoardParams bp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* dbg = nullptr;
+    if constexpr (DBG) {
+        if (bp.dbg && blockIdx.x < 4 && (threadIdx.x & 63) == 0) {
+            dbg = bp.dbg + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;
+            dbg[0] = __builtin_amdgcn_s_memtime();
+        }
+    }
     const ConvParams& p = bp.c;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -431,17 +730,23 @@ __global__ __launch_bounds__(512, 2) void conv_board_kernel(const BoardParams bp
     const int nj = wave_n ? ncols - nj0 : nj0;
 
     f32x4 acc[WMT][kBoardNJ];
-    board_mainloop<WMT>(bp, smem, acc, tile, kt, wave, lane, col0, nj == kBoardNJ, bs);
+    board_mainloop<WMT, DBG, PRIO>(bp, smem, acc, tile, kt, wave, lane, col0, nj == kBoardNJ, bs, dbg);
 
     switch (p.act) {
-    case kMish: board_epilogue<WMT, kMish>(bp, acc, tile, kt, wave, lane, col0, nj); break;
-    case kIdentity: board_epilogue<WMT, kIdentity>(bp, acc, tile, kt, wave, lane, col0, nj); break;
-    case kReLU: board_epilogue<WMT, kReLU>(bp, acc, tile, kt, wave, lane, col0, nj); break;
-    case kSwish: board_epilogue<WMT, kSwish>(bp, acc, tile, kt, wave, lane, col0, nj); break;
-    case kELU: board_epilogue<WMT, kELU>(bp, acc, tile, kt, wave, lane, col0, nj); break;
-    case kSELU: board_epilogue<WMT, kSELU>(bp, acc, tile, kt, wave, lane, col0, nj); break;
-    case kGELU: board_epilogue<WMT, kGELU>(bp, acc, tile, kt, wave, lane, col0, nj); break;
-    default: board_epilogue<WMT, kHardSwish>(bp, acc, tile, kt, wave, lane, col0, nj); break;
+    case kMish: board_epilogue<WMT, kMish>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;
+    case kIdentity: board_epilogue<WMT, kIdentity>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;
+    case kReLU: board_epilogue<WMT, kReLU>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;
+    case kSwish: board_epilogue<WMT, kSwish>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;
+    case kELU: board_epilogue<WMT, kELU>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;
+    case kSELU: board_epilogue<WMT, kSELU>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;
+    case kGELU: board_epilogue<WMT, kGELU>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;
+    default: board_epilogue<WMT, kHardSwish>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;
+    }
+    if constexpr (DBG) {
+        if (dbg) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg[4] = __builtin_amdgcn_s_memtime();
+        }
     }
 }
 

@@ -102,16 +102,18 @@ static void register_all_glds() {
 }
 // one-workgroup-per-board kernels (conv_board.h), by output-channel tile
 typedef void (*BoardFn)(const BoardParams);
-struct BoardEntry { int kot; BoardFn fn; BoardFn fn_se; size_t (*lds)(int); };
+typedef void (*BoardSeFn)(const BoardSeParams);
+struct BoardEntry { int kot; BoardFn fn; BoardSeFn fn_se; size_t (*lds)(int); };
 static const BoardEntry kBoardEntries[] = {
-    {256, &conv_board_kernel<4>, nullptr, &BoardCfg<4>::lds_bytes},
+    {256, &conv_board_kernel<4>, &conv_board_se_kernel<4>, &BoardCfg<4>::lds_bytes},  // SAYURI_BOARD_DBG=n swaps in <4, true> (timeline)
     {192, &conv_board_kernel<3>, nullptr, &BoardCfg<3>::lds_bytes},
-    {128, &conv_board_kernel<2>, nullptr, &BoardCfg<2>::lds_bytes},
+    {128, &conv_board_kernel<2>, &conv_board_se_kernel<2>, &BoardCfg<2>::lds_bytes},
 };
 static void enable_big_lds_glds() {
     register_all_glds();
     for (const auto& e : glds_entries())
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)&conv_board_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     for (const auto& e : kBoardEntries) {
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
         if (e.fn_se) (void)hipFuncSetAttribute((const void*)e.fn_se, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
@@ -211,7 +213,7 @@ static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_
 }
 
 // The one-workgroup-per-board plan of a batch geometry (conv_board.h): consecutive samples packed greedily.
-struct BoardPlan { int ntiles = 0, npos = 0; bool ok = false; double fill = 0; };
+struct BoardPlan { int ntiles = 0, npos = 0; bool ok = false, single = false; double fill = 0; };  // single: one sample per tile
 static BoardPlan board_plan(const HostGeom& geom) {
     BoardPlan bp;
     const ConvOverride ov = conv_override();
@@ -232,6 +234,7 @@ static BoardPlan board_plan(const HostGeom& geom) {
     ++bp.ntiles;
     bp.npos = round_up(max_pos, 64);
     bp.fill = (double)geom.total / ((double)bp.ntiles * kBoardPT);
+    bp.single = bp.ntiles == geom.n;
     bp.ok = true;
     return bp;
 }
@@ -516,6 +519,16 @@ public:
         const int rc = forward();
         profiling_ = false;
         if (rc) return -1;
+        if (d_dbg_) {  // SAYURI_BOARD_DBG: s_memtime timeline of the last tower convolution (workgroups 0-3, all waves)
+            std::vector<unsigned long long> h(4 * 8 * 8);
+            HIP_OK(hipMemcpy(h.data(), d_dbg_, h.size() * 8, hipMemcpyDeviceToHost));
+            for (int wg = 0; wg < 4; ++wg)
+                for (int w = 0; w < 8; ++w) {
+                    const unsigned long long* d = &h[((size_t)wg * 8 + w) * 8];
+                    fprintf(stderr, "[board timeline wg%d wave%d] tables+first DMA %llu | first barrier %llu | main loop %llu (sync %llu) | epilogue %llu | total %llu\n",
+                            wg, w, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[5], d[4] - d[3], d[4] - d[0]);
+                }
+        }
         int i = 0;
         for (auto& kv : stats_) {
             if (i >= cap) break;
@@ -860,6 +873,36 @@ private:
         return pick_board(board_plan_, L.ko_pad, kot_tiles);
     }
 
+    // A block's last 3x3 convolution with the squeeze-and-excitation unit that follows it inside the kernel
+    // (conv_board.h).  Returns 1 when the fused kernel does not apply (the caller then runs conv + se_unit), 0 / -1.
+    int conv_se(const ConvLayerDev& L, const FcLayerDev& sq, const FcLayerDev& ex, const T* in, T* out, const T* res, int C, int act) {
+        const char* sw = getenv("SAYURI_SE_FUSED");  // A/B switch, read per call so that a test can flip it between pipes
+        const bool off = sw && atoi(sw) == 0;
+        int bkt = 0;
+        const BoardEntry* be = off ? nullptr : choose_board(L, &bkt);
+        if (!be || !be->fn_se || bkt != 1 || !board_plan_.single || C > be->kot) return 1;
+        if (sq.out % 4 || sq.out > 512 || ex.out % 4 || ex.out > 2048 || 512 % (sq.out / 4) || 512 % (ex.out / 4)) return 1;
+        if constexpr (sizeof(T) != 2) return 1;
+        const BoardTabs* tabs = nullptr;
+        if (board_tabs(&tabs)) return -1;
+        BoardSeParams sp;
+        BoardParams& bp = sp.b;
+        bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos; bp.dbg = nullptr;
+        ConvParams& p = bp.c;
+        p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
+        p.g = dgeom();
+        p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
+        p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = board_plan_.ntiles;
+        sp.squeeze = sq.dev(); sp.excite = ex.dev(); sp.C = C;
+        const double px = geom_.total;
+        const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out);
+        const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
+        const auto fn = be->fn_se;
+        const size_t lds = be->lds(board_plan_.npos);
+        const int grid = board_plan_.ntiles;
+        return timed("conv3x3_tower_se", flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, sp); });
+    }
+
     int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
         int bkt = 0;
         if (const BoardEntry* be = choose_board(L, &bkt)) {
@@ -867,6 +910,24 @@ private:
             if (board_tabs(&tabs)) return -1;
             BoardParams bp;
             bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos;
+            bp.dbg = nullptr;
+            auto fn = be->fn;
+            if (be->kot == 256 && getenv("SAYURI_BOARD_DBG") && !strcmp(name, "conv3x3_tower")) {
+                // in-kernel timeline of the SAYURI_BOARD_DBG-th tower convolution of the forward (1 = first)
+                if (!d_dbg_ && dev_alloc(&d_dbg_, 4 * 8 * 8)) return -1;
+                if (++dbg_call_ == atoi(getenv("SAYURI_BOARD_DBG"))) {
+                    bp.dbg = d_dbg_;
+                    fn = &conv_board_kernel<4, true>;
+                }
+            }
+            if (be->kot == 256) {
+                static const int prio = getenv("SAYURI_BOARD_PRIO") ? atoi(getenv("SAYURI_BOARD_PRIO")) : 0;  // experiment
+                const bool d = bp.dbg != nullptr;
+                if (prio == 1) fn = d ? &conv_board_kernel<4, true, 1> : &conv_board_kernel<4, false, 1>;
+                if (prio == 2) fn = d ? &conv_board_kernel<4, true, 2> : &conv_board_kernel<4, false, 2>;
+                if (prio == 3) fn = d ? &conv_board_kernel<4, true, 3> : &conv_board_kernel<4, false, 3>;
+                (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+            }
             ConvParams& p = bp.c;
             p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
             p.g = dgeom();
@@ -876,7 +937,6 @@ private:
             const double px = geom_.total;
             const double flops = 2.0 * px * L.cin * L.cout * 9;
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
-            const auto fn = be->fn;
             const size_t lds = be->lds(board_plan_.npos);
             const int grid = board_plan_.ntiles * bkt;
             return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, bp); });
@@ -974,6 +1034,7 @@ private:
         const int C = d.residual_channels, csC = round_up(C, 32), act = d.default_act;
         const BatchGeom g = dgeom();
         for (int i = 0; i < kNumBufs; ++i) busy_[i] = false;
+        dbg_call_ = 0;
 
         int x = take();
         {
@@ -998,10 +1059,20 @@ private:
             const int last_act = se ? (int)kIdentity : act;
             const int y = take();
             int skip = x;  // buffer added back at the end of the block
+            bool se_done = false;  // the SE unit already ran inside the block's last convolution
             if (bd.type == SAYURI_BLOCK_RESIDUAL) {
                 const int t0 = take();
                 if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[x], bufs_[t0], nullptr, act)) return -1;
-                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t0], bufs_[y], se ? nullptr : bufs_[x], last_act)) return -1;
+                int fused = 1;
+                if (se) {
+                    fused = conv_se(cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)),
+                                    fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[t0], bufs_[y], bufs_[x], C, act);
+                    if (fused < 0) return -1;
+                    se_done = fused == 0;
+                }
+                if (fused == 1 &&
+                    conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t0], bufs_[y], se ? nullptr : bufs_[x], last_act))
+                    return -1;
                 give(t0);
             } else if (bd.type == SAYURI_BLOCK_BOTTLENECK) {
                 const int t0 = take(), t1 = take();
@@ -1029,7 +1100,7 @@ private:
                 x = s2;
                 skip = s2;
             }
-            if (se) {
+            if (se && !se_done) {
                 if (se_unit(fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)), fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[y],
                             bufs_[skip], C, csC, act))
                     return -1;
@@ -1119,6 +1190,8 @@ private:
     std::vector<int> prev_bsz_;
     std::map<int, GldsChoice> glds_cache_;
     BoardPlan board_plan_;
+    unsigned long long* d_dbg_ = nullptr;  // SAYURI_BOARD_DBG timeline of one tower convolution
+    int dbg_call_ = 0;
     bool board_plan_valid_ = false;
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;
@@ -1360,7 +1433,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
                 if (!tsrc || !tpix || !tcols) { cleanup(); return fail("test_conv: hipMalloc failed"); }
                 hipLaunchKernelGGL(board_setup_kernel, dim3(plan.ntiles), dim3(256), 0, 0, g, plan.npos, tsrc, tpix, tcols);
                 BoardParams bp;
-                bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos;
+                bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos; bp.dbg = nullptr;
                 ConvParams& p = bp.c;
                 p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
                 p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;

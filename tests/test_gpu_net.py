@@ -167,3 +167,28 @@ def test_reconstruct_smaller_board(tmp_weights_dir):
             assert np.abs(got - oracle.forward(x, 9)).max() <= FP32_ATOL
     finally:
         pipe.Destroy()
+
+
+def test_se_unit_fused_into_the_convolution_matches_the_separate_kernels(tmp_weights_dir, monkeypatch):
+    """20b256 has a squeeze-and-excitation unit on every third block.  With one sample per board tile the unit runs
+    inside the block's second convolution (conv_board.h: pooling over the accumulators, both FCs, the gate); with
+    SAYURI_SE_FUSED=0 it runs as se_pool / se_fc / se_scale on the fp16 activations.  Both against the oracle, and against
+    each other: they differ only by where x is rounded to fp16."""
+    g = Golden("net_20b256", tmp_weights_dir)
+    oracle = PortNet(g.weights_path)
+    bsz = [19, 13, 19, 9, 19, 19, 7, 19]  # no two neighbours of one size: every tile holds one sample
+    planes = W.synthetic_planes(len(bsz), bsz, seed=4242)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SAYURI_SE_FUSED", mode)
+        pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=True)
+        try:
+            outs[mode] = pipe.BatchForward(planes, bsz)
+        finally:
+            pipe.Destroy()
+    for i, (p, bs) in enumerate(zip(planes, bsz)):
+        exp = oracle.forward(p, bs)
+        assert np.abs(outs["1"][i] - exp).max() <= FP16_ATOL, (i, bs)
+        assert np.abs(outs["0"][i] - exp).max() <= FP16_ATOL, (i, bs)
+        assert np.abs(outs["1"][i] - outs["0"][i]).max() <= FP16_ATOL
+        assert np.abs(outs["1"][i] - outs["0"][i]).max() > 0, "the switch did not change the path"
