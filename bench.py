@@ -60,6 +60,19 @@ def algorithmic_flops_per_eval(spec, board: int = 19) -> float:
     return 2.0 * mac
 
 
+def hbm_traffic(fp16: bool) -> dict:
+    """HBM-side bytes per launch of the dominant kernel, from the rocprofv3 PMC passes kept under profiles/ (counters
+    cannot be read from inside this process; MI355X_MICROARCH.md HBM section: separate --pmc passes, FETCH_SIZE x 2)."""
+    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    algo = 2 * 256 * 361 * 256 * 2 + 256 * 256 * 9 * 2  # in + out + weights of one 256->256 layer, fp16, batch 256
+    if not fp16 or not os.path.exists(path):
+        return {"traffic": None, "algorithmic_bytes": algo}
+    t = json.load(open(path))
+    tot = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
+    return {"traffic": tot, "traffic_read": t["read_bytes_per_launch"], "traffic_write": t["write_bytes_per_launch"],
+            "algorithmic_bytes": algo, "traffic_over_algorithmic": round(tot / algo, 3), "traffic_source": t["source"]}
+
+
 def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
     """Time the CPU pipe on this box's host cores on a bounded sample of the same workload.
     Prefers the reference's own BlasForwardPipe (oracle/_ref, kind "reference"); falls back to
@@ -93,7 +106,8 @@ def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
     total = sum(counts)
     return {"value": round(total / dt, 3), "unit": "evals/s", "cores": threads, "kind": kind,
             "sample": f"{total} evals of the same 20b256 19x19 net in {dt:.1f}s, {threads} threads x batch 1 "
-                      f"(1 thread alone: {1.0 / one:.2f} evals/s)"}
+                      f"(1 thread alone: {1.0 / one:.2f} evals/s); the reference's BlasForwardPipe with its BUILT_IN sgemm -- "
+                      "Eigen / OpenBLAS are not in this image, the three CPU variants differ only in the GEMM call (blas.cc:16-166)"}
 
 
 def main():
@@ -106,8 +120,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile", action="store_true", help="also print the per-kernel-class table to stderr")
-    ap.add_argument("--selfplay-seconds", type=float, default=40.0,
+    ap.add_argument("--selfplay-seconds", type=float, default=150.0,
                     help="length of the self-play window (configs[2]: 512 concurrent 19x19 games, 400 visits); 0 = skip")
+    ap.add_argument("--selfplay-stagger", type=int, default=360,
+                    help="the first game of worker g starts after g*N/games policy-sampled moves (0 = every game from move 0): "
+                         "a window of minutes then sees games in every phase, as hours of self-play do, and games/hour can be counted")
+    ap.add_argument("--config5", action="store_true",
+                    help="also time configs[4]: 40-block x 384 net, batch 256 of mixed 9/13/19 boards (adds ~1 min of weight generation)")
     ap.add_argument("--selfplay-games", type=int, default=512, help="concurrent self-play games per GPU")
     ap.add_argument("--selfplay-visits", type=int, default=400)
     args = ap.parse_args()
@@ -130,9 +149,13 @@ def main():
 
     lib = _lib.hip()
     spec = W.spec_20b256()
-    wpath = f"/tmp/sayuri_bench_20b256_seed22_{os.getuid()}.bin"
+    # a directory of its own: the self-play loop watches it for newer networks (reference ShouldHalt, engine.cc:63-90)
+    wdir = f"/tmp/sayuri_bench_weights_{os.getuid()}"
+    wpath = os.path.join(wdir, "net_20b256_seed22.bin")
     if local_rank == 0 and not os.path.exists(wpath):
-        W.write_weights(wpath, spec, seed=22)
+        os.makedirs(wdir, exist_ok=True)
+        W.write_weights(wpath + ".tmp", spec, seed=22)
+        os.replace(wpath + ".tmp", wpath)
     if dist is not None:
         dist.barrier()
     else:
@@ -179,9 +202,9 @@ def main():
     stat = _lib.KernelStat()
     lib.sayuri_hip_timed_stat(ctx, ctypes.byref(stat))
 
+    from sayuri_amd.shard import gather_stats
     if dist is not None:
-        # the path's only exchange: one small stats record per rank (RCCL all-gather)
-        from sayuri_amd.shard import gather_stats
+        # one small stats record per rank (RCCL all-gather)
         stats = gather_stats({"games_done": 0, "nn_queries": n * args.steps, "nn_batches": args.steps,
                               "elapsed": elapsed})
         elapsed = stats["elapsed_max"]
@@ -192,30 +215,47 @@ def main():
     selfplay = None
     if args.selfplay_seconds > 0:
         from sayuri_amd import search as S
-        from sayuri_amd.shard import gather_stats
+        from sayuri_amd.shard import PeriodicGather
         sp_opts = dict(playouts=args.selfplay_visits, parallel_games=args.selfplay_games, num_games=1000000, seed=1000 + rank,
                        dirichlet_noise=1, dirichlet_epsilon=0.25, dirichlet_init=0.03, dirichlet_factor=361, first_pass_bonus=1,
                        random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
                        resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
-                       selfplay_query=["bkp:19:7:1"])
+                       selfplay_query=["bkp:19:7:1"], stagger_moves=args.selfplay_stagger, weights_dir=wdir, weights_file=wpath)
         if dist is not None:
             dist.barrier()
-        st = S.selfplay(pipe, sp_opts, seconds=args.selfplay_seconds, name_suffix=f"-r{rank}")
-        pt = pipe.pump_times()
-        tot = gather_stats({"games_done": st["games_done"], "nn_queries": st["nn_queries"], "nn_batches": pt["batches"],
-                            "cache_hits": st["cache_hits"], "moves": st["moves"], "playouts": st["playouts"], "records": st["records"],
-                            "elapsed": st["elapsed"]})
+        # the path's only exchange: every 2 s each rank contributes its counters and its halt wish (newer weights seen);
+        # RCCL all-gather of ~80 bytes per rank (sayuri_amd/shard.py)
+        pg = PeriodicGather()
+        batches0 = pipe.pump_times()["batches"]
+
+        def local_record(st):
+            return {"games_done": st["games_done"], "nn_queries": st["nn_queries"], "nn_batches": pipe.pump_times()["batches"] - batches0,
+                    "cache_hits": st["cache_hits"], "moves": st["moves"], "playouts": st["playouts"], "records": st["records"],
+                    "elapsed": st["elapsed"]}
+
+        st = S.selfplay(pipe, sp_opts, seconds=args.selfplay_seconds, name_suffix=f"-r{rank}",
+                        on_stats=lambda snap, halt: pg.tick(local_record(snap), halt=halt), stats_interval=2.0)
+        tot = pg.drain(local_record(st))
+        fin = gather_stats({"games_done": st["finished_moves"], "moves": st["prerolled_moves"], "elapsed": st["elapsed"]})
         el = tot["elapsed_max"]
-        selfplay = {"workload": "configs[2]: 19x19, 20b x 256 net, %d visits/move, %d concurrent games per GPU, Dirichlet noise, "
-                                "NN cache 400 MiB; time window (games in progress are not counted as done)" % (args.selfplay_visits, args.selfplay_games),
+        games, finished_moves = int(tot["games_done"]), int(fin["games_done"])
+        moves_per_sec = tot["moves"] / el
+        mean_len = finished_moves / games if games else None
+        selfplay = {"workload": "configs[2]: 19x19, 20b x 256 net, %d visits/move, %d concurrent games per GPU, Dirichlet noise, NN cache "
+                                "400 MiB; %.0f s window; the first game of worker g starts after g*%d/%d policy-sampled moves so that the "
+                                "window sees games in every phase (games still running at the end are not counted)"
+                                % (args.selfplay_visits, args.selfplay_games, args.selfplay_seconds, args.selfplay_stagger, args.selfplay_games),
                     "seconds": round(el, 2), "nn_evals_per_sec": round(tot["nn_queries"] / el, 1),
-                    "playouts_per_sec": round(tot["playouts"] / el, 1), "moves_per_sec": round(tot["moves"] / el, 2),
-                    "games_done": int(tot["games_done"]),
-                    # a 19x19 game needs ~15-25 minutes of wall clock at 512 concurrent games, so a short window ends before
-                    # the first game does; games/hour is measured by tools/selfplay_bench.py over a long window
-                    # (profiles/r01_selfplay_27min_512games_3stream.json: 1518 games/hour on one MI355X)
-                    "games_per_hour_in_window": (round(tot["games_done"] / el * 3600, 1) if tot["games_done"] > 0 else None),
+                    "playouts_per_sec": round(tot["playouts"] / el, 1), "moves_per_sec": round(moves_per_sec, 2),
+                    "games_done": games,
+                    # reference definition: played games / wall (src/selfplay/pipe.cc:272-280)
+                    "games_per_hour": round(games / el * 3600, 1) if games else None,
+                    "mean_moves_per_finished_game": round(mean_len, 1) if mean_len else None,
+                    # the same rate from the move counter: searched moves per second / moves a finished game had
+                    "games_per_hour_from_move_rate": round(moves_per_sec * 3600 / mean_len, 1) if mean_len else None,
+                    "prerolled_moves": int(fin["moves"]),
                     "mean_batch": round(tot["nn_queries"] / max(tot["nn_batches"], 1), 1),
+                    "exchange_rounds": pg.rounds, "halt_seen": bool(pg.any_halt),
                     "frac_of_microbench_evals": None}
 
     result = None
@@ -239,9 +279,9 @@ def main():
                        "whole_net_tflops": round(value * flops_eval / 1e12, 2),
                        "whole_net_mfma_frac": round(value * flops_eval / 1e12 / (peak * world), 4),
                        "device_ms_per_step": round(ms.value / args.steps, 4)},
-            "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<8,3> (conv3x3_tower, 256->256 3x3)",
+            "roofline": {"bound": "mfma", "kernel": "conv_board_kernel<4> (conv3x3_tower: 256->256 3x3, one workgroup per board)",
                          "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4) if ach else None, "traffic": None,
+                         "frac": round(ach / peak, 4) if ach else None, **hbm_traffic(fp16),
                          "launches_timed": int(stat.launches),
                          "avg_launch_us": round(stat.total_ms / max(stat.launches, 1) * 1e3, 2),
                          "flops_per_launch": stat.flops / max(stat.launches, 1)},

@@ -172,6 +172,21 @@ int sayuri_hip_test_conv(int device, int use_fp16, int n, const int* board_sizes
 /* Kernel family the calling thread's last sayuri_hip_test_conv ran: 0 generic implicit GEMM (conv_mfma.h),
  * 1 LDS-DMA tiles across samples (conv_glds.h), 2 one workgroup per board (conv_board.h), 3 depthwise. */
 int sayuri_hip_test_last_conv_kind(void);
+/* One squeeze-and-excitation unit through the se_pool / se_fc / se_scale kernels (reference SEUnit::Forward,
+ * src/neural/blas/se_unit.cc:70-128): x, res (or NULL), y are [n][channels][bs*bs] like sayuri_hip_test_conv's tensors,
+ * w1 [se_size][3*channels], b1 [se_size], w2 [2*channels][se_size], b2 [2*channels];
+ * gate (or NULL) receives [n][2*channels] = sigmoid(gamma) | beta, i.e. GlobalPooling<false> + both FullyConnects. */
+int sayuri_hip_test_se_unit(int device, int use_fp16, int n, const int* board_sizes, int max_board, int channels,
+                            int se_size, int act, const float* x, const float* res, const float* w1, const float* b1,
+                            const float* w2, const float* b2, float* y, float* gate);
+/* Everything after the two head convolutions in one launch (head_tail_kernel; reference blas_forward_pipe.cc:496-580):
+ * pconv [n][policy_channels][bs*bs], vconv [n][value_channels][bs*bs] (activated head convolutions),
+ * weights12 = { p_inter w [Cp][3Cp], b; pass_fc w [pass_outs][Cp], b; v_inter w [3Cv][3Cv], b; v_misc w [misc_outs][3Cv], b;
+ * prob_conv w [prob_channels][Cp], b; ownership w [Cv], b[1] };  outputs in the NN grid as sayuri_hip_forward's. */
+int sayuri_hip_test_head_tail(int device, int use_fp16, int n, const int* board_sizes, int max_board, int policy_channels,
+                              int value_channels, int prob_channels, int pass_outs, int misc_outs, int act,
+                              const float* pconv, const float* vconv, const float* const* weights12, float* prob,
+                              float* pass, float* misc, float* own);
 
 #ifdef __cplusplus
 }

@@ -365,6 +365,56 @@ static void se_unit(int bs, int C, const so_block* b, float* x, const float* res
     free(mid);
 }
 
+/* ---- layer-level taps for the kernel tests (tests/test_gpu_smallops.py): the static restatements above, callable.
+ * They are the same code the whole-network goldens pin (tests/test_oracle.py). */
+void so_tap_global_pool(int bs, int C, const float* x, float* out, int value_head) { global_pool(bs, C, x, out, value_head); }
+void so_tap_fully_connect(int cin, int cout, const float* w, const float* b, const float* in, float* out, int act) {
+    so_fc fc;
+    memset(&fc, 0, sizeof(fc));
+    fc.cin = cin; fc.cout = cout; fc.w = (float*)w; fc.b = (float*)b;
+    fully_connect(&fc, in, out, act);
+}
+/* SEUnit::Forward on x [C][bs*bs] in place (se_unit.cc:70-128); w1 [se][3C], w2 [2C][se] */
+void so_tap_se_unit(int bs, int C, int se, const float* w1, const float* b1, const float* w2, const float* b2, float* x,
+                    const float* res, int act) {
+    so_block b;
+    memset(&b, 0, sizeof(b));
+    b.se = 1; b.se_size = se;
+    b.squeeze.cin = 3 * C; b.squeeze.cout = se; b.squeeze.w = (float*)w1; b.squeeze.b = (float*)b1;
+    b.excite.cin = se; b.excite.cout = 2 * C; b.excite.w = (float*)w2; b.excite.b = (float*)b2;
+    se_unit(bs, C, &b, x, res, act);
+}
+/* everything after the two head convolutions (blas_forward_pipe.cc:496-580): pconv [PC][S] and vconv [VC][S] are the
+ * activated head convolutions; outputs prob [prob_ch][S], pass [pass_outs], own [S], misc [misc_outs] */
+void so_tap_head_tail(int bs, int PC, int VC, int prob_ch, int pass_outs, int misc_outs, int act, float* pconv, const float* vconv,
+                      const float* p_inter_w, const float* p_inter_b, const float* pass_w, const float* pass_b,
+                      const float* v_inter_w, const float* v_inter_b, const float* v_misc_w, const float* v_misc_b,
+                      const float* prob_w, const float* prob_b, const float* own_w, const float* own_b,
+                      float* prob, float* pass, float* own, float* misc) {
+    const int maxi = PC > VC ? PC : VC;
+    float* pool = (float*)malloc(sizeof(float) * 3 * maxi);
+    float* inter = (float*)malloc(sizeof(float) * 3 * maxi);
+    so_fc fc;
+    memset(&fc, 0, sizeof(fc));
+    global_pool(bs, PC, pconv, pool, 0);
+    fc.cin = 3 * PC; fc.cout = PC; fc.w = (float*)p_inter_w; fc.b = (float*)p_inter_b;
+    fully_connect(&fc, pool, inter, act);
+    add_spatial(bs, PC, pconv, inter, NULL, ACT_IDENTITY);
+    conv1(bs, PC, prob_ch, pconv, prob_w, prob);
+    add_spatial(bs, prob_ch, prob, prob_b, NULL, ACT_IDENTITY);
+    fc.cin = PC; fc.cout = pass_outs; fc.w = (float*)pass_w; fc.b = (float*)pass_b;
+    fully_connect(&fc, inter, pass, ACT_IDENTITY);
+    global_pool(bs, VC, vconv, pool, 1);
+    fc.cin = 3 * VC; fc.cout = 3 * VC; fc.w = (float*)v_inter_w; fc.b = (float*)v_inter_b;
+    fully_connect(&fc, pool, inter, act);
+    conv1(bs, VC, 1, vconv, own_w, own);
+    add_spatial(bs, 1, own, own_b, NULL, ACT_IDENTITY);
+    fc.cin = 3 * VC; fc.cout = misc_outs; fc.w = (float*)v_misc_w; fc.b = (float*)v_misc_b;
+    fully_connect(&fc, inter, misc, ACT_IDENTITY);
+    free(pool);
+    free(inter);
+}
+
 /* ------------------------------------------------------------------ forward
  * blas_forward_pipe.cc:46-563.  Buffers are named by role instead of the reference's
  * swap dance: `x` is the block input (the skip), `y` the block output. */

@@ -171,9 +171,10 @@ void sayuri_engine_search_update_territory_helper(void* s) { static_cast<Search*
 static thread_local std::string g_engine_err;
 const char* sayuri_engine_last_error() { return g_engine_err.c_str(); }
 namespace {
-void PackStats(const SelfplayStats& st, std::uint64_t* v) {
-    const std::uint64_t a[10] = {st.games_started, st.games_done, st.moves, st.playouts, st.nn_queries,
-                                 st.cache_lookups, st.cache_hits, st.records, st.chunks_saved, 0};
+void PackStats(const SelfplayStats& st, std::uint64_t* v) {  // the 12 slots of sayuri_selfplay_run_ex
+    const std::uint64_t a[12] = {st.games_started, st.games_done, st.moves, st.playouts, st.nn_queries,
+                                 st.cache_lookups, st.cache_hits, st.records, st.chunks_saved, 0,
+                                 st.finished_moves, st.prerolled_moves};
     std::memcpy(v, a, sizeof(a));
 }
 struct StatsHook {
@@ -182,7 +183,7 @@ struct StatsHook {
 };
 int StatsTrampoline(const SelfplayStats* st, int local_halt, void* user) {
     const StatsHook* h = static_cast<const StatsHook*>(user);
-    std::uint64_t v[10];
+    std::uint64_t v[12];
     PackStats(*st, v);
     return h->fn(v, st->elapsed, local_halt, h->user);
 }
@@ -213,8 +214,10 @@ int sayuri_selfplay_run_ex(void* raw_pipe, int weights_version, const char* opti
 
 int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
                         int move_cap, std::uint64_t* stats, double* elapsed) {
-    return sayuri_selfplay_run_ex(raw_pipe, weights_version, options, name_suffix, seconds, move_cap, nullptr, nullptr, 0.0, stats,
-                                  elapsed);
+    std::uint64_t v[12];
+    const int rc = sayuri_selfplay_run_ex(raw_pipe, weights_version, options, name_suffix, seconds, move_cap, nullptr, nullptr, 0.0, v, elapsed);
+    if (rc == 0) std::memcpy(stats, v, sizeof(std::uint64_t) * 10);
+    return rc;
 }
 
 // The network evaluation facade on a forward pipe (for GPU parity tests of search moves).

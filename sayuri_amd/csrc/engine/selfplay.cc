@@ -489,8 +489,11 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                 started.fetch_add(1);
                 auto item = std::make_shared<DataSgf>();
                 engine_.PrepareGame(g);
-                if (first_game && opt_.selfplay.stagger_moves > 0)
+                if (first_game && opt_.selfplay.stagger_moves > 0) {
+                    const int before = engine_.state(g).GetMoveNumber();
                     engine_.PlayPolicyMoves(g, static_cast<int>(static_cast<long long>(g) * opt_.selfplay.stagger_moves / std::max(games, 1)));
+                    prerolled_moves_.fetch_add(static_cast<std::uint64_t>(engine_.state(g).GetMoveNumber() - before));
+                }
                 first_game = false;
                 // the game loop, abandoned between moves when the clock has run out
                 Search& search = engine_.search(g);
@@ -506,6 +509,7 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                     break;
                 }
                 search.UpdateTerritoryHelper();
+                finished_moves_.fetch_add(static_cast<std::uint64_t>(engine_.state(g).GetMoveNumber()));
                 engine_.GatherTrainingData(item->first, g);
                 item->second = engine_.GatherSgfString(g);
                 const int played = played_games_.fetch_add(1) + 1;
@@ -529,6 +533,8 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
         st.nn_queries = engine_.network().GetNumQueries();
         st.cache_lookups = engine_.network().cache().lookups();
         st.cache_hits = engine_.network().cache().hits();
+        st.finished_moves = finished_moves_.load();
+        st.prerolled_moves = prerolled_moves_.load();
         st.elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     };
     SelfplayStats st;

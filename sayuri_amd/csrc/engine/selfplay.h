@@ -24,6 +24,8 @@ namespace sayuri_engine {
 struct SelfplayStats {
     std::uint64_t games_started{0}, games_done{0}, moves{0}, playouts{0};
     std::uint64_t nn_queries{0}, cache_lookups{0}, cache_hits{0}, records{0}, chunks_saved{0};
+    std::uint64_t finished_moves{0};   // sum of the move numbers of the finished games (their full length)
+    std::uint64_t prerolled_moves{0};  // policy-sampled moves played by the stagger_moves option (not searched, not recorded)
     double elapsed{0};
 };
 
@@ -107,7 +109,7 @@ private:
     std::atomic<bool> writer_running_{false};
     std::atomic<int> accumulation_games_{0}, played_games_{0};
     std::atomic<bool> stop_{false};
-    std::atomic<std::uint64_t> records_{0}, chunks_{0};
+    std::atomic<std::uint64_t> records_{0}, chunks_{0}, finished_moves_{0}, prerolled_moves_{0};
     std::atomic<int> max_games_{0};
     std::atomic<bool> halt_wish_{false};     // set by worker 0 (ShouldHalt) or by the stats callback's verdict
     void WindDown();                         // pipe.cc:248-254

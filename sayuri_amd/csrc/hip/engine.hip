@@ -1507,6 +1507,194 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
 
 }  // namespace sayuri
 
+// ---------------------------------------------------------------------- small-op test taps
+namespace sayuri {
+
+struct TestGeom {
+    HostGeom hg;
+    int slot = 0;
+    int* d_off = nullptr;
+    int* d_bsz = nullptr;
+    BatchGeom g{};
+};
+
+class TestArena {  // device allocations of one tap call, freed at scope exit
+public:
+    ~TestArena() { for (void* p : ptrs_) (void)hipFree(p); }
+    void* alloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, std::max<size_t>(bytes, 256));
+        ptrs_.push_back(p);
+        return p;
+    }
+    template <typename U> U* upload(const std::vector<U>& h) {
+        U* d = (U*)alloc(h.size() * sizeof(U));
+        if (d && hipMemcpy(d, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    }
+private:
+    std::vector<void*> ptrs_;
+};
+
+static int make_test_geom(TestArena& A, int n, const int* board_sizes, int max_board, TestGeom* tg) {
+    tg->hg.n = n;
+    tg->hg.bsz.assign(board_sizes, board_sizes + n);
+    tg->hg.off.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        if (tg->hg.bsz[i] < 2 || tg->hg.bsz[i] > max_board) return fail("test tap: bad board size");
+        tg->hg.off[i + 1] = tg->hg.off[i] + tg->hg.bsz[i] * tg->hg.bsz[i];
+    }
+    tg->hg.total = tg->hg.off[n];
+    tg->slot = max_board * max_board;
+    tg->d_off = A.upload(tg->hg.off);
+    tg->d_bsz = A.upload(tg->hg.bsz);
+    if (!tg->d_off || !tg->d_bsz) return fail("test tap: hipMalloc failed");
+    tg->g = BatchGeom{tg->d_off, tg->d_bsz, n, tg->hg.total, tg->slot};
+    return 0;
+}
+// host NCHW (compact per sample) <-> compact NHWC
+template <typename T> static std::vector<T> nchw_to_nhwc(const TestGeom& tg, const float* src, int C, int cs) {
+    std::vector<T> h((size_t)tg.hg.n * tg.slot * cs, (T)0.f);
+    size_t so = 0;
+    for (int i = 0; i < tg.hg.n; ++i) {
+        const int S = tg.hg.bsz[i] * tg.hg.bsz[i];
+        for (int c = 0; c < C; ++c)
+            for (int p = 0; p < S; ++p) h[((size_t)i * tg.slot + p) * cs + c] = (T)src[so + (size_t)c * S + p];
+        so += (size_t)C * S;
+    }
+    return h;
+}
+static std::vector<float> fc_transposed(const float* w, int in, int out) {  // [out][in] -> [in][out]
+    std::vector<float> t((size_t)in * out);
+    for (int o = 0; o < out; ++o)
+        for (int i = 0; i < in; ++i) t[(size_t)i * out + o] = w[(size_t)o * in + i];
+    return t;
+}
+
+template <typename T>
+static int test_se_unit_impl(int device, int n, const int* board_sizes, int max_board, int C, int se, int act, const float* x,
+                             const float* res, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
+                             float* gate_out) {
+    HIP_OK(hipSetDevice(device));
+    TestArena A;
+    TestGeom tg;
+    if (make_test_geom(A, n, board_sizes, max_board, &tg)) return -1;
+    const int cs = round_up(C, 32);
+    constexpr int EPP = ElemTraits<T>::kPieceElems;
+    if (cs / EPP > 256) return fail("test_se_unit: too many channels");
+    T* dx = A.upload(nchw_to_nhwc<T>(tg, x, C, cs));
+    T* dres = res ? A.upload(nchw_to_nhwc<T>(tg, res, C, cs)) : nullptr;
+    float* dw1 = A.upload(fc_transposed(w1, 3 * C, se));
+    float* dw2 = A.upload(fc_transposed(w2, se, 2 * C));
+    float* db1 = A.upload(std::vector<float>(b1, b1 + se));
+    float* db2 = A.upload(std::vector<float>(b2, b2 + 2 * C));
+    float* separt = (float*)A.alloc(sizeof(float) * (size_t)n * kSeSplit * 2 * cs);
+    float* gate = (float*)A.alloc(sizeof(float) * (size_t)n * 2 * cs);
+    if (!dx || (res && !dres) || !dw1 || !dw2 || !db1 || !db2 || !separt || !gate) return fail("test_se_unit: hipMalloc failed");
+    const FcDev sq{dw1, db1, 3 * C, se}, ex{dw2, db2, se, 2 * C};
+    hipLaunchKernelGGL(se_pool_kernel<T>, dim3(n * kSeSplit), dim3(256), 0, 0, (const T*)dx, separt, tg.g, cs);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(256), sizeof(float) * (3 * C + se + 256), 0, (const float*)separt, gate, tg.g, C, cs, sq,
+                       ex, act);
+    const int ppr = cs / EPP;
+    const dim3 grid((tg.slot * ppr + 256 * kScaleUnroll - 1) / (256 * kScaleUnroll), n);
+    hipLaunchKernelGGL(se_scale_kernel<T>, grid, dim3(256), 0, 0, (const T*)dx, (const T*)dres, dx, (const float*)gate, tg.g, C, cs, act);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<T> hy((size_t)n * tg.slot * cs);
+    HIP_OK(hipMemcpy(hy.data(), dx, hy.size() * sizeof(T), hipMemcpyDeviceToHost));
+    size_t so = 0;
+    for (int i = 0; i < n; ++i) {
+        const int S = tg.hg.bsz[i] * tg.hg.bsz[i];
+        for (int c = 0; c < C; ++c)
+            for (int pp = 0; pp < S; ++pp) y[so + (size_t)c * S + pp] = (float)hy[((size_t)i * tg.slot + pp) * cs + c];
+        so += (size_t)C * S;
+    }
+    if (gate_out) {
+        std::vector<float> hg((size_t)n * 2 * cs);
+        HIP_OK(hipMemcpy(hg.data(), gate, hg.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < C; ++c) {
+                gate_out[(size_t)i * 2 * C + c] = hg[(size_t)i * 2 * cs + c];
+                gate_out[(size_t)i * 2 * C + C + c] = hg[(size_t)i * 2 * cs + cs + c];
+            }
+    }
+    return 0;
+}
+
+template <typename T>
+static int test_head_tail_impl(int device, int n, const int* board_sizes, int max_board, int Cp, int Cv, int prob_ch, int pass_outs,
+                               int misc_outs, int act, const float* pconv, const float* vconv, const float* const* w, float* prob,
+                               float* pass, float* misc, float* own) {
+    // w: p_inter_w, p_inter_b, pass_w, pass_b, v_inter_w, v_inter_b, v_misc_w, v_misc_b, prob_w, prob_b, own_w, own_b
+    HIP_OK(hipSetDevice(device));
+    TestArena A;
+    TestGeom tg;
+    if (make_test_geom(A, n, board_sizes, max_board, &tg)) return -1;
+    if (prob_ch > 8) return fail("test_head_tail: too many policy planes");
+    const int cs_p = round_up(Cp, 32), cs_v = round_up(Cv, 32), B2 = max_board * max_board;
+    T* dp = A.upload(nchw_to_nhwc<T>(tg, pconv, Cp, cs_p));
+    T* dv = A.upload(nchw_to_nhwc<T>(tg, vconv, Cv, cs_v));
+    HeadParams h;
+    float* d_pi = A.upload(fc_transposed(w[0], 3 * Cp, Cp));
+    float* d_pib = A.upload(std::vector<float>(w[1], w[1] + Cp));
+    float* d_pw = A.upload(fc_transposed(w[2], Cp, pass_outs));
+    float* d_pwb = A.upload(std::vector<float>(w[3], w[3] + pass_outs));
+    float* d_vi = A.upload(fc_transposed(w[4], 3 * Cv, 3 * Cv));
+    float* d_vib = A.upload(std::vector<float>(w[5], w[5] + 3 * Cv));
+    float* d_vm = A.upload(fc_transposed(w[6], 3 * Cv, misc_outs));
+    float* d_vmb = A.upload(std::vector<float>(w[7], w[7] + misc_outs));
+    float* d_prw = A.upload(std::vector<float>(w[8], w[8] + (size_t)prob_ch * Cp));
+    float* d_prb = A.upload(std::vector<float>(w[9], w[9] + prob_ch));
+    float* d_ow = A.upload(std::vector<float>(w[10], w[10] + Cv));
+    float* d_ob = A.upload(std::vector<float>(w[11], w[11] + 1));
+    float* d_prob = (float*)A.alloc(sizeof(float) * (size_t)n * prob_ch * B2);
+    float* d_pass = (float*)A.alloc(sizeof(float) * (size_t)n * pass_outs);
+    float* d_misc = (float*)A.alloc(sizeof(float) * (size_t)n * misc_outs);
+    float* d_own = (float*)A.alloc(sizeof(float) * (size_t)n * B2);
+    if (!dp || !dv || !d_pi || !d_pib || !d_pw || !d_pwb || !d_vi || !d_vib || !d_vm || !d_vmb || !d_prw || !d_prb || !d_ow || !d_ob ||
+        !d_prob || !d_pass || !d_misc || !d_own)
+        return fail("test_head_tail: hipMalloc failed");
+    h.p_inter = FcDev{d_pi, d_pib, 3 * Cp, Cp};
+    h.pass_fc = FcDev{d_pw, d_pwb, Cp, pass_outs};
+    h.v_inter = FcDev{d_vi, d_vib, 3 * Cv, 3 * Cv};
+    h.v_misc = FcDev{d_vm, d_vmb, 3 * Cv, misc_outs};
+    h.prob_w = d_prw; h.prob_b = d_prb; h.own_w = d_ow; h.own_b = d_ob;
+    h.Cp = Cp; h.cs_p = cs_p; h.Cv = Cv; h.cs_v = cs_v; h.prob_ch = prob_ch; h.act = act; h.board = max_board;
+    h.prob = d_prob; h.pass = d_pass; h.misc = d_misc; h.own = d_own;
+    const int maxc = std::max(Cp, Cv);
+    hipLaunchKernelGGL(head_tail_kernel<T>, dim3(2 * n), dim3(256), sizeof(float) * (7 * maxc + 512), 0, (const T*)dp, (const T*)dv, tg.g, h);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(prob, d_prob, sizeof(float) * (size_t)n * prob_ch * B2, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(pass, d_pass, sizeof(float) * (size_t)n * pass_outs, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(misc, d_misc, sizeof(float) * (size_t)n * misc_outs, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(own, d_own, sizeof(float) * (size_t)n * B2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // namespace sayuri
+
+extern "C" int sayuri_hip_test_se_unit(int device, int use_fp16, int n, const int* board_sizes, int max_board, int channels, int se_size,
+                                       int act, const float* x, const float* res, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, float* y, float* gate) {
+    if (!board_sizes || !x || !w1 || !b1 || !w2 || !b2 || !y || n <= 0) return fail("test_se_unit: bad argument");
+    if (use_fp16) return test_se_unit_impl<f16>(device, n, board_sizes, max_board, channels, se_size, act, x, res, w1, b1, w2, b2, y, gate);
+    return test_se_unit_impl<float>(device, n, board_sizes, max_board, channels, se_size, act, x, res, w1, b1, w2, b2, y, gate);
+}
+
+extern "C" int sayuri_hip_test_head_tail(int device, int use_fp16, int n, const int* board_sizes, int max_board, int policy_channels,
+                                         int value_channels, int prob_channels, int pass_outs, int misc_outs, int act, const float* pconv,
+                                         const float* vconv, const float* const* weights12, float* prob, float* pass, float* misc,
+                                         float* own) {
+    if (!board_sizes || !pconv || !vconv || !weights12 || !prob || !pass || !misc || !own || n <= 0) return fail("test_head_tail: bad argument");
+    if (use_fp16)
+        return test_head_tail_impl<f16>(device, n, board_sizes, max_board, policy_channels, value_channels, prob_channels, pass_outs,
+                                        misc_outs, act, pconv, vconv, weights12, prob, pass, misc, own);
+    return test_head_tail_impl<float>(device, n, board_sizes, max_board, policy_channels, value_channels, prob_channels, pass_outs,
+                                      misc_outs, act, pconv, vconv, weights12, prob, pass, misc, own);
+}
+
 extern "C" int sayuri_hip_test_last_conv_kind(void) { return sayuri::g_test_conv_kind; }
 
 extern "C" int sayuri_hip_test_conv(int device, int use_fp16, int n, const int* board_sizes, int max_board, int cin,

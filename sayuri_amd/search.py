@@ -175,12 +175,13 @@ def selfplay(pipe=None, options: dict | None = None, seconds: float = 0.0, move_
     if pipe is not None:
         raw = h.sayuri_pipe_raw(pipe._h)
         version = h.sayuri_pipe_weights_version(pipe._h)
-    stats, el = np.zeros(10, np.uint64), ctypes.c_double(0)
+    stats, el = np.zeros(12, np.uint64), ctypes.c_double(0)
     failure = []
 
     def hook(st, elapsed, local_halt, _user):
         try:
             snap = {k: int(st[i]) for i, k in enumerate(STAT_NAMES)}
+            snap["finished_moves"], snap["prerolled_moves"] = int(st[10]), int(st[11])
             snap["elapsed"] = float(elapsed)
             return 1 if on_stats(snap, bool(local_halt)) else 0
         except BaseException as e:  # an exception must not unwind through the C frames
@@ -197,5 +198,6 @@ def selfplay(pipe=None, options: dict | None = None, seconds: float = 0.0, move_
         raise failure[0]
     out = {k: int(stats[i]) for i, k in enumerate(STAT_NAMES)}
     out["max_games"] = int(stats[9])
+    out["finished_moves"], out["prerolled_moves"] = int(stats[10]), int(stats[11])
     out["elapsed"] = el.value
     return out

@@ -3,7 +3,7 @@
 
 Run in the dev container only (needs /root/reference and `make -C oracle ref`):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [fixture names ...]
 
 For each fixture it writes a synthetic network file with sayuri_amd.weights (seeded
 numpy), loads it with the reference's own DNNLoader and evaluates seeded planes with
@@ -45,8 +45,11 @@ def sha256(path):
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: fixture names to (re)generate; default = all
     for fx in FIXTURES:
         name = fx["name"]
+        if only and name not in only:
+            continue
         spec = fx["spec"]()
         keep = fx.get("commit_weights", False)
         wpath = os.path.join(HERE, f"{name}.bin") if keep else f"/tmp/golden_{name}.bin"

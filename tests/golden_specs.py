@@ -54,4 +54,11 @@ FIXTURES = [
     # BASELINE.json configs[1..3] network: 19x19, 20-block x 256-filter
     dict(name="net_20b256", spec=W.spec_20b256, seed=22, commit_weights=False, winograd=(1,),
          cases=((19, 0, 501), (19, 0, 502), (13, 1, 503))),
+    # the same network on 64 more 19x19 positions: the sample the fp16 engine's error is measured on (planes are
+    # regenerated from their seeds, only the reference's outputs are stored)
+    dict(name="net_20b256_x64", spec=W.spec_20b256, seed=22, commit_weights=False, winograd=(1,), store_planes=False,
+         cases=tuple((19, i % 5, 700 + i) for i in range(64))),
+    # BASELINE.json configs[4] network: 40-block x 384-filter, boards 19 / 13 / 9
+    dict(name="net_40b384", spec=W.spec_40b384, seed=23, commit_weights=False, winograd=(1,), store_planes=False,
+         cases=((19, 0, 601), (13, 1, 602), (9, 2, 603), (19, 3, 604))),
 ]

@@ -143,3 +143,60 @@ def test_selfplay_through_the_collector_without_a_gpu(fake_lib, tmp_weights_dir,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "selfplay ok" in r.stdout
+
+
+TWO_PUMP_DRIVER = textwrap.dedent(r"""
+    import ctypes, sys, threading
+    import numpy as np
+    ctypes.CDLL(sys.argv[1], mode=ctypes.RTLD_GLOBAL)
+    from sayuri_amd.pipe import HipForwardPipe
+    B, C = 19, 43
+    def expected(planes, bs, off):
+        grid = np.zeros((C, B, B), np.float32)
+        grid[:, :bs, :bs] = planes.reshape(C, bs, bs)
+        x = grid.reshape(C, B * B).astype(np.float64)
+        prob = (x[off] + 0.5 * x[5] + off).reshape(B, B)[:bs, :bs].ravel()
+        return prob
+    pipe = HipForwardPipe(sys.argv[2], board_size=19, batch_size=8, fp16=True, device=-1)   # -1: every visible GPU
+    assert pipe.GetNumWorkers() == 2, pipe.GetNumWorkers()
+    rng = np.random.default_rng(11)
+    errs = []
+    def worker(seed):
+        try:
+            r = np.random.default_rng(seed)
+            for _ in range(8):
+                n = int(r.choice([1, 7, 8, 9, 30]))
+                cs = [(r.integers(0, 4, size=(C, bs * bs)).astype(np.float32), bs, int(r.integers(0, 5))) for bs in r.choice([19, 13, 9], size=n)]
+                outs = pipe.Forward([c[0] for c in cs], [int(c[1]) for c in cs], offsets=[c[2] for c in cs])
+                for (p, bs, off), got in zip(cs, outs):
+                    exp = expected(p, int(bs), off)
+                    assert np.abs(got[:bs * bs] - exp).max() <= 1e-3 * max(1.0, np.abs(exp).max())
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errs, errs
+    pt = pipe.pump_times()
+    assert pt["batches"] > 0
+    # BatchForward addresses one GPU's graph directly (reference BatchForward(gpu, inputs))
+    cs = [(rng.integers(0, 4, size=(C, 361)).astype(np.float32), 19, 0) for _ in range(5)]
+    for gpu in (0, 1):
+        outs = pipe.BatchForward([c[0] for c in cs], [19] * 5, offsets=[0] * 5, gpu=gpu)
+        for (p, bs, off), got in zip(cs, outs):
+            assert np.abs(got[:361] - expected(p, 19, 0)).max() <= 1e-3 * 10
+    pipe.Destroy()
+    print("two pumps ok", pt["batches"], pt["evals"])
+""")
+
+
+def test_in_process_two_gpu_pumps(fake_lib, tmp_weights_dir):
+    """The drop-in's in-process multi-GPU form (reference: one NNGraph per --gpu inside one process, GetNumWorkers() =
+    number of GPUs): with FAKE_HIP_DEVICES=2 the pipe builds two graphs, each with its own pump thread and staging ring;
+    blocking callers are spread over both and every reply still belongs to its request."""
+    weights = Golden("tiny_res", tmp_weights_dir).weights_path
+    env = dict(os.environ, FAKE_HIP_DELAY_US="300", FAKE_HIP_DEVICES="2",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", TWO_PUMP_DRIVER, fake_lib, weights], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "two pumps ok" in r.stdout

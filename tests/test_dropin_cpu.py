@@ -77,3 +77,41 @@ def test_selfplay_sharded_by_rank_gloo_world2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_newer_weights_on_one_rank_halt_every_rank_gloo_world2(tmp_path):
+    """The periodic exchange (sayuri_amd.shard.PeriodicGather, every 0.25 s here): each rank contributes its counters and
+    its own halt wish; rank 1 alone sees a newer network appear, both ranks wind down (reference ShouldHalt semantics,
+    src/selfplay/engine.cc:88-90, made collective because the games are sharded over processes)."""
+    script = tmp_path / "halt.py"
+    script.write_text(
+        "import os, sys, threading, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from sayuri_amd import search as S\n"
+        "from sayuri_amd.shard import PeriodicGather\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        f"wdir = os.path.join({str(tmp_path)!r}, f'weights{{r}}')\n"
+        "os.makedirs(wdir)\n"
+        "cur = os.path.join(wdir, 'net-0001.bin'); open(cur, 'w').write('old')\n"
+        "if r == 1:\n"
+        "    threading.Thread(target=lambda: (time.sleep(1.0), open(os.path.join(wdir, 'net-0002.bin'), 'w').write('new'))).start()\n"
+        "pg = PeriodicGather()\n"
+        "opts = dict(playouts=30, parallel_games=4, num_games=100000, seed=20 + r, selfplay_query=['bkp:7:7:1'], weights_dir=wdir, weights_file=cur)\n"
+        "def hook(st, halt):\n"
+        "    return pg.tick(dict(games_done=st['games_done'], nn_queries=st['nn_queries'], moves=st['moves'], playouts=st['playouts'], elapsed=st['elapsed']), halt=halt)\n"
+        "st = S.selfplay(None, opts, on_stats=hook, stats_interval=0.25)\n"
+        "tot = pg.drain(dict(games_done=st['games_done'], moves=st['moves'], playouts=st['playouts'], elapsed=st['elapsed']))\n"
+        "assert st['games_done'] == st['max_games'] < 100000, st\n"
+        "assert pg.any_halt and pg.rounds >= 3\n"
+        "if r == 0:\n"
+        "    assert tot['games_done'] >= 2 * 25 and len(tot['per_rank']) == 2, tot\n"
+        "    print('OK', pg.rounds, tot['games_done'])\n"
+        "dist.barrier()\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29535", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

@@ -37,7 +37,7 @@ def test_reference_tree_with_hip_pipe_matches_reference_cpu_pipe(tmp_weights_dir
         pc = np.ascontiguousarray(p, np.float32)
         assert lib.ref_forward(bs, ctypes.c_float(7.5), 0, off, pc.ctypes.data_as(fp), out.ctypes.data_as(fp)) == 0
         exp.append(out)
-    for fp16, tol in ((0, 1e-4), (1, 3e-2)):
+    for fp16, tol in ((0, 1e-4), (1, 1e-2)):
         assert lib.ref_hip_init(19, 8, fp16, 0) == 0, lib.ref_last_error()
         buf = np.zeros((len(bsz), 43 * 361), np.float32)
         for i, p in enumerate(planes):

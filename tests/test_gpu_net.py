@@ -2,9 +2,10 @@
 
 Tolerances (raw, pre-softmax outputs; magnitudes are O(1)):
   fp32 engine : abs <= 1e-4   (SURVEY.md 8c gate; north_star "within fp32 tolerance")
-  fp16 engine : abs <= 3e-2 on 6..20-block nets, and the reference's own GPU-vs-CPU SelfCheck
-                criterion L2(softmax policy ++ pass ++ wdl_winrate) <= 0.2 (network.cc:333-359)
-                as the hard floor.
+  fp16 engine : abs <= 1e-2 on 6..40-block nets -- about 4x the maximum measured on 64 positions of the 20b256
+                network against the reference (2.3e-3 on outputs of scale 4, profiles/r02_fp16_error_20b256.json,
+                test_fp16_error_is_measured_on_64_positions) -- and the reference's own GPU-vs-CPU SelfCheck
+                criterion L2(softmax policy ++ pass ++ wdl_winrate) <= 0.2 (network.cc:333-359) as the hard floor.
 """
 import numpy as np
 import pytest
@@ -18,7 +19,7 @@ from sayuri_amd.pipe import HipForwardPipe
 pytestmark = pytest.mark.gpu
 
 FP32_ATOL = 1e-4
-FP16_ATOL = 3e-2
+FP16_ATOL = 1e-2
 
 
 def self_check_l2(got, exp, bs):
@@ -192,3 +193,76 @@ def test_se_unit_fused_into_the_convolution_matches_the_separate_kernels(tmp_wei
         assert np.abs(outs["0"][i] - exp).max() <= FP16_ATOL, (i, bs)
         assert np.abs(outs["1"][i] - outs["0"][i]).max() <= FP16_ATOL
         assert np.abs(outs["1"][i] - outs["0"][i]).max() > 0, "the switch did not change the path"
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
+def test_40b384_golden_parity(fp16, tmp_weights_dir):
+    """BASELINE.json configs[4] network (40 blocks x 384 filters) on 19 / 13 / 9 boards against the reference's own
+    BlasForwardPipe outputs (tests/golden/net_40b384.npz, generated by tests/golden/make_golden.py)."""
+    g = Golden("net_40b384", tmp_weights_dir)
+    cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=fp16)
+    try:
+        check(pipe, cases, FP16_ATOL if fp16 else FP32_ATOL, "40b384")
+    finally:
+        pipe.Destroy()
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
+def test_config5_full_mixed_batch_40b384(fp16, tmp_weights_dir):
+    """configs[4] at its real size on one GPU: a full batch of 256 samples of mixed 9 / 13 / 19 boards through the
+    40-block x 384-filter network (reference mechanism: batch_forward_pipe.cc:15-33,48-68 re-pad + cuda_forward_pipe.cc:636-682
+    masks; here the compact per-sample layout).  The golden positions sit inside the batch and must come out as the
+    reference computed them; other slots are spot-checked against the oracle."""
+    g = Golden("net_40b384", tmp_weights_dir)
+    oracle = PortNet(g.weights_path)
+    rng = np.random.default_rng(55)
+    bsz = [int(b) for b in rng.choice([9, 13, 19], size=256)]
+    planes = W.synthetic_planes(len(bsz), bsz, seed=5500)
+    gold = {}
+    for k, c in enumerate(g.cases):  # plant the golden positions at scattered slots
+        slot = 17 + 60 * k
+        bsz[slot] = c["board_size"]
+        planes[slot] = g.planes(c)
+        gold[slot] = (c["offset"], g.expected(c))
+    tol = FP16_ATOL if fp16 else FP32_ATOL
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=256, fp16=fp16)
+    try:
+        offs = [gold[i][0] if i in gold else 0 for i in range(256)]
+        outs = pipe.BatchForward(planes, bsz, offsets=offs)
+        for slot, (off, exp) in gold.items():
+            assert np.abs(outs[slot] - exp).max() <= tol, ("golden", slot, bsz[slot])
+        for i in (0, 255):
+            exp = oracle.forward(planes[i], bsz[i])
+            assert np.abs(outs[i] - exp).max() <= tol, ("oracle", i, bsz[i])
+        assert all(np.isfinite(o).all() for o in outs)
+    finally:
+        pipe.Destroy()
+
+
+def test_fp16_error_is_measured_on_64_positions(tmp_weights_dir):
+    """The fp16 gate is a measurement, not a guess: 64 positions of the 20b256 network against the reference's outputs
+    (tests/golden/net_20b256_x64.npz).  Records max-abs error on the raw outputs and the reference's own SelfCheck L2
+    (network.cc:333-359) to gpurun_out/fp16_error_20b256.json; the gate FP16_ATOL must stay >= 2x the measured maximum and
+    the measured maximum must stay below it."""
+    import json
+    import os
+    g = Golden("net_20b256_x64", tmp_weights_dir)
+    cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
+    assert len(cases) == 64
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=64, fp16=True)
+    try:
+        outs = pipe.BatchForward([c[0] for c in cases], [c[1] for c in cases], offsets=[c[2] for c in cases])
+    finally:
+        pipe.Destroy()
+    errs = [float(np.abs(o - c[3]).max()) for o, c in zip(outs, cases)]
+    l2 = [self_check_l2(o, c[3], c[1]) for o, c in zip(outs, cases)]
+    rec = {"positions": 64, "net": "20b256 seed 22", "max_abs": max(errs), "mean_abs_of_max": float(np.mean(errs)),
+           "selfcheck_l2_max": max(l2), "selfcheck_l2_mean": float(np.mean(l2)), "gate": FP16_ATOL,
+           "output_scale": float(max(np.abs(c[3]).max() for c in cases))}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "fp16_error_20b256.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    assert max(errs) <= FP16_ATOL and max(l2) <= 0.2
+    assert FP16_ATOL >= 2 * max(errs) * 0.999, rec

@@ -190,3 +190,32 @@ def test_live_facade_against_reference(tmp_weights_dir):
             got = mnet.output(b, ensemble, symm, temp)
             assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (board, ensemble, symm, temp, np.abs(got - want).max())
     api.lib.ref_net_free(rnet)
+
+
+def test_selfplay_winds_down_when_newer_weights_appear(tmp_path):
+    """Reference Engine::ShouldHalt (src/selfplay/engine.cc:63-90) + the wind-down of SelfPlayPipe (pipe.cc:246-258):
+    once the newest file of weights_dir is no longer the file the engine runs on, the main worker caps the number of
+    games at (games started + 25) rounded up to 25 -- selfplay-worker.sh then restarts on the new network."""
+    import threading
+    import time
+    wdir = tmp_path / "weights"
+    wdir.mkdir()
+    cur = wdir / "net-0001.bin"
+    cur.write_text("old")
+    opts = dict(playouts=30, parallel_games=4, num_games=100000, seed=9, selfplay_query=["bkp:7:7:1"],
+                weights_dir=str(wdir), weights_file=str(cur))
+
+    def newer():
+        time.sleep(1.0)
+        (wdir / "net-0002.bin").write_text("new")
+
+    t = threading.Thread(target=newer)
+    t.start()
+    seen = []
+    st = S.selfplay(None, opts, on_stats=lambda s, halt: seen.append(halt) or halt, stats_interval=0.25)
+    t.join()
+    assert st["games_done"] == st["max_games"] < 100000 and st["max_games"] % 25 == 0, st
+    assert seen and seen[0] is False and seen[-1] is True   # the hook saw the wish appear
+    # without a weights_dir the loop never asks
+    quiet = S.selfplay(None, dict(opts, weights_dir="", num_games=8))
+    assert quiet["games_done"] == 8 and quiet["max_games"] == 8
