@@ -101,6 +101,14 @@ int sayuri_selfplay_run_ex(void* raw_pipe, int weights_version, const char* opti
                            int move_cap, sayuri_selfplay_stats_fn on_stats, void* user, double interval_seconds,
                            uint64_t* stats, double* elapsed);
 
+/* ---- search benchmark (reference --mode benchmark, src/benchmark/benchmark.cc:78-161) -------------------------------
+ * `positions` policy-sampled openings, each searched once (options: playouts, default_boardsize, ...) with a fresh tree
+ * and the evaluation cache off, `concurrent` searches at a time (this engine batches across searches, not inside a tree).
+ * out8: playouts per move, playouts/s per search (the reference's figure), playouts/s of all searches together,
+ * NN evals/s, wall seconds, KataGo's Elo estimate (benchmark.cc:14-28), NN queries, positions. */
+int sayuri_engine_benchmark(void* raw_pipe, int weights_version, const char* options, int positions, int concurrent,
+                            double* out8);
+
 #ifdef __cplusplus
 }
 #endif

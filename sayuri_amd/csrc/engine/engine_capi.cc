@@ -220,6 +220,23 @@ int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options
     return rc;
 }
 
+int sayuri_engine_benchmark(void* raw_pipe, int weights_version, const char* options, int positions, int concurrent, double* out8) {
+    try {
+        EngineOptions opt;
+        opt.Parse(options ? options : "");
+        std::shared_ptr<NetworkForwardPipe> pipe;
+        if (raw_pipe) pipe = std::shared_ptr<NetworkForwardPipe>(static_cast<NetworkForwardPipe*>(raw_pipe), [](NetworkForwardPipe*) {});
+        const SearchBenchmarkResult r = RunSearchBenchmark(pipe, weights_version, opt, positions, concurrent);
+        const double v[8] = {r.playouts_per_move, r.playouts_per_second_per_search, r.playouts_per_second_total, r.nn_evals_per_second,
+                             r.wall_seconds, r.elo, static_cast<double>(r.nn_queries), static_cast<double>(r.positions)};
+        std::memcpy(out8, v, sizeof(v));
+        return 0;
+    } catch (const std::exception& e) {
+        g_engine_err = e.what();
+        return -1;
+    }
+}
+
 // The network evaluation facade on a forward pipe (for GPU parity tests of search moves).
 void* sayuri_engine_net_new_pipe(void* raw_pipe, int weights_version, const char* options) {
     EngineOptions opt;

@@ -121,4 +121,18 @@ private:
 
 float AdjustKomiToHalf(float komi); // utils/komi.cc AdjustKomi<float>
 
+// benchmark.cc -- the reference's --mode benchmark (src/benchmark/benchmark.cc:78-161)
+struct SearchBenchmarkResult {
+    int positions{0}, concurrent{0};
+    double playouts_per_move{0};               // average playouts of a timed search
+    double playouts_per_second_per_search{0};  // average playouts / average elapsed: the reference's "p/s" figure
+    double playouts_per_second_total{0};       // all playouts / wall clock (what `concurrent` searches deliver together)
+    double nn_evals_per_second{0};
+    double wall_seconds{0}, elo{0};
+    std::uint64_t nn_queries{0};
+};
+SearchBenchmarkResult RunSearchBenchmark(std::shared_ptr<NetworkForwardPipe> pipe, int weights_version, const EngineOptions& opt,
+                                         int positions, int concurrent);
+double ComputeEloEffect(double playouts_per_move, double playouts_per_second, int threads);
+
 } // namespace sayuri_engine

@@ -201,3 +201,20 @@ def selfplay(pipe=None, options: dict | None = None, seconds: float = 0.0, move_
     out["finished_moves"], out["prerolled_moves"] = int(stats[10]), int(stats[11])
     out["elapsed"] = el.value
     return out
+
+
+def benchmark(pipe=None, options: dict | None = None, positions: int = 10, concurrent: int = 1, weights_version: int = 4) -> dict:
+    """The reference's `--mode benchmark` (src/benchmark/benchmark.cc:110-161): policy-sampled openings, one timed
+    Search::Computation each, playouts per second (csrc/engine/benchmark.cc)."""
+    h = lib()
+    raw, version = None, weights_version
+    if pipe is not None:
+        raw = h.sayuri_pipe_raw(pipe._h)
+        version = h.sayuri_pipe_weights_version(pipe._h)
+    out = np.zeros(8, np.float64)
+    h.sayuri_engine_benchmark.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    if h.sayuri_engine_benchmark(raw, version, options_text(options or {}), positions, concurrent, out.ctypes.data):
+        raise RuntimeError(h.sayuri_engine_last_error().decode())
+    keys = ("playouts_per_move", "playouts_per_second_per_search", "playouts_per_second_total", "nn_evals_per_second",
+            "wall_seconds", "elo", "nn_queries", "positions")
+    return dict(zip(keys, (float(x) for x in out)))

@@ -37,7 +37,7 @@ def test_reference_tree_with_hip_pipe_matches_reference_cpu_pipe(tmp_weights_dir
         pc = np.ascontiguousarray(p, np.float32)
         assert lib.ref_forward(bs, ctypes.c_float(7.5), 0, off, pc.ctypes.data_as(fp), out.ctypes.data_as(fp)) == 0
         exp.append(out)
-    for fp16, tol in ((0, 1e-4), (1, 1e-2)):
+    for fp16, tol in ((0, 1e-4), (1, 4e-3)):
         assert lib.ref_hip_init(19, 8, fp16, 0) == 0, lib.ref_last_error()
         buf = np.zeros((len(bsz), 43 * 361), np.float32)
         for i, p in enumerate(planes):
@@ -51,5 +51,6 @@ def test_reference_tree_with_hip_pipe_matches_reference_cpu_pipe(tmp_weights_dir
         for i, bs in enumerate(bsz):
             s = bs * bs
             got = np.concatenate([out[i, :s], out[i, 361:361 + s], out[i, 722:]])
-            assert np.abs(got - exp[i]).max() <= tol, (fp16, bs, float(np.abs(got - exp[i]).max()))
+            gate = tol * (max(1.0, float(np.abs(exp[i]).max())) if fp16 else 1.0)  # fp16: relative to the output scale (test_gpu_net.py)
+            assert np.abs(got - exp[i]).max() <= gate, (fp16, bs, float(np.abs(got - exp[i]).max()))
         lib.ref_hip_destroy()

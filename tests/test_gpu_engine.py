@@ -100,3 +100,57 @@ def test_selfplay_on_the_gpu_queue(w6b96, tmp_path):
     assert (len(lines) - 1) % 53 == 0
     assert open(glob.glob(str(tmp_path / "sgf" / "*.sgf"))[0]).read().count("(;GM[1]") == 64
     pipe.Destroy()
+
+
+def test_netbench_agrees_with_the_pump_counters(w6b96):
+    """The reference's `netbench` (src/game/gtp.cc:1468-1568: threads hammering Forward with the cache off, evals = pipe
+    calls / wall): every evaluation it counts went through the pump, and the rate it reports is the counted total over the
+    window."""
+    pipe = HipForwardPipe(w6b96, board_size=19, batch_size=64, fp16=True, waittime_ms=2)
+    before = pipe.pump_times()
+    eps, total = pipe.netbench(threads=128, seconds=1.5)
+    after = pipe.pump_times()
+    pumped = after["evals"] - before["evals"]
+    assert total > 1000 and eps > 0
+    # threads still inside Forward() when the window closes finish their evaluation after the count was taken
+    assert total <= pumped <= total + 128, (total, pumped)
+    assert abs(eps - total / 1.5) <= 0.1 * eps
+    batches = after["batches"] - before["batches"]
+    assert pumped / batches > 32, "netbench callers are not being batched"
+    pipe.Destroy()
+
+
+def test_search_benchmark_mode_on_the_gpu(w6b96):
+    """Reference --mode benchmark (src/benchmark/benchmark.cc:110-161) on the HIP pipe: one search at a time gives the
+    latency figure, 64 concurrent searches the throughput figure; every playout beyond the root costs one evaluation
+    at most (cache off)."""
+    pipe = HipForwardPipe(w6b96, board_size=9, batch_size=32, fp16=True, waittime_ms=1)
+    one = S.benchmark(pipe, dict(playouts=100, default_boardsize=9, seed=3), positions=4, concurrent=1)
+    many = S.benchmark(pipe, dict(playouts=100, default_boardsize=9, seed=3), positions=64, concurrent=64)
+    assert one["playouts_per_move"] == 100 and many["playouts_per_move"] == 100
+    assert 0 < one["nn_queries"] <= 4 * 101 and 0 < many["nn_queries"] <= 64 * 101
+    assert many["playouts_per_second_total"] > 3 * one["playouts_per_second_total"], (one, many)
+    pipe.Destroy()
+
+
+def test_selfplay_configs2_workload_keeps_full_batches(tmp_weights_dir, tmp_path):
+    """BASELINE.json configs[2] at its real size for half a minute: 20b256, 19x19, 512 concurrent games, 400 visits, batch
+    256.  The queue must run full (mean batch > 200), records must be well formed, nothing may fail."""
+    path = os.path.join(tmp_weights_dir, "engine_20b256.bin")
+    if not os.path.exists(path):
+        W.write_weights(path, W.spec_20b256(), seed=22)
+    pipe = HipForwardPipe(path, board_size=19, batch_size=256, fp16=True, waittime_ms=2)
+    opts = dict(playouts=400, parallel_games=512, num_games=1000000, seed=77, dirichlet_noise=1, dirichlet_epsilon=0.25, dirichlet_init=0.03,
+                dirichlet_factor=361, first_pass_bonus=1, random_moves_factor=0.1, komi_stddev=2.5, resign_playouts=80, resign_threshold=0.05,
+                early_symm_cache=1, cache_memory_mib=400, selfplay_query=["bkp:19:7:1"], stagger_moves=360, target_directory=str(tmp_path))
+    st = S.selfplay(pipe, opts, seconds=30.0, name_suffix="-r0")
+    pt = pipe.pump_times()
+    assert st["nn_queries"] > 30 * 20000, st          # > 20 k evals/s through encoder + queue + PCIe
+    assert pt["evals"] / pt["batches"] > 200, (pt["evals"], pt["batches"])
+    assert st["moves"] > 1000 and st["playouts"] > 100000
+    assert st["games_done"] > 0 and st["chunks_saved"] == st["games_done"], st   # staggered starts: games do finish in the window
+    chunks = glob.glob(str(tmp_path / "tdata" / "*-r0" / "*.gz"))
+    assert len(chunks) == st["games_done"]
+    lines = gzip.open(chunks[0]).read().decode().split("\n")
+    assert (len(lines) - 1) % 53 == 0 and lines[1] == "0"   # version line, then the mode line of a 19x19 record
+    pipe.Destroy()

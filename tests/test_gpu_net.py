@@ -2,8 +2,9 @@
 
 Tolerances (raw, pre-softmax outputs; magnitudes are O(1)):
   fp32 engine : abs <= 1e-4   (SURVEY.md 8c gate; north_star "within fp32 tolerance")
-  fp16 engine : abs <= 1e-2 on 6..40-block nets -- about 4x the maximum measured on 64 positions of the 20b256
-                network against the reference (2.3e-3 on outputs of scale 4, profiles/r02_fp16_error_20b256.json,
+  fp16 engine : abs <= 4e-3 * max(1, max|expected|) -- twice the largest error measured over every golden fixture
+                against the reference (1.9e-3 of the output scale on tiny_all, 5.9e-4 = 2.3e-3 abs on 64 positions of
+                the 20b256 network; profiles/r02_fp16_error_fixtures.txt, profiles/r02_fp16_error_20b256.json,
                 test_fp16_error_is_measured_on_64_positions) -- and the reference's own GPU-vs-CPU SelfCheck
                 criterion L2(softmax policy ++ pass ++ wdl_winrate) <= 0.2 (network.cc:333-359) as the hard floor.
 """
@@ -19,7 +20,11 @@ from sayuri_amd.pipe import HipForwardPipe
 pytestmark = pytest.mark.gpu
 
 FP32_ATOL = 1e-4
-FP16_ATOL = 1e-2
+FP16_ATOL = 4e-3  # times max(1, output scale): fp16_tol()
+
+
+def fp16_tol(exp):
+    return FP16_ATOL * max(1.0, float(np.abs(exp).max()))
 
 
 def self_check_l2(got, exp, bs):
@@ -41,7 +46,7 @@ def check(pipe, cases, atol, label):
             assert got.shape == exp.shape
             assert np.isfinite(got).all(), (label, mode)
             err = float(np.abs(got - exp).max())
-            assert err <= atol, (label, mode, bs, off, err)
+            assert err <= (atol(exp) if callable(atol) else atol), (label, mode, bs, off, err)
             assert self_check_l2(got, exp, bs) <= 0.2
 
 
@@ -53,7 +58,7 @@ def test_golden_parity(name, fp16, tmp_weights_dir):
     cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases if c["winograd"] == 1]
     pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=16, fp16=fp16)
     try:
-        check(pipe, cases, FP16_ATOL if fp16 else FP32_ATOL, name)
+        check(pipe, cases, fp16_tol if fp16 else FP32_ATOL, name)
     finally:
         pipe.Destroy()
 
@@ -67,7 +72,7 @@ def test_20b256_fallback_conv_paths(variant, tmp_weights_dir, monkeypatch):
     cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
     pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=True)
     try:
-        check(pipe, cases, FP16_ATOL, "20b256-" + variant)
+        check(pipe, cases, fp16_tol, "20b256-" + variant)
     finally:
         pipe.Destroy()
 
@@ -83,7 +88,7 @@ def test_20b256_golden_and_oracle(fp16, tmp_weights_dir):
         cases.append((p, bs, i, oracle.forward(p, bs, offset=i)))
     pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=fp16)
     try:
-        check(pipe, cases, FP16_ATOL if fp16 else FP32_ATOL, "20b256")
+        check(pipe, cases, fp16_tol if fp16 else FP32_ATOL, "20b256")
     finally:
         pipe.Destroy()
 
@@ -123,7 +128,7 @@ def test_full_mixed_batches_fit_a_tile_configuration(seed, fp16, tmp_weights_dir
         outs = pipe.BatchForward(planes, bsz)
         for i in (0, 17, 101, 255):
             exp = oracle.forward(planes[i], bsz[i])
-            assert np.abs(outs[i] - exp).max() <= (FP16_ATOL if fp16 else FP32_ATOL), (i, bsz[i])
+            assert np.abs(outs[i] - exp).max() <= (fp16_tol(exp) if fp16 else FP32_ATOL), (i, bsz[i])
     finally:
         pipe.Destroy()
 
@@ -148,7 +153,7 @@ def test_batch256_properties_20b256(tmp_weights_dir):
         oracle = PortNet(g.weights_path)
         for i in (0, 5):
             exp = oracle.forward(base[i], 19)
-            assert np.abs(outs[i] - exp).max() <= FP16_ATOL
+            assert np.abs(outs[i] - exp).max() <= fp16_tol(exp)
         one = pipe.BatchForward([base[3]], [19])[0]
         assert np.abs(one - outs[3]).max() <= 1e-6  # batch of 1 vs inside a batch of 256
     finally:
@@ -189,9 +194,9 @@ def test_se_unit_fused_into_the_convolution_matches_the_separate_kernels(tmp_wei
             pipe.Destroy()
     for i, (p, bs) in enumerate(zip(planes, bsz)):
         exp = oracle.forward(p, bs)
-        assert np.abs(outs["1"][i] - exp).max() <= FP16_ATOL, (i, bs)
-        assert np.abs(outs["0"][i] - exp).max() <= FP16_ATOL, (i, bs)
-        assert np.abs(outs["1"][i] - outs["0"][i]).max() <= FP16_ATOL
+        assert np.abs(outs["1"][i] - exp).max() <= fp16_tol(exp), (i, bs)
+        assert np.abs(outs["0"][i] - exp).max() <= fp16_tol(exp), (i, bs)
+        assert np.abs(outs["1"][i] - outs["0"][i]).max() <= fp16_tol(exp)
         assert np.abs(outs["1"][i] - outs["0"][i]).max() > 0, "the switch did not change the path"
 
 
@@ -203,7 +208,7 @@ def test_40b384_golden_parity(fp16, tmp_weights_dir):
     cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
     pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=fp16)
     try:
-        check(pipe, cases, FP16_ATOL if fp16 else FP32_ATOL, "40b384")
+        check(pipe, cases, fp16_tol if fp16 else FP32_ATOL, "40b384")
     finally:
         pipe.Destroy()
 
@@ -225,16 +230,16 @@ def test_config5_full_mixed_batch_40b384(fp16, tmp_weights_dir):
         bsz[slot] = c["board_size"]
         planes[slot] = g.planes(c)
         gold[slot] = (c["offset"], g.expected(c))
-    tol = FP16_ATOL if fp16 else FP32_ATOL
+    tol = (lambda e: fp16_tol(e)) if fp16 else (lambda e: FP32_ATOL)
     pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=256, fp16=fp16)
     try:
         offs = [gold[i][0] if i in gold else 0 for i in range(256)]
         outs = pipe.BatchForward(planes, bsz, offsets=offs)
         for slot, (off, exp) in gold.items():
-            assert np.abs(outs[slot] - exp).max() <= tol, ("golden", slot, bsz[slot])
+            assert np.abs(outs[slot] - exp).max() <= tol(exp), ("golden", slot, bsz[slot])
         for i in (0, 255):
             exp = oracle.forward(planes[i], bsz[i])
-            assert np.abs(outs[i] - exp).max() <= tol, ("oracle", i, bsz[i])
+            assert np.abs(outs[i] - exp).max() <= tol(exp), ("oracle", i, bsz[i])
         assert all(np.isfinite(o).all() for o in outs)
     finally:
         pipe.Destroy()
@@ -257,12 +262,13 @@ def test_fp16_error_is_measured_on_64_positions(tmp_weights_dir):
         pipe.Destroy()
     errs = [float(np.abs(o - c[3]).max()) for o, c in zip(outs, cases)]
     l2 = [self_check_l2(o, c[3], c[1]) for o, c in zip(outs, cases)]
+    scale = float(max(np.abs(c[3]).max() for c in cases))
+    gate = FP16_ATOL * max(1.0, scale)
     rec = {"positions": 64, "net": "20b256 seed 22", "max_abs": max(errs), "mean_abs_of_max": float(np.mean(errs)),
-           "selfcheck_l2_max": max(l2), "selfcheck_l2_mean": float(np.mean(l2)), "gate": FP16_ATOL,
-           "output_scale": float(max(np.abs(c[3]).max() for c in cases))}
+           "selfcheck_l2_max": max(l2), "selfcheck_l2_mean": float(np.mean(l2)), "gate": gate, "output_scale": scale}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     with open(os.path.join(root, "gpurun_out", "fp16_error_20b256.json"), "w") as f:
         json.dump(rec, f, indent=1)
-    assert max(errs) <= FP16_ATOL and max(l2) <= 0.2
-    assert FP16_ATOL >= 2 * max(errs) * 0.999, rec
+    assert max(errs) <= gate and max(l2) <= 0.2
+    assert gate >= 2 * max(errs), rec

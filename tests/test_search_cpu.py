@@ -219,3 +219,14 @@ def test_selfplay_winds_down_when_newer_weights_appear(tmp_path):
     # without a weights_dir the loop never asks
     quiet = S.selfplay(None, dict(opts, weights_dir="", num_games=8))
     assert quiet["games_done"] == 8 and quiet["max_games"] == 8
+
+
+def test_search_benchmark_mode_on_the_dummy_backend():
+    """Reference --mode benchmark (src/benchmark/benchmark.cc:110-161): policy-sampled openings, one timed search each."""
+    r = S.benchmark(None, dict(playouts=120, default_boardsize=9, seed=5), positions=6, concurrent=3)
+    assert r["positions"] == 6 and r["playouts_per_move"] == 120
+    assert r["playouts_per_second_per_search"] > 0 and r["playouts_per_second_total"] > 0 and r["wall_seconds"] > 0
+    # KataGo's estimate as the reference evaluates it (benchmark.cc:14-28), one thread per tree
+    import math
+    exp = 250.0 * math.log(r["playouts_per_second_per_search"]) / math.log(2.0) - 7.0 * (1600.0 / (800.0 + 120)) ** 0.85
+    assert abs(r["elo"] - exp) < 1e-6 * abs(exp)
