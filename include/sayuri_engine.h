@@ -109,6 +109,10 @@ int sayuri_selfplay_run_ex(void* raw_pipe, int weights_version, const char* opti
 int sayuri_engine_benchmark(void* raw_pipe, int weights_version, const char* options, int positions, int concurrent,
                             double* out8);
 
+/* ---- M:N game scheduling self-test (csrc/host/fiber.h): `fibers` coroutines on `threads` OS threads, each waits
+ * `rounds` times for its own word to change; returns fibers * rounds, or -1. */
+long sayuri_fiber_selftest(int fibers, int threads, int rounds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,9 @@ struct SelfplayOptions {
     // extension (measurement only): the first game of worker g starts after g * stagger_moves / parallel_games
     // policy-sampled moves, so that a short window sees games in every phase, as a long-running self-play does
     int stagger_moves{0};
+    // extension: how the concurrent games are scheduled (selfplay.cc): 0 = fibers on a few threads per usable core from 256
+    // games on, one OS thread per game below; N > 0 = fibers on N threads; -1 = always one thread per game
+    int game_threads{0};
 };
 
 struct EngineOptions {

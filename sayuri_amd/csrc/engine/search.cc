@@ -52,6 +52,7 @@ Search::Search(GameState& state, Network& network, const SearchParams& params)
     active_ = &params_[0];
     passive_ = &params_[1];
     shared_.t_quantiles = &t_quantiles_;
+    shared_.arena = &arena_;
 }
 
 void Search::Seed(std::uint64_t caller_seed, std::uint64_t playout_seed) {
@@ -176,7 +177,7 @@ bool Search::AdvanceToNewRootState(int tag) {
 
 void Search::PrepareRootNode(ComputationResult& result, int tag) {
     const bool reused = AdvanceToNewRootState(tag);
-    if (!reused) root_ = std::make_unique<Node>(active_, &shared_, kPassMove, 1.0f);
+    if (!reused) root_.reset(new (&shared_) Node(active_, &shared_, kPassMove, 1.0f));
     playouts_ = 0;
     root_evals_ = NodeEvals{};
     const bool fresh = root_->PrepareRootNode(network_, root_state_, root_evals_, caller_rng_);

@@ -112,6 +112,7 @@ private:
     GameState& root_state_;
     GameState last_state_;
     Network& network_;
+    TreeArena arena_;             // before root_: the tree is destroyed first, its blocks go back into a living arena
     std::unique_ptr<Node> root_;
     NodeEvals root_evals_;
     SearchParams params_[2]; // [0] normal, [1] exploration disabled

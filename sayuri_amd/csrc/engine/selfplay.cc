@@ -1,5 +1,7 @@
 #include "selfplay.h"
 
+#include "fiber.h"
+
 #include <dirent.h>
 #include <sys/stat.h>
 
@@ -432,6 +434,34 @@ void SelfplayPipe::WindDown() {
     }
 }
 
+namespace {
+// CPUs worth of time this process can get: the affinity mask, limited by a cgroup v2 / v1 CPU quota if there is one
+int UsableCores(int affinity_cpus) {
+    int cores = std::max(1, affinity_cpus);
+    auto apply = [&cores](double quota, double period) {
+        if (quota > 0 && period > 0) cores = std::max(1, std::min(cores, static_cast<int>(quota / period + 0.5)));
+    };
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        double period = 0;
+        if (std::fscanf(f, "%63s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0) apply(std::atof(q), period);
+        std::fclose(f);
+    } else {
+        double quota = -1, period = 0;
+        if (FILE* a = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (std::fscanf(a, "%lf", &quota) != 1) quota = -1;
+            std::fclose(a);
+        }
+        if (FILE* b = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(b, "%lf", &period) != 1) period = 0;
+            std::fclose(b);
+        }
+        apply(quota, period);
+    }
+    return cores;
+}
+} // namespace
+
 SelfplayStats SelfplayPipe::Run(double seconds) {
     // Hundreds of game threads build and drop a search tree per move.  Keep freed heap inside the process instead of
     // trimming / unmapping it: every munmap or brk shrink takes the address-space lock exclusively and stalls the page
@@ -456,27 +486,47 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                 if (CPU_ISSET(c, &set)) cpus.push_back(c);
     }
     for (int g = 0; g < games; ++g) engine_.search(g).SetAbortFlag(&stop_);
-    for (int g = 0; g < games; ++g) {
-        workers.emplace_back([this, g, games, &started, &cpus]() {
-            if (cpus.size() > 1) {
-                cpu_set_t one;
-                CPU_ZERO(&one);
-                CPU_SET(cpus[static_cast<size_t>(g) % cpus.size()], &one);
-                pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
-            }
-            {
-                // Grow this thread's malloc arena once to about the size of a move's search tree (a node plus its edge
-                // list is ~7 KB, one per playout) and pre-fault it.  Otherwise the arena grows in page-sized mprotect
-                // steps while the first trees are built -- thousands of address-space write locks per thread, all of
-                // them contending with every other game thread's page faults.
-                const size_t bytes = static_cast<size_t>(std::max(opt_.search.playouts, 64)) * 8192 + (1u << 20);
-                void* warm = std::malloc(bytes);
-                if (warm) {
-                    std::memset(warm, 0, bytes);
-                    std::free(warm);
-                }
-            }
-            try {
+    // How the games are run: from 256 concurrent games on as fibers on a few threads per usable core (csrc/host/fiber.h):
+    // a game blocks in exactly one place, the forward pipe, and that call yields to the thread's next game when it comes
+    // from a fiber.  Fewer games: one OS thread per game (the reference's scheme, pipe.cc:235-296).  Measured on one
+    // MI355X host (16 cores of CPU quota), 20b x 256, 400 visits: fibers 66.1 / 67.2 / 63.4 / 64.7 / 63.7 k evals/s at
+    // 512 / 1024 / 2048 / 4096 / 8192 games, threads 57.7 / 59.5 / 18.5 / 7.4 k at 512 / 1024 / 2048 / 4096
+    // (profiles/r02_selfplay_{fibers,threads}_g*.json).  `game_threads`: 0 = choose, N = N worker threads with the games
+    // as fibers on them, -1 = always one thread per game.
+    // Worker threads of the fiber mode: a few per core this process may actually use -- the CPUs of its affinity mask, cut
+    // down to its cgroup CPU quota (the MI355X boxes of this pool show 256 CPUs and grant 16 cores of time: 256 polling
+    // scheduler threads eat that quota in futex calls, 64 leave it to the games).
+    const int cores = UsableCores(static_cast<int>(cpus.size()));
+    int fiber_threads = 0;
+    if (opt_.selfplay.game_threads > 0) fiber_threads = std::min(opt_.selfplay.game_threads, games);
+    else if (opt_.selfplay.game_threads == 0 && games >= 256) fiber_threads = std::min(games, std::max(8, 4 * cores));
+    const int games_per_thread = fiber_threads > 0 ? (games + fiber_threads - 1) / fiber_threads : 1;
+    auto thread_start = [this, &cpus, games_per_thread](int idx) {
+        if (cpus.size() > 1) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[static_cast<size_t>(idx) % cpus.size()], &one);
+            pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+        }
+        // Grow this thread's malloc arena once to about the size of the search trees it will hold (a node plus its edge
+        // list is ~7 KB, one per playout; one tree per game of this thread) and pre-fault it.  Otherwise the arena grows in
+        // page-sized mprotect steps while the first trees are built -- thousands of address-space write locks per thread,
+        // all of them contending with every other game thread's page faults (measured: 12 cores of system time and a
+        // tenth of the throughput while 2048 games build their first trees).  In chunks below the mmap threshold so that
+        // the memory stays in the arena when it is freed.
+        const size_t per_game = static_cast<size_t>(std::max(opt_.search.playouts, 64)) * 8192 + (1u << 20);
+        const size_t chunk = size_t(8) << 20;
+        std::vector<void*> warm;
+        for (size_t done = 0; done < per_game * static_cast<size_t>(games_per_thread); done += chunk) {
+            void* p = std::malloc(std::min(chunk, per_game * static_cast<size_t>(games_per_thread) - done));
+            if (!p) break;
+            std::memset(p, 0, std::min(chunk, per_game * static_cast<size_t>(games_per_thread) - done));
+            warm.push_back(p);
+        }
+        for (void* p : warm) std::free(p);
+    };
+    auto game_loop = [this, games, &started](int g) {
+        try {
             bool first_game = true, halting = false;
             while (!stop_.load(std::memory_order_relaxed) && accumulation_games_.fetch_add(1) < max_games_.load(std::memory_order_relaxed)) {
                 if (g == 0 && !halting) {  // pipe.cc:246-258: only the main worker looks, once per game
@@ -517,13 +567,23 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                 data_queue_.push_back(item);
                 queries_queue_.emplace_back(played, std::string("hip ") + std::to_string(engine_.network().GetNumQueries()));
             }
-            } catch (const std::exception& e) {
-                // a failing backend ends the run: remember the first message, stop the other workers
-                std::lock_guard<std::mutex> lock(data_mu_);
-                if (error_.empty()) error_ = e.what();
-                stop_.store(true);
-            }
-        });
+        } catch (const std::exception& e) {
+            // a failing backend ends the run: remember the first message, stop the other workers
+            std::lock_guard<std::mutex> lock(data_mu_);
+            if (error_.empty()) error_ = e.what();
+            stop_.store(true);
+        }
+    };
+    sayuri_fiber::FiberPool pool;
+    if (fiber_threads > 0) {
+        for (int g = 0; g < games; ++g) pool.Add([&game_loop, g] { game_loop(g); });
+        workers.emplace_back([&pool, fiber_threads, &thread_start] { pool.Run(fiber_threads, thread_start); });
+    } else {
+        for (int g = 0; g < games; ++g)
+            workers.emplace_back([g, &thread_start, &game_loop] {
+                thread_start(g);
+                game_loop(g);
+            });
     }
     auto snapshot = [&](SelfplayStats& st) {
         st.games_started = started.load();

@@ -220,7 +220,7 @@ void Node::ComputeScoreBonus(GameState& state, NodeEvals& parent) {
 // ---------------------------------------------------------------------------------------------
 // Selection.
 Node* Node::Inflate(Edge& e) {
-    if (!e.node) e.node = std::make_unique<Node>(param_, shared_, e.vertex, e.policy);
+    if (!e.node) e.node.reset(new (shared_) Node(param_, shared_, e.vertex, e.policy));
     return e.node.get();
 }
 

@@ -19,6 +19,7 @@
 #include "game_state.h"
 #include "network.h"
 #include "search_params.h"
+#include "tree_arena.h"
 
 namespace sayuri_engine {
 
@@ -31,6 +32,7 @@ struct NodeEvals { // node.h:16-21
 
 struct SearchShared { // what every node of one search can reach
     const TQuantiles* t_quantiles{nullptr};
+    TreeArena* arena{nullptr}; // the game's own tree memory (tree_arena.h); null = malloc
 };
 
 class Node {
@@ -46,8 +48,17 @@ public:
         int GetVisits() const { return node ? node->GetVisits() : 0; }
     };
 
+    using EdgeList = std::vector<Edge, TreeArenaAllocator<Edge>>;
+
     Node(SearchParams* param, const SearchShared* shared, int vertex, float policy)
-        : param_(param), shared_(shared), policy_(policy), vertex_(static_cast<std::int16_t>(vertex)) {}
+        : param_(param), shared_(shared), children_(TreeArenaAllocator<Edge>(shared ? shared->arena : nullptr)), policy_(policy),
+          vertex_(static_cast<std::int16_t>(vertex)) {}
+    // nodes come out of the game's tree arena: `new (shared) Node(...)`; a plain `new Node` uses malloc behind the same
+    // header, so `delete` (the unique_ptrs of the edges) is one function for both
+    static void* operator new(std::size_t n, const SearchShared* shared) { return TreeArena::Alloc(shared ? shared->arena : nullptr, n); }
+    static void* operator new(std::size_t n) { return TreeArena::Alloc(nullptr, n); }
+    static void operator delete(void* p) noexcept { TreeArena::Release(p); }
+    static void operator delete(void* p, const SearchShared*) noexcept { TreeArena::Release(p); }
 
     // node.cc:127-357
     bool ExpandChildren(Network& network, GameState& state, NodeEvals& evals, bool is_root, Rng& rng);
@@ -69,8 +80,8 @@ public:
     std::vector<float> GetProbLogitsCompletedQ(GameState& state); // node.cc:1487-1505
     bool ShouldApplyGumbel() const;
 
-    std::vector<Edge>& GetChildren() { return children_; }
-    const std::vector<Edge>& GetChildren() const { return children_; }
+    EdgeList& GetChildren() { return children_; }
+    const EdgeList& GetChildren() const { return children_; }
     bool HasChildren() const { return expanded_ && color_ != sayuri_go::kWall; }
     Node* GetChild(int vertex);
     std::unique_ptr<Node> PopChild(int vertex);
@@ -122,7 +133,7 @@ private:
 
     SearchParams* param_;
     const SearchShared* shared_;
-    std::vector<Edge> children_;
+    EdgeList children_;
     std::array<float, sayuri_go::kMaxPoints> avg_black_ownership_;
     double sq_eval_diff_{static_cast<double>(1e-4f)};
     double sq_score_diff_{static_cast<double>(1e-4f)};

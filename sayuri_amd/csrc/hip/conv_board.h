@@ -40,6 +40,7 @@ struct BoardParams {
     const int2* tab_pix;   // [tile][384]    x = lpos | lstr << 16, y = output activation row (-1 = none)
     const int* tab_cols;   // [tile]         column tiles in use (1..24) | board size << 8
     int npos;              // halo positions per tile of this launch (multiple of 64, <= 512)
+    int uniform_info;      // >= 0: every tile's tab_cols entry has this value (a uniform batch: one table read less)
     unsigned long long* dbg;  // DBG kernels only: s_memtime timeline [workgroup < 4][wave][8]
 };
 
@@ -220,7 +221,7 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint3
 // The main loop: returns with the accumulators (bias included) of this wave's (WMT x 12) output tiles.
 // `full` = the wave's 12th column tile is in use (else its MFMAs are skipped; other unused tiles are computed on
 // whatever the padded pixel slots point at and never stored).
-template <int WMT, bool DBG = false, int PRIO = 0>
+template <int WMT, bool DBG = false>
 __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
                                                int kt, int wave, int lane, int col0, bool full, int bs,
                                                unsigned long long* dbg = nullptr) {
@@ -262,14 +263,25 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
 #pragma unroll
         for (int i = 0; i < AI; ++i) issue_a(0, dx, i);
 
-    uint32_t boff[4];
+    // every table read goes out before the halo DMA (whose "memory" clobber keeps them above it): the halo sources are
+    // waited for first, the pixel positions and the bias arrive while the DMA is being issued
+    int src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int q = wave + 8 * i, kgq = q & 3, blk = q >> 2;
-        int src = -1;
-        if (q < nbinstr) src = bp.tab_src[(size_t)tile * npos + blk * 64 + lane];
-        boff[i] = (src >= 0 ? (uint32_t)kZeroPrefix + (uint32_t)src * (uint32_t)(p.cin_s * 2) : 0u) + kgq * 16;
+        const int q = wave + 8 * i;
+        src[i] = q < nbinstr ? bp.tab_src[(size_t)tile * npos + (q >> 2) * 64 + lane] : -1;
     }
+    int lp[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) lp[j] = bp.tab_pix[(size_t)tile * kBoardPT + (col0 + j) * 16 + (lane & 15)].x;
+    f32x4 b4[WMT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) b4[i] = *(const f32x4*)(p.bias + kt * KO_T + (wave_m * WMT + i) * 16 + 4 * kg);
+
+    uint32_t boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        boff[i] = (src[i] >= 0 ? (uint32_t)kZeroPrefix + (uint32_t)src[i] * (uint32_t)(p.cin_s * 2) : 0u) + ((wave + 8 * i) & 3) * 16;
     auto issue_b = [&](int chunk, int i) {
         const int q = wave + 8 * i;
         if (q >= nbinstr) return;
@@ -281,23 +293,15 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
     // per-lane B fragment addresses of the current (halo slot, kernel row); moved by scalars from group to group
     uint32_t bb[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int2 e = bp.tab_pix[(size_t)tile * kBoardPT + (col0 + j) * 16 + (lane & 15)];
-        const uint32_t lp = e.x & 0xffff;
-        bb[j] = b_ring + (lp - 1) * 16 + (uint32_t)kg * npos * 16 - ls16;  // kernel row 0 (dy = -1) in slot 0
-    }
+    for (int j = 0; j < NJ; ++j)
+        bb[j] = b_ring + (((uint32_t)lp[j] & 0xffffu) - 1) * 16 + (uint32_t)kg * npos * 16 - ls16;  // kernel row 0 (dy = -1) in slot 0
     // accumulators start at the bias: D rows 4*(lane>>4)+r of row tile i are 4 consecutive output channels
 #pragma unroll
-    for (int i = 0; i < WMT; ++i) {
-        const f32x4 b4 = *(const f32x4*)(p.bias + kt * KO_T + (wave_m * WMT + i) * 16 + 4 * kg);
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = b4;
-    }
+        for (int j = 0; j < NJ; ++j) acc[i][j] = b4[i];
 
     const uint32_t arow_off = (uint32_t)((kg * KO_T + wave_m * WMT * 16 + (lane & 15)) * 16);
-    if constexpr (PRIO == 1) {  // experiment: the younger SIMD partner always wins the arbitration
-        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    }
     unsigned long long t_sync = 0;  // DBG: cycles spent in vmcnt(0) + s_barrier at the group boundaries
     if constexpr (DBG) { if (dbg) dbg[1] = __builtin_amdgcn_s_memtime(); }
 
@@ -328,16 +332,6 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
             static_for<kNB>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
                 constexpr int dx = b / NJ, j = b % NJ;
-                if constexpr (PRIO == 2) {  // experiment: the SIMD partners take turns block by block
-                    if (((b & 1) != 0) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
-                }
-                if constexpr (PRIO == 3) {  // experiment: turns of four blocks
-                    if constexpr (b % 4 == 0) {
-                        if ((((b >> 2) & 1) != 0) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
-                        else __builtin_amdgcn_s_setprio(0);
-                    }
-                }
                 // DMA of the next group / chunk, front-loaded: weights at blocks 0, 3, 6, ..., halo pieces at blocks 1
                 // and 4 of rows 0 and 1 (the next chunk's slot is free from the start of this chunk)
                 if constexpr (b % 3 == 0 && b / 3 < 3 * AI) {
@@ -373,7 +367,6 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
     }
     // the last MFMAs retire before the epilogue reads the accumulators (hipcc pads nothing after an asm statement)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
     if constexpr (DBG) { if (dbg) { dbg[3] = __builtin_amdgcn_s_memtime(); dbg[5] = t_sync; } }
 }
 
@@ -680,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void conv_board_se_kernel(const BoardSePara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;  // one output-channel tile: KO_T covers the layer
-    const int info = __builtin_amdgcn_readfirstlane(bp.tab_cols[tile]);
+    const int info = bp.uniform_info >= 0 ? bp.uniform_info : __builtin_amdgcn_readfirstlane(bp.tab_cols[tile]);
     const int ncols = info & 0xff, bs = info >> 8;
     const int nj0 = (ncols + 1) >> 1;
     const int wave_n = wave >> 2;
@@ -705,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void conv_board_se_kernel(const BoardSePara
     }
 }
 
-template <int WMT, bool DBG = false, int PRIO = 0>
+template <int WMT, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void conv_board_kernel(const BoardParams bp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* dbg = nullptr;
@@ -722,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void conv_board_kernel(const BoardParams bp
     const int kt = blockIdx.x / p.num_pix_tiles;
     // column tiles: wave column 0 (waves 0-3) takes the first ceil(n/2), wave column 1 (waves 4-7, the SIMD partners
     // of 0-3) the rest
-    const int info = __builtin_amdgcn_readfirstlane(bp.tab_cols[tile]);
+    const int info = bp.uniform_info >= 0 ? bp.uniform_info : __builtin_amdgcn_readfirstlane(bp.tab_cols[tile]);
     const int ncols = info & 0xff, bs = info >> 8;
     const int nj0 = (ncols + 1) >> 1;
     const int wave_n = wave >> 2;
@@ -730,7 +723,7 @@ __global__ __launch_bounds__(512, 2) void conv_board_kernel(const BoardParams bp
     const int nj = wave_n ? ncols - nj0 : nj0;
 
     f32x4 acc[WMT][kBoardNJ];
-    board_mainloop<WMT, DBG, PRIO>(bp, smem, acc, tile, kt, wave, lane, col0, nj == kBoardNJ, bs, dbg);
+    board_mainloop<WMT, DBG>(bp, smem, acc, tile, kt, wave, lane, col0, nj == kBoardNJ, bs, dbg);
 
     switch (p.act) {
     case kMish: board_epilogue<WMT, kMish>(bp, smem, acc, tile, kt, wave, lane, col0, nj); break;

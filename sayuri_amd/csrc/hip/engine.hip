@@ -213,25 +213,35 @@ static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_
 }
 
 // The one-workgroup-per-board plan of a batch geometry (conv_board.h): consecutive samples packed greedily.
-struct BoardPlan { int ntiles = 0, npos = 0; bool ok = false, single = false; double fill = 0; };  // single: one sample per tile
+struct BoardPlan {
+    int ntiles = 0, npos = 0;
+    bool ok = false, single = false;  // single: one sample per tile
+    int uniform_info = -1;            // every tile has this (column tiles | board size << 8), or -1
+    double fill = 0;
+};
 static BoardPlan board_plan(const HostGeom& geom) {
     BoardPlan bp;
     const ConvOverride ov = conv_override();
     if (ov.no_board || geom.n <= 0) return bp;
     BoardPack pk;
-    int max_pos = 0;
+    int max_pos = 0, info0 = -2;
+    auto close_tile = [&] {
+        max_pos = std::max(max_pos, pk.pos);
+        const int info = ((pk.px + 15) / 16) | (pk.bs0 << 8);
+        info0 = info0 == -2 ? info : (info0 == info ? info0 : -1);
+        ++bp.ntiles;
+    };
     for (int s = 0; s < geom.n; ++s) {
         const int bs = geom.bsz[s];
         if (!BoardPack{}.fits(bs)) return bp;  // a board that does not fit a tile on its own
         if (pk.cnt > 0 && !pk.fits(bs)) {
-            max_pos = std::max(max_pos, pk.pos);
-            ++bp.ntiles;
+            close_tile();
             pk = BoardPack{};
         }
         pk.add(bs);
     }
-    max_pos = std::max(max_pos, pk.pos);
-    ++bp.ntiles;
+    close_tile();
+    bp.uniform_info = info0;
     bp.npos = round_up(max_pos, 64);
     bp.fill = (double)geom.total / ((double)bp.ntiles * kBoardPT);
     bp.single = bp.ntiles == geom.n;
@@ -888,6 +898,7 @@ private:
         BoardSeParams sp;
         BoardParams& bp = sp.b;
         bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos; bp.dbg = nullptr;
+        bp.uniform_info = board_plan_.uniform_info;
         ConvParams& p = bp.c;
         p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
         p.g = dgeom();
@@ -911,6 +922,7 @@ private:
             BoardParams bp;
             bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos;
             bp.dbg = nullptr;
+            bp.uniform_info = board_plan_.uniform_info;
             auto fn = be->fn;
             if (be->kot == 256 && getenv("SAYURI_BOARD_DBG") && !strcmp(name, "conv3x3_tower")) {
                 // in-kernel timeline of the SAYURI_BOARD_DBG-th tower convolution of the forward (1 = first)
@@ -919,14 +931,6 @@ private:
                     bp.dbg = d_dbg_;
                     fn = &conv_board_kernel<4, true>;
                 }
-            }
-            if (be->kot == 256) {
-                static const int prio = getenv("SAYURI_BOARD_PRIO") ? atoi(getenv("SAYURI_BOARD_PRIO")) : 0;  // experiment
-                const bool d = bp.dbg != nullptr;
-                if (prio == 1) fn = d ? &conv_board_kernel<4, true, 1> : &conv_board_kernel<4, false, 1>;
-                if (prio == 2) fn = d ? &conv_board_kernel<4, true, 2> : &conv_board_kernel<4, false, 2>;
-                if (prio == 3) fn = d ? &conv_board_kernel<4, true, 3> : &conv_board_kernel<4, false, 3>;
-                (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
             }
             ConvParams& p = bp.c;
             p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
@@ -1434,6 +1438,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
                 hipLaunchKernelGGL(board_setup_kernel, dim3(plan.ntiles), dim3(256), 0, 0, g, plan.npos, tsrc, tpix, tcols);
                 BoardParams bp;
                 bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos; bp.dbg = nullptr;
+                bp.uniform_info = plan.uniform_info;
                 ConvParams& p = bp.c;
                 p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
                 p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;

@@ -309,3 +309,47 @@ extern "C" int sayuri_pipe_netbench(void* hp, int threads, double seconds, int b
         return -1;
     }
 }
+
+// Self-test of the fiber runtime (fiber.h), for tests/test_host_cpu.py: `fibers` coroutines on `threads` OS threads, each
+// waits `rounds` times for its own word to change; a driver thread changes the words in a scrambled order and calls
+// NotifyAll.  Returns the number of completed waits (fibers * rounds), or -1.
+#include "fiber.h"
+extern "C" long sayuri_fiber_selftest(int fibers, int threads, int rounds) {
+    if (fibers <= 0 || threads <= 0 || rounds <= 0) return -1;
+    std::vector<std::atomic<int>> words(static_cast<size_t>(fibers));
+    for (auto& w : words) w.store(0);
+    std::atomic<long> waits{0};
+    std::atomic<int> finished{0};
+    sayuri_fiber::FiberPool pool(64 << 10);
+    for (int f = 0; f < fibers; ++f)
+        pool.Add([&, f] {
+            // some stack use and a value carried across every switch
+            volatile char pad[2048];
+            pad[0] = static_cast<char>(f);
+            long mine = 0;
+            for (int r = 0; r < rounds; ++r) {
+                sayuri_fiber::WaitWhileEqual(&words[static_cast<size_t>(f)], r);
+                ++mine;
+            }
+            if (pad[0] == static_cast<char>(f)) waits.fetch_add(mine);
+            finished.fetch_add(1);
+        });
+    std::thread driver([&] {
+        std::mt19937 rng(7);
+        for (int r = 0; r < rounds; ++r) {
+            std::vector<int> order(static_cast<size_t>(fibers));
+            for (int i = 0; i < fibers; ++i) order[static_cast<size_t>(i)] = i;
+            std::shuffle(order.begin(), order.end(), rng);
+            for (int i : order) {
+                // a fiber may not have reached round r yet: words only ever go up by one when it has
+                while (words[static_cast<size_t>(i)].load() != r) std::this_thread::yield();
+                words[static_cast<size_t>(i)].store(r + 1, std::memory_order_release);
+                if ((i & 7) == 0) sayuri_fiber::NotifyAll();
+            }
+            sayuri_fiber::NotifyAll();
+        }
+    });
+    pool.Run(threads);
+    driver.join();
+    return finished.load() == fibers ? waits.load() : -1;
+}

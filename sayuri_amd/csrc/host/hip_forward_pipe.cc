@@ -1,5 +1,6 @@
 // hip_forward_pipe.cc -- see hip_forward_pipe.h.
 #include "hip_forward_pipe.h"
+#include "fiber.h"
 
 #include <algorithm>
 #include <chrono>
@@ -322,11 +323,13 @@ void HipForwardPipe::FinishBatch(Graph* g, Staging* s, int n) {
     const auto t1 = std::chrono::steady_clock::now();
     // the previous batch of this set was handed out at least one batch time ago
     while (s->wakes_done.load(std::memory_order_acquire) < s->fin_count) std::this_thread::yield();
-    int count = 0;
+    int count = 0, fibers = 0;
     for (int i = 0; i < n; ++i) {
         const Request& r = s->reqs[i];
         s->fin_reqs[i] = r;
-        if (r.self_serve) {
+        if (r.fiber) {
+            ++fibers;  // flagged below, once fin_status is in place
+        } else if (r.self_serve) {
             s->fin_pos[i] = count;
             s->fin_list[count++] = i;
         } else {  // asynchronous Submit(): filled and signalled here
@@ -339,9 +342,15 @@ void HipForwardPipe::FinishBatch(Graph* g, Staging* s, int n) {
     evals_.fetch_add(static_cast<size_t>(n), std::memory_order_relaxed);
     s->n_inflight = 0;
     s->fin_count = count;
+    s->fin_fibers = fibers;
     s->wakes_done.store(0, std::memory_order_relaxed);
     s->consumed.store(0, std::memory_order_relaxed);
     s->fin_status.store(rc == 0 ? 1 : -1, std::memory_order_relaxed);
+    if (fibers > 0) {  // games scheduled as fibers: one flag store each, one wake word for their scheduler threads
+        for (int i = 0; i < n; ++i)
+            if (s->fin_reqs[i].fiber) s->fin_reqs[i].done->store(rc == 0 ? 1 : -1, std::memory_order_release);
+        sayuri_fiber::NotifyAll();
+    }
     if (count > 0) {  // root of the wake tree
         std::atomic<int>* root = s->fin_reqs[s->fin_list[0]].done;
         root->store(1, std::memory_order_release);
@@ -361,6 +370,7 @@ void HipForwardPipe::Reopen(Graph* g, Staging* s) {
     s->reserved.store(0, std::memory_order_release);  // re-open for callers
     g->epoch.fetch_add(1, std::memory_order_release);
     FutexWakeAll(&g->epoch);
+    if (fibers_seen_.load(std::memory_order_relaxed)) sayuri_fiber::NotifyAll();  // fibers parked for a free staging set
 }
 
 // One persistent pump per GPU over a ring of staging sets.  Callers fill the set `fill` points at; when it holds
@@ -443,7 +453,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
         const auto tc0 = clock::now();
         while (s.ready.load(std::memory_order_acquire) < static_cast<unsigned>(n)) std::this_thread::yield();
         // every blocking caller of this set's previous batch has copied its result out of the pinned outputs
-        while (s.consumed.load(std::memory_order_acquire) < s.fin_count) std::this_thread::yield();
+        while (s.consumed.load(std::memory_order_acquire) < s.fin_count + s.fin_fibers) std::this_thread::yield();
         pump_ns_[7] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - tc0).count();
         try {
             SubmitBatch(g, &s, n);
@@ -459,6 +469,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
                 s.reqs[k].done->store(-1, std::memory_order_release);
                 FutexWakeAll(s.reqs[k].done);
             }
+            sayuri_fiber::NotifyAll();
             Reopen(g, &s);
         }
     };
@@ -539,7 +550,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
     }
 }
 
-HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputResult* out, std::atomic<int>* done, bool self_serve) {
+HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputResult* out, std::atomic<int>* done, bool self_serve, bool fiber) {
     if (graphs_.empty()) throw std::runtime_error("HipForwardPipe is not constructed");
     if (input.board_size < 2 || input.board_size > board_size_)
         throw std::runtime_error("InputData board size does not fit the NN board");
@@ -556,7 +567,7 @@ HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputRes
             if (!(r & Staging::kClosed) && r < cap) {
                 const int slot = static_cast<int>(r);
                 StageInput(&s, slot, input, false);  // the one copy of the planes, by the calling thread
-                s.reqs[slot] = Request{&input, out, done, self_serve};
+                s.reqs[slot] = Request{&input, out, done, self_serve, fiber};
                 s.ready.fetch_add(1, std::memory_order_release);
                 if (r == 0 || r + 1 >= want) g->cv.notify_one();
                 return Ticket{g, &s, slot};
@@ -564,7 +575,8 @@ HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputRes
         }
         // both sets are taken (one on the GPU, one full or being rotated): sleep until the pump re-opens one
         if (!running_.load()) throw std::runtime_error("HipForwardPipe is shutting down");
-        FutexWait(&g->epoch, epoch);
+        if (fiber) sayuri_fiber::WaitWhileEqual(&g->epoch, epoch);  // let the thread's other games run meanwhile
+        else FutexWait(&g->epoch, epoch);
     }
 }
 
@@ -575,6 +587,18 @@ void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atom
 OutputResult HipForwardPipe::Forward(const InputData& input) {
     OutputResult out;
     std::atomic<int> done{0};
+    if (sayuri_fiber::InFiber()) {
+        fibers_seen_.store(true, std::memory_order_relaxed);
+        // M:N game scheduling (fiber.h): hand the request over and run this thread's other games until the batch is back
+        const Ticket t = Reserve(input, nullptr, &done, false, true);
+        sayuri_fiber::WaitWhileEqual(&done, 0);
+        Staging& s = *t.s;
+        const int status = done.load(std::memory_order_acquire);
+        if (status > 0) FillOutput(&s, t.slot, input, true, &out);
+        s.consumed.fetch_add(1, std::memory_order_release);
+        if (status < 0) throw std::runtime_error("HIP forward pipe failed while evaluating a batch");
+        return out;
+    }
     const Ticket t = Reserve(input, nullptr, &done, true);
     int st;
     while ((st = done.load(std::memory_order_acquire)) == 0) FutexWait(&done, 0);

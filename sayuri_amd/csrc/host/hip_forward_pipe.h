@@ -92,6 +92,8 @@ private:
         OutputResult* output;
         std::atomic<int>* done;
         bool self_serve;  // a blocking Forward() caller: woken through the tree, takes its result itself
+        bool fiber;       // a Forward() caller that is a fiber (fiber.h): takes its result itself, no futex: the pump only
+                          // flips `done`, the fiber's scheduler thread sees it
     };
     // One batch being assembled or evaluated.  Callers reserve a slot with one atomic add and copy
     // their planes straight into the pinned buffer the GPU will read (one copy per evaluation,
@@ -116,6 +118,7 @@ private:
         std::vector<int> fin_list;          // slots of the blocking callers
         std::vector<int> fin_pos;           // slot -> position in fin_list
         int fin_count{0};
+        int fin_fibers{0};                  // fiber callers of the finished batch (they also count in `consumed`)
         std::atomic<int> fin_status{0};     // 1 ok, -1 failed
         std::atomic<int> wakes_done{0};     // callers that have woken their children
         std::atomic<int> consumed{0};       // callers that have taken their result
@@ -137,7 +140,7 @@ private:
     };
 
     struct Ticket { Graph* g; Staging* s; int slot; };
-    Ticket Reserve(const InputData& input, OutputResult* out, std::atomic<int>* done, bool self_serve);
+    Ticket Reserve(const InputData& input, OutputResult* out, std::atomic<int>* done, bool self_serve, bool fiber = false);
     void Reopen(Graph* g, Staging* s);
     void BuildGraphs();
     void DestroyGraphs();
@@ -153,6 +156,7 @@ private:
     std::atomic<int> forward_size_{0};  // batch size the collector forwards at (<= max_batch_); Construct() may lower it live
     std::vector<std::unique_ptr<Graph>> graphs_;
     std::atomic<bool> running_{false};
+    std::atomic<bool> fibers_seen_{false};  // some caller is a fiber: re-opened staging sets are announced to the fiber schedulers too
     std::atomic<unsigned> next_graph_{0};
     std::atomic<size_t> batches_{0}, evals_{0};
     mutable std::atomic<long long> pump_ns_[8] = {};

@@ -118,7 +118,7 @@ SELFPLAY_DRIVER = textwrap.dedent(r"""
     from sayuri_amd import search as S
     pipe = HipForwardPipe(sys.argv[2], board_size=9, batch_size=16, fp16=True, waittime_ms=2)
     opts = dict(playouts=24, parallel_games=40, num_games=40, seed=5, dirichlet_noise=1, random_moves_factor=0.1,
-                selfplay_query=["bkp:9:7:0.7", "bkp:7:9:0.3"], target_directory=sys.argv[3])
+                selfplay_query=["bkp:9:7:0.7", "bkp:7:9:0.3"], target_directory=sys.argv[3], game_threads=int(sys.argv[4]))
     st = S.selfplay(pipe, opts, move_cap=24, name_suffix="-cpu")
     pt = pipe.pump_times()
     assert st["games_done"] == 40 and st["chunks_saved"] == 40, st
@@ -133,13 +133,15 @@ SELFPLAY_DRIVER = textwrap.dedent(r"""
 """)
 
 
-def test_selfplay_through_the_collector_without_a_gpu(fake_lib, tmp_weights_dir, tmp_path):
+@pytest.mark.parametrize("game_threads", [-1, 3], ids=["thread-per-game", "fibers-on-3-threads"])
+def test_selfplay_through_the_collector_without_a_gpu(fake_lib, tmp_weights_dir, tmp_path, game_threads):
     """The whole host-side path of a self-play run -- game threads, search, encoder, NN cache, collector, training-data
     writer -- on the fake device: 40 games of 9x9 / 7x7 finish, every NN query went through the pump, the chunks have the
-    53-line record format."""
+    53-line record format.  Once with one OS thread per game (the reference's scheme), once with the 40 games as fibers
+    on 3 threads (csrc/host/fiber.h: a game yields inside Forward() instead of parking its thread)."""
     weights = Golden("tiny_res", tmp_weights_dir).weights_path
     env = dict(os.environ, FAKE_HIP_DELAY_US="300", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, "-c", SELFPLAY_DRIVER, fake_lib, weights, str(tmp_path)], env=env, cwd=ROOT,
+    r = subprocess.run([sys.executable, "-c", SELFPLAY_DRIVER, fake_lib, weights, str(tmp_path), str(game_threads)], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "selfplay ok" in r.stdout

@@ -128,7 +128,8 @@ def test_search_benchmark_mode_on_the_gpu(w6b96):
     one = S.benchmark(pipe, dict(playouts=100, default_boardsize=9, seed=3), positions=4, concurrent=1)
     many = S.benchmark(pipe, dict(playouts=100, default_boardsize=9, seed=3), positions=64, concurrent=64)
     assert one["playouts_per_move"] == 100 and many["playouts_per_move"] == 100
-    assert 0 < one["nn_queries"] <= 4 * 101 and 0 < many["nn_queries"] <= 64 * 101
+    # cache off: the root, one evaluation per playout, and the few extra root-level queries of a search (ownership)
+    assert 0 < one["nn_queries"] <= 4 * 104 and 0 < many["nn_queries"] <= 64 * 104
     assert many["playouts_per_second_total"] > 3 * one["playouts_per_second_total"], (one, many)
     pipe.Destroy()
 

@@ -103,3 +103,13 @@ def test_fails_loudly_without_gpu(tmp_weights_dir):
     g = Golden("tiny_res", tmp_weights_dir)
     with pytest.raises(RuntimeError, match="No executable GPU device"):
         HipForwardPipe(g.weights_path)
+
+
+@pytest.mark.parametrize("fibers,threads,rounds", [(1, 1, 5), (64, 3, 50), (1000, 8, 20), (4096, 4, 5)])
+def test_fiber_runtime_selftest(fibers, threads, rounds):
+    """csrc/host/fiber.h, the M:N scheduling of self-play games: every fiber is resumed exactly when its word changes,
+    keeps its stack across switches and finishes; thousands of fibers on a handful of OS threads."""
+    import ctypes
+    h = _lib.host()
+    h.sayuri_fiber_selftest.restype = ctypes.c_long
+    assert h.sayuri_fiber_selftest(fibers, threads, rounds) == fibers * rounds

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--out", default="")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--game-threads", type=int, default=0, help="0 = one OS thread per game up to 1024 games, fibers above; N = fibers on N threads; -1 = threads")
     ap.add_argument("--boards", default="", help="comma list of board sizes drawn uniformly per game (mixed-size batches), e.g. 9,13,19")
     args = ap.parse_args()
 
@@ -50,11 +51,14 @@ def main():
                 random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
                 resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
                 selfplay_query=([f"bkp:{b}:7:1" for b in args.boards.split(",")] if args.boards else [f"bkp:{args.board}:7:1"]),
-                target_directory=args.out)
+                target_directory=args.out, game_threads=args.game_threads)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.time()
-    st = S.selfplay(pipe, opts, seconds=args.seconds, move_cap=args.move_cap)
+    series = []
+    st = S.selfplay(pipe, opts, seconds=args.seconds, move_cap=args.move_cap,
+                    on_stats=lambda snap, halt: series.append((snap['elapsed'], snap['nn_queries'], snap['moves'], snap['playouts'])) and False,
+                    stats_interval=5.0)
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     pt = pipe.pump_times()
     el = st["elapsed"]
@@ -68,7 +72,12 @@ def main():
                host_cpu_cores_busy=round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / el, 1),
                host_sys_cores=round((ru1.ru_stime - ru0.ru_stime) / el, 1), host_cpus=os.cpu_count(),
                ctx_switches_per_sec=round(((ru1.ru_nvcsw - ru0.ru_nvcsw) + (ru1.ru_nivcsw - ru0.ru_nivcsw)) / el),
-               wall=round(time.time() - t0, 1))
+               max_rss_gb=round(ru1.ru_maxrss / 1048576, 2), wall=round(time.time() - t0, 1))
+    if len(series) >= 4:  # the rate once the start-up transient (first trees, first-touch page faults) is over
+        a, b = series[len(series) // 2], series[-1]
+        dt = max(b[0] - a[0], 1e-9)
+        out.update(second_half={"from_s": round(a[0], 1), "to_s": round(b[0], 1), "nn_evals_per_sec": round((b[1] - a[1]) / dt, 1),
+                                "moves_per_sec": round((b[2] - a[2]) / dt, 2), "playouts_per_sec": round((b[3] - a[3]) / dt, 1)})
     print(json.dumps(out))
     pipe.Destroy()
 
