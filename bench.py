@@ -73,6 +73,59 @@ def hbm_traffic(fp16: bool) -> dict:
             "algorithmic_bytes": algo, "traffic_over_algorithmic": round(tot / algo, 3), "traffic_source": t["source"]}
 
 
+def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
+    """BASELINE.json configs[4] on this GPU: 40-block x 384-filter net, fp16, a batch of 256 samples whose board size is
+    drawn uniformly from 9 / 13 / 19, planes resident in HBM.  Returns evals/s, the tower convolution's
+    launch time and the MFMA fraction on the batch's REAL pixels (a 9x9 sample costs 81/361 of a 19x19 one)."""
+    import ctypes
+    from sayuri_amd import _lib
+    from sayuri_amd import weights as W
+    from sayuri_amd.pipe import HipForwardPipe
+    spec = W.spec_40b384()
+    wdir = f"/tmp/sayuri_bench_weights_{os.getuid()}"
+    wpath = os.path.join(wdir + "_c5", "net_40b384_seed23.bin")
+    if local_rank == 0 and not os.path.exists(wpath):
+        os.makedirs(os.path.dirname(wpath), exist_ok=True)
+        W.write_weights(wpath + ".tmp", spec, seed=23)
+        os.replace(wpath + ".tmp", wpath)
+    while not os.path.exists(wpath):
+        time.sleep(0.2)
+    n = 256
+    rng = np.random.default_rng(5000 + rank)
+    bsz = rng.choice([9, 13, 19], size=n).astype(np.int32)  # arrival order; the engine groups the samples by size on the device
+    planes = W.synthetic_planes(n, [int(b) for b in bsz], seed=5100 + rank)
+    grid = np.zeros((n, 43, 19, 19), np.float32)
+    for i, (p, b) in enumerate(zip(planes, bsz)):
+        grid[i, :, :b, :b] = p.reshape(43, b, b)
+    grid = np.ascontiguousarray(grid.reshape(n, 43, 361))
+    pipe = HipForwardPipe(wpath, board_size=19, batch_size=n, fp16=True, device=local_rank)
+    ctx = pipe.ctx(0)
+    if lib.sayuri_hip_upload(ctx, n, grid.ctypes.data_as(_lib.c_float_p), bsz.ctypes.data_as(_lib.c_int_p)):
+        raise RuntimeError(lib.sayuri_hip_last_error().decode())
+    ms = ctypes.c_float(0)
+    lib.sayuri_hip_mark_kernel(ctx, b"")
+    lib.sayuri_hip_time_runs(ctx, warmup, ctypes.byref(ms))
+    lib.sayuri_hip_mark_kernel(ctx, b"conv3x3_tower")
+    lib.sayuri_hip_sync(ctx)
+    t0 = time.perf_counter()
+    if lib.sayuri_hip_time_runs(ctx, steps, ctypes.byref(ms)):
+        raise RuntimeError(lib.sayuri_hip_last_error().decode())
+    lib.sayuri_hip_sync(ctx)
+    el = time.perf_counter() - t0
+    stat = _lib.KernelStat()
+    lib.sayuri_hip_timed_stat(ctx, ctypes.byref(stat))
+    pipe.Destroy()
+    px = float((bsz.astype(np.int64) ** 2).sum())
+    flops_batch = sum(algorithmic_flops_per_eval(spec, int(b)) for b in bsz)
+    tower_tf = (stat.flops / stat.launches) / (stat.total_ms / stat.launches * 1e-3) / 1e12 if stat.launches else None
+    return {"workload": "configs[4]: 40-block x 384-filter net, fp16, batch 256 of mixed 9/13/19 boards (uniform draw, random order), "
+                        "planes resident in HBM", "evals_per_sec": round(n * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+            "real_pixel_fraction": round(px / (n * 361), 4), "gflop_per_batch": round(flops_batch / 1e9, 1),
+            "whole_net_tflops": round(flops_batch * steps / el / 1e12, 1), "whole_net_mfma_frac": round(flops_batch * steps / el / 1e12 / 2500.0, 4),
+            "tower_conv_avg_launch_us": round(stat.total_ms / max(stat.launches, 1) * 1e3, 2),
+            "tower_conv_tflops": round(tower_tf, 1) if tower_tf else None, "tower_conv_mfma_frac": round(tower_tf / 2500.0, 4) if tower_tf else None}
+
+
 def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
     """Time the CPU pipe on this box's host cores on a bounded sample of the same workload.
     Prefers the reference's own BlasForwardPipe (oracle/_ref, kind "reference"); falls back to
@@ -279,7 +332,8 @@ def main():
                        "whole_net_tflops": round(value * flops_eval / 1e12, 2),
                        "whole_net_mfma_frac": round(value * flops_eval / 1e12 / (peak * world), 4),
                        "device_ms_per_step": round(ms.value / args.steps, 4)},
-            "roofline": {"bound": "mfma", "kernel": "conv_board_kernel<4> (conv3x3_tower: 256->256 3x3, one workgroup per board)",
+            "roofline": {"bound": "mfma", "kernel": ("conv_board_kernel<4> (conv3x3_tower: 256->256 3x3, one workgroup per board)" if fp16 else
+                                                     "conv_mfma_kernel<float> (conv3x3_tower: 256->256 3x3, v_mfma_f32_16x16x4_f32)"),
                          "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4) if ach else None, **hbm_traffic(fp16),
                          "launches_timed": int(stat.launches),
@@ -291,6 +345,8 @@ def main():
             result["selfplay"] = selfplay
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wpath, planes, args.cpu_seconds)
+        if args.config5:
+            result["config5"] = config5_segment(lib, local_rank, rank, args.steps, args.warmup)
         if args.profile:
             rows = (_lib.KernelStat * 32)()
             k = lib.sayuri_hip_profile_run(ctx, rows, 32)

@@ -250,12 +250,16 @@ static BoardPlan board_plan(const HostGeom& geom) {
 }
 static const BoardEntry* pick_board(const BoardPlan& bp, int ko_pad, int* kot_tiles) {
     if (!bp.ok) return nullptr;
-    for (const auto& e : kBoardEntries)
-        if (ko_pad % e.kot == 0 && e.lds(bp.npos) <= kMaxLds) {
-            *kot_tiles = ko_pad / e.kot;
-            return &e;
-        }
-    return nullptr;
+    // the channel tile that needs the fewest rounds of workgroups over the 256 CUs (time of a round ~ its channel count);
+    // ties go to the larger tile (the halo is staged once per workgroup)
+    const BoardEntry* best = nullptr;
+    long best_cost = 0;
+    for (const auto& e : kBoardEntries) {
+        if (ko_pad % e.kot != 0 || e.lds(bp.npos) > kMaxLds) continue;
+        const long kts = ko_pad / e.kot, rounds = (bp.ntiles * kts + kNumCU - 1) / kNumCU, cost = rounds * e.kot;
+        if (!best || cost < best_cost) { best = &e; best_cost = cost; *kot_tiles = (int)kts; }
+    }
+    return best;
 }
 
 struct Stat {
@@ -430,11 +434,22 @@ public:
         geom_.bsz.resize(n);
         geom_.off.resize(n + 1);
         geom_.off[0] = 0;
+        // Device order = the batch's samples sorted by board size (largest first, stable): samples of one size become
+        // neighbours, so the one-workgroup-per-board convolution packs them into full tiles (two 13x13 or four 9x9 boards
+        // per tile) whatever order the queue collected them in.  perm[i] = the caller's slot of device sample i; only
+        // pack_input (reads the planes) and head_tail (writes the outputs) see the caller's order.
+        perm_.resize(n);
+        bool mixed = false;
         for (int i = 0; i < n; ++i) {
             const int bs = board_sizes ? board_sizes[i] : board_;
             if (bs < 2 || bs > board_) return fail("sample board size out of range");
-            geom_.bsz[i] = bs;
-            geom_.off[i + 1] = geom_.off[i] + bs * bs;
+            perm_[i] = i;
+            mixed |= board_sizes && bs != board_sizes[0];
+        }
+        if (mixed) std::stable_sort(perm_.begin(), perm_.end(), [&](int a, int b) { return board_sizes[a] > board_sizes[b]; });
+        for (int i = 0; i < n; ++i) {
+            geom_.bsz[i] = board_sizes ? board_sizes[perm_[i]] : board_;
+            geom_.off[i + 1] = geom_.off[i] + geom_.bsz[i] * geom_.bsz[i];
         }
         geom_.total = geom_.off[n];
         if (geom_.bsz != prev_bsz_) {  // tile choices and index tables depend on the geometry only
@@ -448,12 +463,14 @@ public:
             slot.board.fresh = false;
             slot.tabs_bsz = geom_.bsz;
         }
-        int* hg = h_geom_ + (size_t)geom_slot_ * (2 * max_batch_ + 1);
+        int* hg = h_geom_ + (size_t)geom_slot_ * (3 * max_batch_ + 1);
         geom_slot_ ^= 1;
         std::memcpy(hg, geom_.off.data(), sizeof(int) * (n + 1));
         std::memcpy(hg + max_batch_ + 1, geom_.bsz.data(), sizeof(int) * n);
+        std::memcpy(hg + 2 * max_batch_ + 1, perm_.data(), sizeof(int) * n);
         HIP_OK(hipMemcpyAsync(d_off_, hg, sizeof(int) * (n + 1), hipMemcpyHostToDevice, copy_stream));
         HIP_OK(hipMemcpyAsync(d_bsz_, hg + max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
+        HIP_OK(hipMemcpyAsync(d_perm_, hg + 2 * max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
         HIP_OK(hipMemcpyAsync(d_planes_, planes, sizeof(float) * (size_t)n * desc_.input_channels * board_ * board_,
                               hipMemcpyHostToDevice, copy_stream));
         return 0;
@@ -716,14 +733,14 @@ private:
         const size_t B2 = (size_t)board_ * board_;
         for (IoSlot& io : io_) {
             if (dev_alloc(&io.planes, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
-            if (dev_alloc(&io.off, max_batch_ + 1) || dev_alloc(&io.bsz, max_batch_)) return -1;
+            if (dev_alloc(&io.off, max_batch_ + 1) || dev_alloc(&io.bsz, max_batch_) || dev_alloc(&io.perm, max_batch_)) return -1;
             if (dev_alloc(&io.prob, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
             if (dev_alloc(&io.pass, (size_t)max_batch_ * desc_.pass_probability_outputs)) return -1;
             if (dev_alloc(&io.misc, (size_t)max_batch_ * desc_.value_misc_outputs)) return -1;
             if (dev_alloc(&io.own, (size_t)max_batch_ * B2)) return -1;
         }
         if (dev_alloc(&d_zeros_, 64)) return -1;
-        HIP_OK(hipHostMalloc((void**)&h_geom_, sizeof(int) * 2 * (2 * max_batch_ + 1), hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void**)&h_geom_, sizeof(int) * 2 * (3 * max_batch_ + 1), hipHostMallocDefault));
         for (IoSlot& io : io_) {
             if (dev_alloc(&io.gate, (size_t)max_batch_ * 2 * round_up(desc_.residual_channels, 32))) return -1;
             if (dev_alloc(&io.separt, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
@@ -1050,7 +1067,7 @@ private:
             const int cin = d.input_channels, cs = L.cin_s, board = board_;
             if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
                     hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(256), 0, stream_,
-                                       (const float*)d_planes_, dst, g, cin, cs, board);
+                                       (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_);
                 }))
                 return -1;
             if (conv("conv3x3_input", L, bufs_[in], bufs_[x], nullptr, act)) return -1;
@@ -1136,7 +1153,7 @@ private:
         h.own_b = cv(SAYURI_L_V_OWNERSHIP).bias;
         h.Cp = Cp; h.cs_p = round_up(Cp, 32); h.Cv = Cv; h.cs_v = round_up(Cv, 32);
         h.prob_ch = d.probabilities_channels; h.act = act; h.board = board_;
-        h.prob = d_prob_; h.pass = d_pass_; h.misc = d_misc_; h.own = d_own_;
+        h.prob = d_prob_; h.pass = d_pass_; h.misc = d_misc_; h.own = d_own_; h.perm = d_perm_;
         const int maxc = std::max(Cp, Cv);
         const size_t smem = sizeof(float) * (7 * maxc + 512);
         const T* pc = bufs_[pb];
@@ -1160,7 +1177,7 @@ private:
     // device-side batch i/o, one set per ticket; the d_* members below alias the slot the current forward uses
     struct IoSlot {
         float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;
-        int *off = nullptr, *bsz = nullptr;
+        int *off = nullptr, *bsz = nullptr, *perm = nullptr;
         T* bufs[kNumBufs] = {};
         float *gate = nullptr, *separt = nullptr;
         std::map<int, TileTabs> tabs;   // index tables of the geometry this slot last ran (keyed by tile variant)
@@ -1173,7 +1190,7 @@ private:
     void select_slot(int t) {
         IoSlot& io = io_[t];
         cur_slot_ = t;
-        d_planes_ = io.planes; d_off_ = io.off; d_bsz_ = io.bsz;
+        d_planes_ = io.planes; d_off_ = io.off; d_bsz_ = io.bsz; d_perm_ = io.perm;
         d_prob_ = io.prob; d_pass_ = io.pass; d_misc_ = io.misc; d_own_ = io.own;
         for (int i = 0; i < kNumBufs; ++i) bufs_[i] = io.bufs[i];
         d_gate_ = io.gate; d_separt_ = io.separt;
@@ -1185,9 +1202,10 @@ private:
     bool busy_[kNumBufs] = {};
     float *d_planes_ = nullptr, *d_gate_ = nullptr, *d_separt_ = nullptr, *d_prob_ = nullptr, *d_pass_ = nullptr, *d_misc_ = nullptr,
           *d_own_ = nullptr;
-    int *d_off_ = nullptr, *d_bsz_ = nullptr;
+    int *d_off_ = nullptr, *d_bsz_ = nullptr, *d_perm_ = nullptr;
+    std::vector<int> perm_;  // device sample -> caller's slot (enqueue_inputs)
     float* d_zeros_ = nullptr;
-    int* h_geom_ = nullptr;  // pinned 2-slot ring: [slot][off(max_batch+1) | bsz(max_batch)]
+    int* h_geom_ = nullptr;  // pinned 2-slot ring: [slot][off(max_batch+1) | bsz(max_batch) | perm(max_batch)]
     int geom_slot_ = 0, next_ticket_ = 0;
     hipEvent_t tick_ev_[2] = {nullptr, nullptr};
     HostGeom geom_;
@@ -1666,7 +1684,7 @@ static int test_head_tail_impl(int device, int n, const int* board_sizes, int ma
     h.v_misc = FcDev{d_vm, d_vmb, 3 * Cv, misc_outs};
     h.prob_w = d_prw; h.prob_b = d_prb; h.own_w = d_ow; h.own_b = d_ob;
     h.Cp = Cp; h.cs_p = cs_p; h.Cv = Cv; h.cs_v = cs_v; h.prob_ch = prob_ch; h.act = act; h.board = max_board;
-    h.prob = d_prob; h.pass = d_pass; h.misc = d_misc; h.own = d_own;
+    h.prob = d_prob; h.pass = d_pass; h.misc = d_misc; h.own = d_own; h.perm = nullptr;
     const int maxc = std::max(Cp, Cv);
     hipLaunchKernelGGL(head_tail_kernel<T>, dim3(2 * n), dim3(256), sizeof(float) * (7 * maxc + 512), 0, (const T*)dp, (const T*)dv, tg.g, h);
     HIP_OK(hipGetLastError());

