@@ -562,7 +562,7 @@ __device__ __forceinline__ void se_fc4(const FcDev fc, const float* x, float* re
 
 template <int WMT>
 __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
-                                               int wave, int lane, int col0, int nj, int bs) {
+                                               int wave, int lane, int col0, int nj, int bs, unsigned long long* dbg = nullptr) {
     using Cfg = BoardCfg<WMT>;
     constexpr int NJ = Cfg::NJ, KO_T = Cfg::KO_T;
     const ConvParams& p = sp.b.c;
@@ -583,17 +583,26 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
     f32x4 s4[WMT], m4[WMT];
 #pragma unroll
     for (int i = 0; i < WMT; ++i) { s4[i] = f32x4{0.f, 0.f, 0.f, 0.f}; m4[i] = f32x4{-5000.f, -5000.f, -5000.f, -5000.f}; }
+    // a one-sample tile has its unused pixel slots at the end: only the wave's LAST column tile can hold any, so only
+    // that one is masked (the others are summed with packed adds)
+    const bool last_valid = nj > 0 ? pix[(nj - 1) * 16].y >= 0 : false;
     static_for<NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nj) {
-            const bool valid = pix[j * 16].y >= 0;
+            const bool valid = j + 1 < nj ? true : last_valid;
 #pragma unroll
             for (int i = 0; i < WMT; ++i) {
                 const f32x4 v = acc[i][j];
+                if (j + 1 < nj) {  // wave-uniform
+                    s4[i] += v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s4[i][r] += valid ? v[r] : 0.f;
-                    m4[i][r] = valid ? fmaxf(m4[i][r], v[r]) : m4[i][r];
+                    for (int r = 0; r < 4; ++r) m4[i][r] = fmaxf(m4[i][r], v[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s4[i][r] += valid ? v[r] : 0.f;
+                        m4[i][r] = valid ? fmaxf(m4[i][r], v[r]) : m4[i][r];
+                    }
                 }
             }
         }
@@ -618,6 +627,7 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
         }
     }
     __syncthreads();
+    if (dbg) dbg[2] = __builtin_amdgcn_s_memtime();  // pooled partials exchanged
     const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
     for (int c = tid; c < C; c += 512) {
         const float mean = (psum[c] + psum[KO_T + c]) / npix;
@@ -636,6 +646,7 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
         mid[o] = activate(a, p.act);
     }
     __syncthreads();
+    if (dbg) dbg[3] = __builtin_amdgcn_s_memtime();  // squeeze FC done
     se_fc4(sp.excite, mid, red, tid);
     __syncthreads();
     {
@@ -648,6 +659,7 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
         }
     }
     __syncthreads();
+    if (dbg) dbg[4] = __builtin_amdgcn_s_memtime();  // excite FC done, gate in LDS
     // ---- x <- sigmoid(gamma) x + beta on the accumulators (pad channels: weights and bias are 0, x stays 0 * g + b:
     // their gate entries are never written, so they are masked here)
 #pragma unroll
@@ -680,11 +692,19 @@ __global__ __launch_bounds__(512, 2) void conv_board_se_kernel(const BoardSePara
     const int col0 = wave_n ? nj0 : 0;
     const int nj = wave_n ? ncols - nj0 : nj0;
 
+    // timeline (SAYURI_BOARD_DBG=-n): [0] start, [1] K loop done, [2] pooled, [3] squeeze FC, [4] excite FC, [5] gate applied, [6] end
+    unsigned long long* dbg = nullptr;
+    if (bp.dbg && blockIdx.x < 4 && lane == 0) {
+        dbg = bp.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        dbg[0] = __builtin_amdgcn_s_memtime();
+    }
     f32x4 acc[WMT][kBoardNJ];
     board_mainloop<WMT>(bp, smem, acc, tile, 0, wave, lane, col0, nj == kBoardNJ, bs);
-    board_se_stage<WMT>(sp, smem, acc, tile, wave, lane, col0, nj, bs);
+    if (dbg) dbg[1] = __builtin_amdgcn_s_memtime();
+    board_se_stage<WMT>(sp, smem, acc, tile, wave, lane, col0, nj, bs, dbg);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // gate fully read before the epilogue's residual pieces land in the same LDS
+    if (dbg) dbg[5] = __builtin_amdgcn_s_memtime();
 
     switch (p.act) {
     case kMish: board_epilogue<WMT, kMish>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
@@ -695,6 +715,10 @@ __global__ __launch_bounds__(512, 2) void conv_board_se_kernel(const BoardSePara
     case kSELU: board_epilogue<WMT, kSELU>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
     case kGELU: board_epilogue<WMT, kGELU>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
     default: board_epilogue<WMT, kHardSwish>(bp, smem, acc, tile, 0, wave, lane, col0, nj); break;
+    }
+    if (dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg[6] = __builtin_amdgcn_s_memtime();
     }
 }
 

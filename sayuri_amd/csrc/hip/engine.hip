@@ -24,6 +24,7 @@
 #include "conv_mfma.h"
 #include "conv_glds.h"
 #include "conv_board.h"
+#include "head_board.h"
 #include "small_ops.h"
 
 namespace sayuri {
@@ -109,11 +110,19 @@ static const BoardEntry kBoardEntries[] = {
     {192, &conv_board_kernel<3>, nullptr, &BoardCfg<3>::lds_bytes},
     {128, &conv_board_kernel<2>, &conv_board_se_kernel<2>, &BoardCfg<2>::lds_bytes},
 };
+// head_board_kernel variants: {row tiles, trunk chunks in flight}; the first that fits the LDS is used (head_board_fits)
+typedef void (*HeadFn)(const HeadBoardParams);
+struct HeadEntry { int rt, depth; HeadFn fn; };
+static const HeadEntry kHeadEntries[] = {
+    {2, 5, &head_board_kernel<2, 5>}, {4, 5, &head_board_kernel<4, 5>}, {4, 3, &head_board_kernel<4, 3>},
+    {6, 3, &head_board_kernel<6, 3>}, {6, 2, &head_board_kernel<6, 2>},
+};
 static void enable_big_lds_glds() {
     register_all_glds();
     for (const auto& e : glds_entries())
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)&conv_board_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    for (const auto& e : kHeadEntries) (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     for (const auto& e : kBoardEntries) {
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
         if (e.fn_se) (void)hipFuncSetAttribute((const void*)e.fn_se, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
@@ -546,10 +555,25 @@ public:
         const int rc = forward();
         profiling_ = false;
         if (rc) return -1;
+        if (d_hdbg_) {
+            std::vector<unsigned long long> h(4 * 8);
+            HIP_OK(hipMemcpy(h.data(), d_hdbg_, h.size() * 8, hipMemcpyDeviceToHost));
+            for (int wg = 0; wg < 4; ++wg) {
+                const unsigned long long* d = &h[wg * 8];
+                fprintf(stderr, "[heads timeline wg%d] DMA + K loop %llu | act, per-pixel MFMA, pooling partials %llu | pool fold %llu | FC 1 %llu | FC 2 + row bias %llu | stores %llu | total %llu\n",
+                        wg, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[6] - d[0]);
+            }
+        }
         if (d_dbg_) {  // SAYURI_BOARD_DBG: s_memtime timeline of the last tower convolution (workgroups 0-3, all waves)
             std::vector<unsigned long long> h(4 * 8 * 8);
             HIP_OK(hipMemcpy(h.data(), d_dbg_, h.size() * 8, hipMemcpyDeviceToHost));
-            for (int wg = 0; wg < 4; ++wg)
+            for (int wg = 0; wg < 4 && dbg_is_se_; ++wg)
+                for (int w = 0; w < 8; w += 4) {
+                    const unsigned long long* d = &h[((size_t)wg * 8 + w) * 8];
+                    fprintf(stderr, "[board+SE timeline wg%d wave%d] prologue+K loop %llu | pooling %llu | squeeze FC %llu | excite FC %llu | gate applied %llu | epilogue %llu | total %llu\n",
+                            wg, w, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[6] - d[0]);
+                }
+            for (int wg = 0; wg < 4 && !dbg_is_se_; ++wg)
                 for (int w = 0; w < 8; ++w) {
                     const unsigned long long* d = &h[((size_t)wg * 8 + w) * 8];
                     fprintf(stderr, "[board timeline wg%d wave%d] tables+first DMA %llu | first barrier %llu | main loop %llu (sync %llu) | epilogue %llu | total %llu\n",
@@ -667,8 +691,62 @@ private:
 
     static bool is_tiny_head_conv(int id) { return id == SAYURI_L_PROB_CONV || id == SAYURI_L_V_OWNERSHIP; }
 
+    static bool heads_fused_enabled() {
+        const char* sw = getenv("SAYURI_HEADS_FUSED");  // A/B switch, read per call
+        return !(sw && atoi(sw) == 0);
+    }
+    // Stacked [policy | value] head-convolution image for head_board_kernel (fp16 engine, normal policy head).
+    int build_head_image() {
+        const sayuri_hip_netdesc& d = desc_;
+        if (sizeof(T) != 2 || d.policy_head_type != 0 || board_ * board_ > kHeadPix) return 0;
+        const ConvLayerDev& P = convs_.at(SAYURI_L_P_HD_CONV);
+        const ConvLayerDev& V = convs_.at(SAYURI_L_V_HD_CONV);
+        if (P.hw.empty() || V.hw.empty() || P.hb.empty() || V.hb.empty()) return 0;
+        // rows: policy channels rounded to a row tile of 16, then the value channels up to an even number of row tiles
+        const int PT = round_up(P.cout, 16), rows = round_up(PT + V.cout, 32), VT = rows - PT, cs = round_up(P.cin, 32), nch = cs / 32;
+        head_fn_ = nullptr;
+        for (const auto& e : kHeadEntries)
+            if (e.rt * 16 == rows && head_board_fits(rows, nch, e.depth)) { head_fn_ = e.fn; break; }
+        const ConvLayerDev& PW = convs_.at(SAYURI_L_PROB_CONV);
+        const ConvLayerDev& OW = convs_.at(SAYURI_L_V_OWNERSHIP);
+        if (!head_fn_ || PW.hw.empty() || OW.hw.empty() || d.probabilities_channels > 8) return 0;
+        // per-pixel weights in the accumulator's channel order: k-group kg of pair t holds stacked rows 32t + 4kg + s (s < 4)
+        // and 32t + 16 + 4kg + (s - 4); row k < prob_ch = policy plane k over the policy rows, row prob_ch = ownership
+        std::vector<T> img2((size_t)(rows / 32) * 4 * 16 * 8, from_float_host(0.f));
+        for (int t = 0; t < rows / 32; ++t)
+            for (int kg = 0; kg < 4; ++kg)
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = 32 * t + (e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4));
+                    for (int k = 0; k < d.probabilities_channels; ++k)
+                        if (ch < P.cout) img2[(((size_t)t * 4 + kg) * 16 + k) * 8 + e] = from_float_host(PW.hw[(size_t)k * P.cout + ch]);
+                    if (ch >= PT && ch - PT < V.cout)
+                        img2[(((size_t)t * 4 + kg) * 16 + d.probabilities_channels) * 8 + e] = from_float_host(OW.hw[ch - PT]);
+                }
+        T* w2 = nullptr;
+        if (dev_upload(&w2, img2)) return -1;
+        head_img2_ = w2;
+        std::vector<T> img((size_t)nch * 4 * rows * 8, from_float_host(0.f));
+        std::vector<float> b(rows, 0.f);
+        for (int half = 0; half < 2; ++half) {
+            const ConvLayerDev& L = half ? V : P;
+            const int r0 = half ? PT : 0;
+            for (int ko = 0; ko < L.cout; ++ko) {
+                b[r0 + ko] = L.hb[ko];
+                for (int c = 0; c < L.cin; ++c)
+                    img[(((size_t)(c / 32) * 4 + (c % 32) / 8) * rows + r0 + ko) * 8 + c % 8] = from_float_host(L.hw[(size_t)ko * L.cin + c]);
+            }
+        }
+        T* w = nullptr;
+        if (dev_upload(&w, img) || dev_upload(&head_bias_, b)) return -1;
+        head_img_ = w;
+        head_pt_ = PT;
+        head_vt_ = VT;
+        return 0;
+    }
+
     int finalize() {
         if (finalized_) return 0;
+        if (build_head_image()) return -1;
         for (auto& kv : convs_) {
             ConvLayerDev& L = kv.second;
             if (L.hw.empty() || L.hb.empty()) return fail("missing tensors for conv layer " + std::to_string(kv.first));
@@ -906,8 +984,14 @@ private:
         const char* sw = getenv("SAYURI_SE_FUSED");  // A/B switch, read per call so that a test can flip it between pipes
         const bool off = sw && atoi(sw) == 0;
         int bkt = 0;
-        const BoardEntry* be = off ? nullptr : choose_board(L, &bkt);
-        if (!be || !be->fn_se || bkt != 1 || !board_plan_.single || C > be->kot) return 1;
+        const BoardEntry* be = nullptr;
+        // the variant whose channel tile covers the whole layer, whatever the batch size: a position's result must not
+        // depend on how many others share its batch (a small batch would otherwise pick two half-width workgroups and
+        // the separate SE kernels, which round x to fp16 before pooling)
+        if (!off && choose_board(L, &bkt))
+            for (const auto& e : kBoardEntries)
+                if (e.fn_se && e.kot == L.ko_pad && e.lds(board_plan_.npos) <= kMaxLds) be = &e;
+        if (!be || !board_plan_.single || C > be->kot) return 1;
         if (sq.out % 4 || sq.out > 512 || ex.out % 4 || ex.out > 2048 || 512 % (sq.out / 4) || 512 % (ex.out / 4)) return 1;
         if constexpr (sizeof(T) != 2) return 1;
         const BoardTabs* tabs = nullptr;
@@ -922,6 +1006,12 @@ private:
         p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
         p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = board_plan_.ntiles;
         sp.squeeze = sq.dev(); sp.excite = ex.dev(); sp.C = C;
+        if (const char* dv = getenv("SAYURI_BOARD_DBG")) {  // negative n: timeline of the n-th SE convolution of the forward
+            if (atoi(dv) < 0) {
+                if (!d_dbg_ && dev_alloc(&d_dbg_, 4 * 8 * 8)) return -1;
+                if (++dbg_se_call_ == -atoi(dv)) { bp.dbg = d_dbg_; dbg_is_se_ = true; }
+            }
+        }
         const double px = geom_.total;
         const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out);
         const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
@@ -1056,6 +1146,7 @@ private:
         const BatchGeom g = dgeom();
         for (int i = 0; i < kNumBufs; ++i) busy_[i] = false;
         dbg_call_ = 0;
+        dbg_se_call_ = 0;
 
         int x = take();
         {
@@ -1132,16 +1223,6 @@ private:
 
         // heads
         const int Cp = d.policy_head_channels, Cv = d.value_head_channels;
-        int pb = take();
-        const int vb = take();
-        if (conv("conv1x1_head", cv(SAYURI_L_P_HD_CONV), bufs_[x], bufs_[pb], nullptr, act)) return -1;
-        if (d.policy_head_type == 1) {
-            const int p2 = take();
-            if (depthwise("depthwise", cv(SAYURI_L_P_DW_CONV), bufs_[pb], bufs_[p2], nullptr, act)) return -1;
-            if (conv("conv1x1_head", cv(SAYURI_L_P_PT_CONV), bufs_[p2], bufs_[pb], nullptr, act)) return -1;
-            give(p2);
-        }
-        if (conv("conv1x1_head", cv(SAYURI_L_V_HD_CONV), bufs_[x], bufs_[vb], nullptr, act)) return -1;
         HeadParams h;
         h.p_inter = fc(SAYURI_L_P_INTER_FC).dev();
         h.pass_fc = fc(SAYURI_L_PASS_FC).dev();
@@ -1154,6 +1235,34 @@ private:
         h.Cp = Cp; h.cs_p = round_up(Cp, 32); h.Cv = Cv; h.cs_v = round_up(Cv, 32);
         h.prob_ch = d.probabilities_channels; h.act = act; h.board = board_;
         h.prob = d_prob_; h.pass = d_pass_; h.misc = d_misc_; h.own = d_own_; h.perm = d_perm_;
+        if (head_img_ && heads_fused_enabled()) {
+            // both heads of a sample in one workgroup: trunk -> LDS -> stacked 1x1 convolution on the matrix cores -> pooling,
+            // FCs and the per-pixel planes (head_board.h)
+            HeadBoardParams hp;
+            hp.dbg = nullptr;
+            if (getenv("SAYURI_HEADS_DBG")) {
+                if (!d_hdbg_ && dev_alloc(&d_hdbg_, 4 * 8)) return -1;
+                hp.dbg = d_hdbg_;
+            }
+            hp.trunk = bufs_[x]; hp.w = head_img_; hp.w2 = head_img2_; hp.bias = head_bias_; hp.g = g; hp.cs = csC; hp.PT = head_pt_; hp.VT = head_vt_; hp.h = h;
+            const auto fn = head_fn_;
+            {
+                const double flops = 2.0 * geom_.total * C * (Cp + Cv);
+                return timed("heads_fused", flops, (double)geom_.total * csC * 2, [&] {
+                    hipLaunchKernelGGL(fn, dim3(geom_.n), dim3(512), kMaxLds, stream_, hp);
+                });
+            }
+        }
+        int pb = take();
+        const int vb = take();
+        if (conv("conv1x1_head", cv(SAYURI_L_P_HD_CONV), bufs_[x], bufs_[pb], nullptr, act)) return -1;
+        if (d.policy_head_type == 1) {
+            const int p2 = take();
+            if (depthwise("depthwise", cv(SAYURI_L_P_DW_CONV), bufs_[pb], bufs_[p2], nullptr, act)) return -1;
+            if (conv("conv1x1_head", cv(SAYURI_L_P_PT_CONV), bufs_[p2], bufs_[pb], nullptr, act)) return -1;
+            give(p2);
+        }
+        if (conv("conv1x1_head", cv(SAYURI_L_V_HD_CONV), bufs_[x], bufs_[vb], nullptr, act)) return -1;
         const int maxc = std::max(Cp, Cv);
         const size_t smem = sizeof(float) * (7 * maxc + 512);
         const T* pc = bufs_[pb];
@@ -1212,8 +1321,15 @@ private:
     std::vector<int> prev_bsz_;
     std::map<int, GldsChoice> glds_cache_;
     BoardPlan board_plan_;
+    HeadFn head_fn_ = nullptr;
+    void* head_img2_ = nullptr;  // per-pixel weights (policy planes, ownership) as an MFMA image
+    void* head_img_ = nullptr;   // stacked head-convolution image (head_board.h); null = separate head kernels
+    float* head_bias_ = nullptr;
+    int head_pt_ = 0, head_vt_ = 0;
+    unsigned long long* d_hdbg_ = nullptr;  // SAYURI_HEADS_DBG timeline of head_board_kernel
     unsigned long long* d_dbg_ = nullptr;  // SAYURI_BOARD_DBG timeline of one tower convolution
-    int dbg_call_ = 0;
+    int dbg_call_ = 0, dbg_se_call_ = 0;
+    bool dbg_is_se_ = false;
     bool board_plan_valid_ = false;
     std::map<int, TileChoice> tile_cache_;
     std::map<std::string, Stat> stats_;

@@ -200,6 +200,31 @@ def test_se_unit_fused_into_the_convolution_matches_the_separate_kernels(tmp_wei
         assert np.abs(outs["1"][i] - outs["0"][i]).max() > 0, "the switch did not change the path"
 
 
+@pytest.mark.parametrize("name", ["net_20b256", "net_40b384", "net_6b96", "tiny_res", "tiny_all"])
+def test_heads_fused_kernel_matches_the_separate_head_kernels(name, tmp_weights_dir, monkeypatch):
+    """fp16 engine, normal policy head: both 1x1 head convolutions, the pooling, the four FCs and the per-pixel planes run
+    as one workgroup per sample (head_board.h); SAYURI_HEADS_FUSED=0 runs conv1x1 x2 + head_tail_kernel.  Both against the
+    oracle, mixed board sizes in caller order (the fused kernel writes through the sort permutation)."""
+    g = Golden(name, tmp_weights_dir)
+    oracle = PortNet(g.weights_path)
+    bsz = [19, 13, 19, 9, 19, 19, 7, 19, 13]
+    planes = W.synthetic_planes(len(bsz), bsz, seed=777)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SAYURI_HEADS_FUSED", mode)
+        pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=16, fp16=True)
+        try:
+            outs[mode] = pipe.BatchForward(planes, bsz)
+        finally:
+            pipe.Destroy()
+    for i, (p, bs) in enumerate(zip(planes, bsz)):
+        exp = oracle.forward(p, bs)
+        assert np.abs(outs["1"][i] - exp).max() <= fp16_tol(exp), (i, bs)
+        assert np.abs(outs["0"][i] - exp).max() <= fp16_tol(exp), (i, bs)
+    if name != "tiny_all":  # tiny_all has a RepLK policy head: the fused kernel does not apply, both runs are the same path
+        assert any(np.abs(outs["1"][i] - outs["0"][i]).max() > 0 for i in range(len(bsz))), "the switch did not change the path"
+
+
 @pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
 def test_40b384_golden_parity(fp16, tmp_weights_dir):
     """BASELINE.json configs[4] network (40 blocks x 384 filters) on 19 / 13 / 9 boards against the reference's own
