@@ -105,7 +105,7 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
     ms = ctypes.c_float(0)
     lib.sayuri_hip_mark_kernel(ctx, b"")
     lib.sayuri_hip_time_runs(ctx, warmup, ctypes.byref(ms))
-    lib.sayuri_hip_mark_kernel(ctx, b"conv3x3_tower")
+    lib.sayuri_hip_mark_kernel(ctx, b"conv3x3_tower/5")  # one event pair per run of five tower launches (see main())
     lib.sayuri_hip_sync(ctx)
     t0 = time.perf_counter()
     if lib.sayuri_hip_time_runs(ctx, steps, ctypes.byref(ms)):
@@ -124,6 +124,55 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
             "whole_net_tflops": round(flops_batch * steps / el / 1e12, 1), "whole_net_mfma_frac": round(flops_batch * steps / el / 1e12 / 2500.0, 4),
             "tower_conv_avg_launch_us": round(stat.total_ms / max(stat.launches, 1) * 1e3, 2),
             "tower_conv_tflops": round(tower_tf, 1) if tower_tf else None, "tower_conv_mfma_frac": round(tower_tf / 2500.0, 4) if tower_tf else None}
+
+
+def pump_segment(lib, ctx, grid, n: int, steps: int) -> dict:
+    """The production form of the same step: what the pump thread of HipForwardPipe does (hip_forward_pipe.cc) -- two
+    batches in flight on the engine's two compute streams through sayuri_hip_submit / sayuri_hip_wait, fp32 planes from
+    pinned host buffers (H2D), outputs back into pinned buffers (D2H).  PCIe-inclusive, so it is reported beside `value`,
+    never as `value`; the two streams let the epilogue of one batch's convolution run under the K loop of the other's."""
+    FP = ctypes.POINTER(ctypes.c_float)
+    lib.sayuri_hip_host_alloc.restype = ctypes.c_void_p
+    lib.sayuri_hip_host_alloc.argtypes = [ctypes.c_size_t]
+    lib.sayuri_hip_host_free.argtypes = [ctypes.c_void_p]
+    lib.sayuri_hip_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, FP, ctypes.POINTER(ctypes.c_int), FP, FP, FP, FP,
+                                      ctypes.POINTER(ctypes.c_int)]
+    lib.sayuri_hip_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    B2 = grid.shape[2]
+    sizes = (grid.size, n * 5 * B2, n * 8, n * 32, n * B2)  # planes, prob, pass, misc (generous), own
+    raw, bufs = [], []
+    for _ in range(2):
+        ptrs = [lib.sayuri_hip_host_alloc(k * 4) for k in sizes]
+        if not all(ptrs):
+            raise RuntimeError("sayuri_hip_host_alloc failed")
+        raw += ptrs
+        np.ctypeslib.as_array(ctypes.cast(ptrs[0], FP), (grid.size,))[:] = grid.ravel()
+        bufs.append([ctypes.cast(q, FP) for q in ptrs])
+    tick = [ctypes.c_int(-1), ctypes.c_int(-1)]
+
+    def submit(i):
+        pl, pr, pa, mi, ow = bufs[i]
+        if lib.sayuri_hip_submit(ctx, n, pl, None, pr, pa, mi, ow, ctypes.byref(tick[i])):
+            raise RuntimeError(lib.sayuri_hip_last_error().decode())
+
+    def wait(i):
+        if lib.sayuri_hip_wait(ctx, tick[i].value):
+            raise RuntimeError(lib.sayuri_hip_last_error().decode())
+
+    for _ in range(2):
+        submit(0); wait(0)
+    steps = max(steps, 4)
+    t0 = time.perf_counter()
+    submit(0); submit(1)
+    for k in range(steps - 2):
+        wait(k & 1); submit(k & 1)
+    wait(steps & 1); wait((steps + 1) & 1)
+    dt = time.perf_counter() - t0
+    for q in raw:
+        lib.sayuri_hip_host_free(ctypes.c_void_p(q))
+    return {"nn_evals_per_sec": round(n * steps / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 4), "batches": steps, "in_flight": 2,
+            "what": "sayuri_hip_submit/wait as the pump thread drives them: H2D of fp32 planes from pinned memory + forward + D2H, "
+                    "two batches in flight on two compute streams (PCIe-inclusive, so not `value`)"}
 
 
 def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
@@ -172,6 +221,8 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="strict-parity fp32 engine instead of fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-pump", dest="pump", action="store_false",
+                    help="skip the pipelined segment (two batches in flight through submit/wait, PCIe-inclusive)")
     ap.add_argument("--profile", action="store_true", help="also print the per-kernel-class table to stderr")
     ap.add_argument("--selfplay-seconds", type=float, default=150.0,
                     help="length of the self-play window (configs[2]: 512 concurrent 19x19 games, 400 visits); 0 = skip")
@@ -236,7 +287,10 @@ def main():
         lib.sayuri_hip_mark_kernel(ctx, b"")
         if lib.sayuri_hip_time_runs(ctx, args.warmup, ctypes.byref(ms)):
             raise RuntimeError(lib.sayuri_hip_last_error().decode())
-    lib.sayuri_hip_mark_kernel(ctx, b"conv3x3_tower")
+    # every launch of the class is timed, one event pair per RUN of consecutive tower launches (five between two SE
+    # convolutions): an event is a barrier packet, one pair per launch costs ~5 % of the step and counts the pipeline
+    # refill after the barrier (~3 us) into every duration
+    lib.sayuri_hip_mark_kernel(ctx, b"conv3x3_tower/5")
 
     # ---- timed region: exactly K steps between barrier+sync pairs
     sync_all()
@@ -254,6 +308,7 @@ def main():
 
     stat = _lib.KernelStat()
     lib.sayuri_hip_timed_stat(ctx, ctypes.byref(stat))
+    pump = pump_segment(lib, ctx, grid, n, max(args.steps, 40)) if args.pump else None
 
     from sayuri_amd.shard import gather_stats
     if dist is not None:
@@ -340,6 +395,8 @@ def main():
                          "avg_launch_us": round(stat.total_ms / max(stat.launches, 1) * 1e3, 2),
                          "flops_per_launch": stat.flops / max(stat.launches, 1)},
         }
+        if pump is not None:
+            result["config"]["pump"] = pump
         if selfplay is not None:
             selfplay["frac_of_microbench_evals"] = round(selfplay["nn_evals_per_sec"] / value, 4)
             result["selfplay"] = selfplay
