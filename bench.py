@@ -126,11 +126,11 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
             "tower_conv_tflops": round(tower_tf, 1) if tower_tf else None, "tower_conv_mfma_frac": round(tower_tf / 2500.0, 4) if tower_tf else None}
 
 
-def pump_segment(lib, ctx, grid, n: int, steps: int) -> dict:
+def pump_segment(lib, ctx, grid, n: int, steps: int, packed: bool = False) -> dict:
     """The production form of the same step: what the pump thread of HipForwardPipe does (hip_forward_pipe.cc) -- two
-    batches in flight on the engine's two compute streams through sayuri_hip_submit / sayuri_hip_wait, fp32 planes from
-    pinned host buffers (H2D), outputs back into pinned buffers (D2H).  PCIe-inclusive, so it is reported beside `value`,
-    never as `value`; the two streams let the epilogue of one batch's convolution run under the K loop of the other's."""
+    batches in flight on the engine's streams (copies in, forward, copies out) through sayuri_hip_submit[_packed] /
+    sayuri_hip_wait, planes from pinned host buffers (H2D), outputs back into pinned buffers (D2H).  PCIe-inclusive, so it
+    is reported beside `value`, never as `value`."""
     FP = ctypes.POINTER(ctypes.c_float)
     lib.sayuri_hip_host_alloc.restype = ctypes.c_void_p
     lib.sayuri_hip_host_alloc.argtypes = [ctypes.c_size_t]
@@ -138,21 +138,32 @@ def pump_segment(lib, ctx, grid, n: int, steps: int) -> dict:
     lib.sayuri_hip_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, FP, ctypes.POINTER(ctypes.c_int), FP, FP, FP, FP,
                                       ctypes.POINTER(ctypes.c_int)]
     lib.sayuri_hip_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.sayuri_hip_submit_packed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                             FP, FP, FP, FP, ctypes.POINTER(ctypes.c_int)]
     B2 = grid.shape[2]
-    sizes = (grid.size, n * 5 * B2, n * 8, n * 32, n * B2)  # planes, prob, pass, misc (generous), own
+    if packed:  # the compact planes of csrc/host/packed_planes.h: 37 bit planes + 6 scalars, 1.8 KB per sample
+        from sayuri_amd.engine import pack_planes
+        inp = np.stack([pack_planes(grid[i], 37) for i in range(n)]).view(np.float32)
+    else:
+        inp = grid
+    sizes = (inp.size, n * 5 * B2, n * 8, n * 32, n * B2)  # planes, prob, pass, misc (generous), own
     raw, bufs = [], []
     for _ in range(2):
         ptrs = [lib.sayuri_hip_host_alloc(k * 4) for k in sizes]
         if not all(ptrs):
             raise RuntimeError("sayuri_hip_host_alloc failed")
         raw += ptrs
-        np.ctypeslib.as_array(ctypes.cast(ptrs[0], FP), (grid.size,))[:] = grid.ravel()
+        np.ctypeslib.as_array(ctypes.cast(ptrs[0], FP), (inp.size,))[:] = inp.ravel()
         bufs.append([ctypes.cast(q, FP) for q in ptrs])
     tick = [ctypes.c_int(-1), ctypes.c_int(-1)]
 
     def submit(i):
         pl, pr, pa, mi, ow = bufs[i]
-        if lib.sayuri_hip_submit(ctx, n, pl, None, pr, pa, mi, ow, ctypes.byref(tick[i])):
+        if packed:
+            rc = lib.sayuri_hip_submit_packed(ctx, n, ctypes.cast(pl, ctypes.c_void_p), 37, None, pr, pa, mi, ow, ctypes.byref(tick[i]))
+        else:
+            rc = lib.sayuri_hip_submit(ctx, n, pl, None, pr, pa, mi, ow, ctypes.byref(tick[i]))
+        if rc:
             raise RuntimeError(lib.sayuri_hip_last_error().decode())
 
     def wait(i):
@@ -171,8 +182,11 @@ def pump_segment(lib, ctx, grid, n: int, steps: int) -> dict:
     for q in raw:
         lib.sayuri_hip_host_free(ctypes.c_void_p(q))
     return {"nn_evals_per_sec": round(n * steps / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 4), "batches": steps, "in_flight": 2,
-            "what": "sayuri_hip_submit/wait as the pump thread drives them: H2D of fp32 planes from pinned memory + forward + D2H, "
-                    "two batches in flight on two compute streams (PCIe-inclusive, so not `value`)"}
+            "h2d_bytes_per_eval": int(inp.size * 4 // n),
+            "what": ("sayuri_hip_submit_packed/wait: H2D of packed planes (37 bit planes + 6 scalars) from pinned memory + forward + D2H, "
+                     if packed else
+                     "sayuri_hip_submit/wait as the pump thread drives them: H2D of fp32 planes from pinned memory + forward + D2H, ") +
+                    "two batches in flight (PCIe-inclusive, so not `value`)"}
 
 
 def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
@@ -309,6 +323,7 @@ def main():
     stat = _lib.KernelStat()
     lib.sayuri_hip_timed_stat(ctx, ctypes.byref(stat))
     pump = pump_segment(lib, ctx, grid, n, max(args.steps, 40)) if args.pump else None
+    pump_packed = pump_segment(lib, ctx, grid, n, max(args.steps, 40), packed=True) if args.pump else None
 
     from sayuri_amd.shard import gather_stats
     if dist is not None:
@@ -397,6 +412,7 @@ def main():
         }
         if pump is not None:
             result["config"]["pump"] = pump
+            result["config"]["pump_packed"] = pump_packed
         if selfplay is not None:
             selfplay["frac_of_microbench_evals"] = round(selfplay["nn_evals_per_sec"] / value, 4)
             result["selfplay"] = selfplay

@@ -60,6 +60,11 @@ void sayuri_go_info(void* game, uint64_t* info16);
 void sayuri_go_scalars(void* game, float* out6);
 void sayuri_go_maps(void* game, uint8_t* out /* [9][N+1] */);
 int sayuri_go_planes(void* game, int symmetry, int weights_version, float* planes /* [43|38][N] */);
+/* the same planes in compact form (csrc/host/packed_planes.h): record = uint32 bits[binary][12] (bit y*bs+x of a 0/1 plane)
+ * followed by 8 floats (one per broadcast plane); returns the number of binary planes (37, or 34 for v1/v2 nets) */
+int sayuri_go_planes_packed(void* game, int symmetry, int weights_version, unsigned* record /* [binary*12 + 8] */);
+/* measurement: seconds for `iters` encodings of the position; packed = 0: the 43 fp32 planes, 1: the compact record */
+double sayuri_go_encode_seconds(void* game, int iters, int packed, int symmetry, int weights_version);
 void sayuri_go_rng_stream(uint64_t seed, int n, uint32_t range, double prob, uint64_t* out /* [3n] */);
 
 /* ---- evaluation facade and tree search (reference Network, src/neural/network.h:17-98; Search,

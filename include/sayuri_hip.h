@@ -121,6 +121,18 @@ int sayuri_hip_download(sayuri_hip_ctx* ctx, float* prob, float* pass, float* mi
  * All host buffers must be page-locked (sayuri_hip_host_alloc) and stay valid until the wait. */
 int sayuri_hip_submit(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes, float* prob,
                       float* pass, float* misc, float* own, int* ticket);
+/* The same two entry points for PACKED planes (sayuri_amd/csrc/host/packed_planes.h; SURVEY.md section 8 row f1, the
+ * encoder on the critical path -- reference src/neural/encoder.cc:101-368 fills 43 fp32 planes per evaluation).
+ *   records  [n][binary_planes*12 + 8] 32-bit words: bits[binary_planes][12] (bit y*bs+x of a 0/1 plane, in the
+ *            SAMPLE's own cell order -- no re-padding into the NN grid), then 8 floats (the value of each broadcast
+ *            plane: rule, wave, komi/20, -komi/20, N/361, 1 for 43-plane nets)
+ *   binary_planes = input_channels - 6 (37) for v3+ nets, 34 for the 38-plane v1/v2 encoder
+ * 1.8 KB per sample instead of 62 KB; the first kernel expands the bits into the fp16 activations, the network sees the
+ * same values as through sayuri_hip_forward and returns bit-identical outputs. */
+int sayuri_hip_forward_packed(sayuri_hip_ctx* ctx, int n, const unsigned* records, int binary_planes, const int* board_sizes,
+                              float* prob, float* pass, float* misc, float* own);
+int sayuri_hip_submit_packed(sayuri_hip_ctx* ctx, int n, const unsigned* records, int binary_planes, const int* board_sizes,
+                             float* prob, float* pass, float* misc, float* own, int* ticket);
 int sayuri_hip_wait(sayuri_hip_ctx* ctx, int ticket);
 int sayuri_hip_query(sayuri_hip_ctx* ctx, int ticket); /* 1 = finished, 0 = still running, -1 = error */
 

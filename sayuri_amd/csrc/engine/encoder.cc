@@ -117,4 +117,109 @@ void Encoder::Planes(const GameState& state, int symmetry, int weights_version, 
     }
 }
 
+// The compact encoder: every 0/1 feature is first noted as a bit of a per-cell plane mask (indexed by the raw cell), then
+// one pass over the output cells sets the plane bits through the symmetry map -- work proportional to the stones and
+// marks on the board, not to 43 x 361 floats.  Feature semantics as in Planes() above (reference encoder.cc:101-368).
+void Encoder::Packed(const GameState& state, int symmetry, int weights_version, sayuri_host::PackedPlanes* out) {
+    const int n = state.GetNumIntersections();
+    const int version = EncoderVersion(weights_version);
+    const int channels = InputChannels(weights_version);
+    const int binary = sayuri_host::PackedPlanes::BinaryPlanes(channels);
+    const int me = state.GetToMove(), you = Opp(me);
+    const Position& b = state.board_;
+    out->Clear(binary);
+    out->board_size = state.GetBoardSize();
+    out->side_to_move = me;
+    out->komi = state.GetKomi();
+
+    std::uint64_t mask[kMaxPoints];
+    std::fill(mask, mask + n, std::uint64_t{0});
+    auto bit = [](int plane) { return std::uint64_t{1} << plane; };
+    const int past = std::min(state.GetMoveNumber() + 1, kHistory);
+    for (int p = 0; p < past; ++p) {
+        const Frame& f = state.Past(p);
+        const std::uint64_t mine = bit(3 * p), yours = bit(3 * p + 1);
+        for (int i = 0; i < n; ++i) {
+            if (f.stones[i] == me) mask[i] |= mine;
+            else if (f.stones[i] == you) mask[i] |= yours;
+        }
+        const int lm = f.last_move;
+        if (lm != kNoVertex && lm != kPassMove && lm != kResignMove) mask[b.VertexToIndex(lm)] |= bit(3 * p + 2);
+    }
+    int plane = 3 * kHistory;
+    if (b.KoMove() != kNoVertex) mask[b.VertexToIndex(b.KoMove())] |= bit(plane);
+    ++plane;
+    if (version == 1) {
+        bool safe[kMaxPoints];
+        b.SafeArea(safe, false);
+        for (int i = 0; i < n; ++i)
+            if (safe[i]) mask[i] |= bit(plane);
+        plane += 1;
+    } else {
+        if (state.GetScoringRule() != kTerritoryScoring) {
+            int owner[kMaxPoints];
+            bool safe[kMaxPoints];
+            b.ScoreAndSafeArea(owner, safe);
+            for (int i = 0; i < n; ++i) {
+                if (safe[i]) {
+                    if (owner[i] == me) mask[i] |= bit(plane);
+                    else if (owner[i] == you) mask[i] |= bit(plane + 1);
+                }
+                if (owner[i] == me) mask[i] |= bit(plane + 2);
+                else if (owner[i] == you) mask[i] |= bit(plane + 3);
+            }
+        }
+        plane += 4;
+    }
+    for (int i = 0; i < n; ++i) {
+        const int v = b.IndexToVertex(i);
+        const int s = b.At(v);
+        if (s == kBlack || s == kWhite) {
+            const int l = b.Liberties(v);
+            if (l >= 1 && l <= 4) mask[i] |= bit(plane + l - 1);
+        }
+    }
+    plane += 4;
+    std::uint8_t marks[kMaxPoints];
+    b.LadderMap(marks);
+    for (int i = 0; i < n; ++i) {
+        switch (marks[i]) {
+            case kLadderDeath: mask[i] |= bit(plane); break;
+            case kLadderEscapable: mask[i] |= bit(plane + 1); break;
+            case kLadderAtari: mask[i] |= bit(plane + 2); break;
+            case kLadderTake: mask[i] |= bit(plane + 3); break;
+            default: break;
+        }
+    }
+    // output cell d shows raw cell Index(symmetry, d)
+    const SymmetryTables& t = SymmetryTables::Get();
+    const int bs = state.GetBoardSize();
+    const bool identity = symmetry == SymmetryTables::kIdentity;
+    for (int d = 0; d < n; ++d) {
+        std::uint64_t m = mask[identity ? d : t.Index(bs, symmetry, d)];
+        while (m) {
+            out->Set(__builtin_ctzll(m), d);
+            m &= m - 1;
+        }
+    }
+    // scalars: the same arithmetic as Planes()
+    float komi = state.GetKomiWithPenalty();
+    if (me == kWhite) komi = 0.0f - komi;
+    const float komi_plane = komi * 0.05f;
+    const float size_plane = static_cast<float>(n) * (1.f / 361.f);
+    if (version == 1) {
+        out->scalars[0] = komi_plane;
+        out->scalars[1] = -komi_plane;
+        out->scalars[2] = size_plane;
+        out->scalars[3] = 1.f;
+    } else {
+        out->scalars[0] = state.GetScoringRule() == kAreaScoring ? 0.f : 1.f;
+        out->scalars[1] = state.GetWave();
+        out->scalars[2] = komi_plane;
+        out->scalars[3] = -komi_plane;
+        out->scalars[4] = size_plane;
+        out->scalars[5] = 1.f;
+    }
+}
+
 } // namespace sayuri_go

@@ -7,6 +7,7 @@
 #pragma once
 
 #include "game_state.h"
+#include "packed_planes.h"
 
 namespace sayuri_go {
 
@@ -17,6 +18,9 @@ struct Encoder {
 
     // planes: [InputChannels][board*board] of the state's own board size, already symmetry-transformed.
     static void Planes(const GameState& state, int symmetry, int weights_version, float* planes);
+    // The same planes in compact form (packed_planes.h): bits for the 0/1 planes, one float per broadcast plane; the
+    // symmetry is applied while the bits are set.  Expand() of the result equals Planes() bit for bit.
+    static void Packed(const GameState& state, int symmetry, int weights_version, sayuri_host::PackedPlanes* out);
 };
 
 } // namespace sayuri_go

@@ -74,6 +74,7 @@ void EngineOptions::Parse(const std::string& text) {
         OPT_FLT("ci_alpha", s.ci_alpha);
         OPT_BOOL("no_cache", network.no_cache);
         OPT_BOOL("early_symm_cache", network.early_symm_cache);
+        OPT_BOOL("packed_inputs", network.packed_inputs);
         else if (k == "cache_memory_mib") network.cache_memory_mib = static_cast<size_t>(std::stol(v));
         else if (k == "policy_buffer_offset") network.default_policy_offset = static_cast<PolicyBufferOffset>(std::stoi(v));
         OPT_INT("num_games", selfplay.num_games);

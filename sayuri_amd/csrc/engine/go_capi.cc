@@ -1,5 +1,6 @@
 // C entry points of the Go engine for the Python face (sayuri_amd/engine.py) and the parity tests.
 // Moves cross this boundary as intersection indices: 0..N-1, N = pass, -1 = resign.
+#include <chrono>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -78,6 +79,40 @@ void sayuri_go_scalars(void* h, float* out) {
     out[5] = g->GetPenaltyOffset(kAreaScoring, kTerritoryScoring);
 }
 
+// the compact encoder, as the record the HIP pipe ships: bits [binary][12] then 8 scalars; returns the binary plane count
+int sayuri_go_planes_packed(void* h, int symmetry, int weights_version, unsigned* record) {
+    sayuri_host::PackedPlanes p;
+    Encoder::Packed(*G(h), symmetry, weights_version, &p);
+    p.Store(record);
+    return p.binary_planes;
+}
+// measurement: seconds for `iters` encodings of the position (packed = 0: 43 fp32 planes, 1: the compact record)
+double sayuri_go_encode_seconds(void* h, int iters, int packed, int symmetry, int weights_version) {
+    static thread_local float planes[43 * kMaxPoints];
+    sayuri_host::PackedPlanes pk;
+    unsigned sink = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) {
+        if (packed == 2) {  // the two board analyses on their own
+            std::uint8_t marks[kMaxPoints];
+            G(h)->board_.LadderMap(marks);
+            sink += marks[i % 81];
+        } else if (packed == 3) {
+            int owner[kMaxPoints];
+            bool safe[kMaxPoints];
+            G(h)->board_.ScoreAndSafeArea(owner, safe);
+            sink += owner[i % 81];
+        } else if (packed) {
+            Encoder::Packed(*G(h), symmetry, weights_version, &pk);
+            sink += pk.bits[i % 24][3];
+        } else {
+            Encoder::Planes(*G(h), symmetry, weights_version, planes);
+            sink += planes[(i * 7) % (43 * 81)] > 0.5f;
+        }
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return sink == 0xffffffffu ? -dt : dt;
+}
 int sayuri_go_planes(void* h, int symmetry, int weights_version, float* out) {
     Encoder::Planes(*G(h), symmetry, weights_version, out);
     return Encoder::InputChannels(weights_version) * G(h)->GetNumIntersections();

@@ -115,6 +115,17 @@ Network::Result Network::DummyForward(const InputData& inputs, Rng& rng) const {
 }
 
 Network::Result Network::GetOutputInternal(const GameState& state, int symmetry, PolicyBufferOffset offset, Rng& rng) {
+    if (Valid() && opt_.packed_inputs && pipe_->AcceptsPacked()) {
+        // the compact route (packed_planes.h): 37 bit planes + 6 scalars straight into the pipe's pinned staging, expanded
+        // on the GPU -- the 43 fp32 planes (62 KB written here, copied, sent, read) never exist
+        sayuri_host::PackedPlanes pk;
+        Encoder::Packed(state, symmetry, version_, &pk);
+        pk.offset = static_cast<int>((offset == PolicyBufferOffset::kDefault) ? opt_.default_policy_offset : offset);
+        num_queries_.fetch_add(1, std::memory_order_relaxed);
+        Result result = pipe_->ForwardPacked(pk);
+        TransformResult(result, symmetry);
+        return result;
+    }
     InputData in; // 62 KB of planes on the caller's stack: no sharing between threads (or fibers)
     in.board_size = state.GetBoardSize();
     in.side_to_move = state.GetToMove();

@@ -85,6 +85,7 @@ struct NetworkOptions {
     bool no_cache{false};
     bool early_symm_cache{false};
     size_t cache_memory_mib{400};
+    bool packed_inputs{true};  // compact planes (packed_planes.h) when the pipe takes them; false = 43 fp32 planes as the reference
 };
 
 class Network {

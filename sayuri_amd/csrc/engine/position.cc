@@ -707,7 +707,8 @@ void Position::InnerRegions(int v, int c, const Groups& regions, bool* inner) co
         p = regions.next[p];
     } while (p != v);
 
-    auto rest = std::make_unique<Groups>();
+    Groups rest_store;  // ~2.5 KB of scratch on the stack (Classify writes every field it later reads)
+    Groups* const rest = &rest_store;
     Classify(kEmpty, surround, *rest);
     int cnt = rest->count;
     // NOTE: after dropping an edge-touching group the scan advances past the group that slid into its slot;
@@ -776,8 +777,9 @@ void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_p
         const int v = IndexToVertex(i);
         occ[v] = cell_[v] == color ? static_cast<std::uint8_t>(color) : static_cast<std::uint8_t>(kEmpty);
     }
-    auto regions = std::make_unique<Groups>();
-    auto chains = std::make_unique<Groups>();
+    Groups regions_store, chains_store;
+    Groups* const regions = &regions_store;
+    Groups* const chains = &chains_store;
     Classify(kEmpty, occ, *regions);
     const int region_count = regions->count;
     std::uint16_t region_heads[kMaxPoints];

@@ -299,14 +299,15 @@ class EngineBase {
 public:
     virtual ~EngineBase() {}
     virtual int load_tensor(int layer, int kind, const float* host, size_t n) = 0;
-    virtual int upload(int n, const float* planes, const int* board_sizes) = 0;
+    // `packed` != null: the inputs are packed records (packed_planes.h) with `binary` bit planes, `planes` is ignored
+    virtual int upload(int n, const float* planes, const int* board_sizes, const unsigned* packed = nullptr, int binary = 0) = 0;
     virtual int run() = 0;
     virtual int sync() = 0;
     virtual int download(float* prob, float* pass, float* misc, float* own) = 0;
     virtual int time_runs(int iters, float* ms) = 0;
     virtual int profile_run(sayuri_hip_kernel_stat* rows, int cap) = 0;
     virtual int submit(int n, const float* planes, const int* bsz, float* prob, float* pass, float* misc, float* own,
-                       int* ticket) = 0;
+                       int* ticket, const unsigned* packed = nullptr, int binary = 0) = 0;
     virtual int wait(int ticket) = 0;
     virtual int query(int ticket) = 0;
     virtual int mark_kernel(const char* name) = 0;
@@ -376,7 +377,7 @@ public:
     // -------------------------------------------------------------- batch i/o
     // asynchronous: H2D, graph, D2H enqueued on the stream, an event marks the end
     int submit(int n, const float* planes, const int* board_sizes, float* prob, float* pass, float* misc, float* own,
-               int* ticket) override {
+               int* ticket, const unsigned* packed = nullptr, int binary = 0) override {
         // Three streams: uploads, the forward graph, downloads.  The planes of batch k+1 cross PCIe while batch k
         // computes, and the results of batch k while batch k+1 computes; each of the two tickets owns its own device
         // input / geometry / output buffers.
@@ -386,7 +387,7 @@ public:
         if (finalize()) return -1;
         select_slot(t);
         HIP_OK(hipStreamWaitEvent(h2d_stream_, fwd_done_[t], 0));  // the forward that last read this slot's inputs
-        if (enqueue_inputs(n, planes, board_sizes, h2d_stream_)) return -1;
+        if (enqueue_inputs(n, planes, board_sizes, h2d_stream_, packed, binary)) return -1;
         HIP_OK(hipEventRecord(h2d_done_[t], h2d_stream_));
         HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
         if (tick_ev_[t]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t], 0));  // the download that last read this slot's outputs
@@ -418,7 +419,7 @@ public:
         return fail(std::string("hipEventQuery: ") + hipGetErrorString(e));
     }
 
-    int upload(int n, const float* planes, const int* board_sizes) override {
+    int upload(int n, const float* planes, const int* board_sizes, const unsigned* packed = nullptr, int binary = 0) override {
         HIP_OK(hipSetDevice(device_));
         if (finalize()) return -1;
         HIP_OK(hipStreamSynchronize(h2d_stream_));
@@ -426,7 +427,7 @@ public:
         for (hipStream_t cs : compute_)
             if (cs) HIP_OK(hipStreamSynchronize(cs));
         select_slot(0);
-        if (enqueue_inputs(n, planes, board_sizes, stream_)) return -1;
+        if (enqueue_inputs(n, planes, board_sizes, stream_, packed, binary)) return -1;
         HIP_OK(hipStreamSynchronize(stream_));
         have_batch_ = true;
         return 0;
@@ -434,9 +435,12 @@ public:
 
     // geometry + planes H2D on the stream (no sync).  The geometry arrays are staged in a
     // 2-deep pinned ring so a second batch can be enqueued while the first is still copying.
-    int enqueue_inputs(int n, const float* planes, const int* board_sizes, hipStream_t copy_stream) {
+    int enqueue_inputs(int n, const float* planes, const int* board_sizes, hipStream_t copy_stream, const unsigned* packed = nullptr,
+                       int binary = 0) {
         HIP_OK(hipSetDevice(device_));
         if (n <= 0 || n > max_batch_) return fail("batch size out of range");
+        if (packed && (binary <= 0 || binary > desc_.input_channels || desc_.input_channels - binary > 8 || board_ * board_ > 12 * 32))
+            return fail("packed planes: bad binary plane count for this network");
         if (finalize()) return -1;
         prev_bsz_.swap(geom_.bsz);
         geom_.n = n;
@@ -480,6 +484,14 @@ public:
         HIP_OK(hipMemcpyAsync(d_off_, hg, sizeof(int) * (n + 1), hipMemcpyHostToDevice, copy_stream));
         HIP_OK(hipMemcpyAsync(d_bsz_, hg + max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
         HIP_OK(hipMemcpyAsync(d_perm_, hg + 2 * max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
+        IoSlot& io = io_[cur_slot_];
+        io.packed_binary = packed ? binary : 0;
+        if (packed) {
+            const size_t words = (size_t)binary * 12 + 8;
+            if (!io.packed && dev_alloc(&io.packed, (size_t)max_batch_ * (40 * 12 + 8))) return -1;
+            HIP_OK(hipMemcpyAsync(io.packed, packed, sizeof(unsigned) * n * words, hipMemcpyHostToDevice, copy_stream));
+            return 0;
+        }
         HIP_OK(hipMemcpyAsync(d_planes_, planes, sizeof(float) * (size_t)n * desc_.input_channels * board_ * board_,
                               hipMemcpyHostToDevice, copy_stream));
         return 0;
@@ -1177,7 +1189,16 @@ private:
             const double px = geom_.total;
             T* dst = bufs_[in];
             const int cin = d.input_channels, cs = L.cin_s, board = board_;
-            if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
+            const IoSlot& io = io_[cur_slot_];
+            if (io.packed_binary > 0) {
+                const unsigned* rec = io.packed;
+                const int nbin = io.packed_binary, words = nbin * 12 + 8;
+                if (timed("pack_input", 0, (double)geom_.n * words * 4 + px * cs * sizeof(T), [&] {
+                        hipLaunchKernelGGL(pack_bits_kernel<T>, dim3(grid), dim3(256), 0, stream_, rec, words, nbin, dst, g, cin, cs,
+                                           (const int*)d_perm_);
+                    }))
+                    return -1;
+            } else if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
                     hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(256), 0, stream_,
                                        (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_);
                 }))
@@ -1307,6 +1328,8 @@ private:
     // device-side batch i/o, one set per ticket; the d_* members below alias the slot the current forward uses
     struct IoSlot {
         float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;
+        unsigned* packed = nullptr;  // packed records of the batch (allocated on first use)
+        int packed_binary = 0;       // > 0: the slot's current batch came as packed records with this many bit planes
         int *off = nullptr, *bsz = nullptr, *perm = nullptr;
         T* bufs[kNumBufs] = {};
         float *gate = nullptr, *separt = nullptr;
@@ -1434,6 +1457,18 @@ int sayuri_hip_forward(sayuri_hip_ctx* ctx, int n, const float* planes, const in
     return ctx->eng->download(prob, pass, misc, own);
 }
 
+int sayuri_hip_forward_packed(sayuri_hip_ctx* ctx, int n, const unsigned* records, int binary_planes, const int* board_sizes,
+                              float* prob, float* pass, float* misc, float* own) {
+    if (!ctx || !records) return fail("forward_packed: null argument");
+    if (ctx->eng->upload(n, nullptr, board_sizes, records, binary_planes)) return -1;
+    if (ctx->eng->run()) return -1;
+    return ctx->eng->download(prob, pass, misc, own);
+}
+int sayuri_hip_submit_packed(sayuri_hip_ctx* ctx, int n, const unsigned* records, int binary_planes, const int* board_sizes,
+                             float* prob, float* pass, float* misc, float* own, int* ticket) {
+    if (!ctx || !records || !ticket) return fail("submit_packed: null argument");
+    return ctx->eng->submit(n, nullptr, board_sizes, prob, pass, misc, own, ticket, records, binary_planes);
+}
 int sayuri_hip_submit(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes, float* prob,
                       float* pass, float* misc, float* own, int* ticket) {
     if (!ctx || !planes || !prob || !pass || !misc || !own || !ticket) return fail("submit: null argument");

@@ -41,6 +41,38 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
     *(uint4*)(out + ((size_t)n * g.slot_pix + pp) * cs + piece * EPP) = *(uint4*)v;
 }
 
+// The same activations from PACKED planes (csrc/host/packed_planes.h): record of a sample = uint32
+// bits[nbin][12] (bit y*bs+x of a 0/1 plane, the sample's OWN cell order -- no re-padding into the NN grid) followed by 8
+// floats (the value of each broadcast plane).  1.8 KB per sample instead of 62 KB over PCIe and out of HBM.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_bits_kernel(const unsigned* __restrict__ records, int rec_words, int nbin,
+                                                        T* __restrict__ out, BatchGeom g, int cin, int cs,
+                                                        const int* __restrict__ perm) {
+    constexpr int EPP = ElemTraits<T>::kPieceElems;
+    const int ppr = cs / EPP;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, 16-byte piece)
+    if (idx >= (size_t)g.total_pix * ppr) return;
+    const int gi = (int)(idx / ppr), piece = (int)(idx - (size_t)gi * ppr);
+    int lo = 0, hi = g.n_samples;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (g.sample_off[mid] <= gi) lo = mid; else hi = mid;
+    }
+    const int n = lo, pp = gi - g.sample_off[n];
+    const unsigned* rec = records + (size_t)(perm ? perm[n] : n) * rec_words;  // perm: device sample -> caller's slot
+    const int word = pp >> 5, sh = pp & 31;
+    T v[EPP];
+#pragma unroll
+    for (int e = 0; e < EPP; ++e) {
+        const int c = piece * EPP + e;
+        float f = 0.f;
+        if (c < nbin) f = (float)((rec[c * 12 + word] >> sh) & 1u);
+        else if (c < cin) f = __uint_as_float(rec[nbin * 12 + (c - nbin)]);
+        v[e] = from_float<T>(f);
+    }
+    *(uint4*)(out + ((size_t)n * g.slot_pix + pp) * cs + piece * EPP) = *(uint4*)v;
+}
+
 struct FcDev {
     const float* wt;  // transposed [in][out]
     const float* b;   // [out]

@@ -165,7 +165,8 @@ int sayuri_pipe_netbench(void* hp, int threads, double seconds, int board, doubl
 // zero tail), then at offset 722: pass, wdl[3], stm, score, q_err, score_err, offset.
 // mode 0: HipForwardPipe::BatchForward(gpu) after re-padding the inputs here the way
 //         SendQueryAndWait would, outputs un-padded here; mode 1: n concurrent Forward() calls
-//         through the queue (n threads).
+//         through the queue (n threads); mode 2: the same through ForwardPacked() (packed_planes.h), mode 3: odd
+//         requests packed, even ones fp32 (a mixed batch).
 int sayuri_pipe_eval(void* hp, int mode, int gpu, int n, const float* planes, const int* board_sizes,
                      const float* komi, const int* offsets, float* out);
 }
@@ -225,12 +226,31 @@ extern "C" int sayuri_pipe_eval(void* hp, int mode, int gpu, int n, const float*
                 outs[i] = r;
             }
         } else {
+            // modes 2 / 3: every / every other request goes in as packed planes (packed_planes.h); the planes handed in
+            // must be packable (0/1 binary planes, constant scalar planes), as every encoder output is
+            const int nbin = PackedPlanes::BinaryPlanes(C);
+            std::vector<PackedPlanes> packed(mode >= 2 ? n : 0);
+            for (int i = 0; i < static_cast<int>(packed.size()); ++i) {
+                PackedPlanes& pk = packed[i];
+                const int bs = inputs[i].board_size, cells = bs * bs;
+                pk.Clear(nbin);
+                pk.board_size = bs;
+                pk.komi = inputs[i].komi;
+                pk.offset = static_cast<int>(inputs[i].offset);
+                for (int c = 0; c < C; ++c) {
+                    const float* pl = inputs[i].planes.data() + static_cast<size_t>(c) * cells;
+                    if (c >= nbin) { pk.scalars[c - nbin] = pl[0]; continue; }
+                    for (int k = 0; k < cells; ++k)
+                        if (pl[k] != 0.f) pk.Set(c, k);
+                }
+            }
             std::vector<std::thread> th;
             std::vector<std::string> errs(n);
             for (int i = 0; i < n; ++i)
                 th.emplace_back([&, i] {
                     try {
-                        outs[i] = h->pipe->Forward(inputs[i]);
+                        if (mode == 2 || (mode == 3 && (i & 1))) outs[i] = h->pipe->ForwardPacked(packed[i]);
+                        else outs[i] = h->pipe->Forward(inputs[i]);
                     } catch (const std::exception& e) {
                         errs[i] = e.what();
                     }

@@ -197,6 +197,8 @@ void HipForwardPipe::BuildGraphs() {
         };
         for (Staging& s : g->st) {
             s.planes = pinned(static_cast<size_t>(max_batch_) * w.input_channels * B2);
+            s.packed = reinterpret_cast<std::uint32_t*>(pinned(static_cast<size_t>(max_batch_) * PackedPlanes::RecordWords(BinaryPlanes())));
+            s.is_packed.assign(max_batch_, 0);
             s.prob = pinned(static_cast<size_t>(max_batch_) * w.probabilities_channels * B2);
             s.pass = pinned(static_cast<size_t>(max_batch_) * w.pass_probability_outputs);
             s.misc = pinned(static_cast<size_t>(max_batch_) * w.value_misc_outputs);
@@ -228,6 +230,7 @@ void HipForwardPipe::DestroyGraphs() {
     for (auto& g : graphs_) {
         for (Staging& s : g->st) {
             sayuri_hip_host_free(s.planes);
+            sayuri_hip_host_free(s.packed);
             sayuri_hip_host_free(s.prob);
             sayuri_hip_host_free(s.pass);
             sayuri_hip_host_free(s.misc);
@@ -260,10 +263,39 @@ void HipForwardPipe::StageInput(Staging* st, int slot, const InputData& in, bool
                         sizeof(float) * bs);
 }
 
+int HipForwardPipe::BinaryPlanes() const { return PackedPlanes::BinaryPlanes(weights_->input_channels); }
+
+// The packed flavour: the record goes into the pinned packed buffer as it is -- the bits are in the sample's own cell
+// order, the device kernel knows the sample's board size, nothing is re-padded.
+void HipForwardPipe::StagePacked(Staging* st, int slot, const PackedPlanes& in) {
+    if (in.board_size < 2 || in.board_size > board_size_) throw std::runtime_error("PackedPlanes board size does not fit the NN board");
+    if (in.binary_planes != BinaryPlanes()) throw std::runtime_error("PackedPlanes: binary plane count does not match the network");
+    st->bsz[slot] = in.board_size;
+    in.Store(st->packed + static_cast<size_t>(slot) * PackedPlanes::RecordWords(in.binary_planes));
+}
+
+// A packed slot of a batch that also holds fp32 requests: expand it into the fp32 staging (NN grid), pump thread.
+void HipForwardPipe::ExpandPacked(Staging* st, int slot) {
+    const int B = board_size_, bs = st->bsz[slot], C = weights_->input_channels, nbin = BinaryPlanes();
+    const std::uint32_t* rec = st->packed + static_cast<size_t>(slot) * PackedPlanes::RecordWords(nbin);
+    float* dst = st->planes + static_cast<size_t>(slot) * C * B * B;
+    std::memset(dst, 0, sizeof(float) * C * B * B);
+    for (int c = 0; c < C; ++c) {
+        float scalar = 0.f;
+        if (c >= nbin) std::memcpy(&scalar, rec + nbin * PackedPlanes::kWords + (c - nbin), sizeof scalar);
+        for (int y = 0; y < bs; ++y)
+            for (int x = 0; x < bs; ++x) {
+                const int cell = y * bs + x;
+                dst[(static_cast<size_t>(c) * B + y) * B + x] =
+                    c < nbin ? static_cast<float>((rec[c * PackedPlanes::kWords + (cell >> 5)] >> (cell & 31)) & 1u) : scalar;
+            }
+    }
+}
+
 // FillOutputs of the CPU pipe (blas_forward_pipe.cc:565-619 -- the oracle; the CUDA pipe's
 // pass[0] for every offset, cuda_forward_pipe.cc:1074, is a known discrepancy) fused with the
 // un-padding of SendQueryAndWait (batch_forward_pipe.cc:48-68).
-void HipForwardPipe::FillOutput(const Staging* g, int slot, const InputData& in, bool unpad, OutputResult* out) const {
+void HipForwardPipe::FillOutput(const Staging* g, int slot, const Echo& in, bool unpad, OutputResult* out) const {
     DNNWeights& w = *weights_;
     const int B = board_size_, B2 = B * B, bs = in.board_size;
     const bool v1 = w.version <= 2;  // Encoder::GetEncoderVersion, encoder.h:64-77
@@ -306,9 +338,18 @@ void HipForwardPipe::FillOutput(const Staging* g, int slot, const InputData& in,
 
 void HipForwardPipe::SubmitBatch(Graph* g, Staging* s, int n) {
     const auto t0 = std::chrono::steady_clock::now();
+    int npacked = 0;
+    for (int i = 0; i < n; ++i) npacked += s->is_packed[i];
+    if (npacked > 0 && npacked < n)  // a mixed batch travels as fp32 planes
+        for (int i = 0; i < n; ++i)
+            if (s->is_packed[i]) ExpandPacked(s, i);
     std::lock_guard<std::mutex> dev(g->dev_mu);
-    if (sayuri_hip_submit(g->ctx, n, s->planes, s->bsz.data(), s->prob, s->pass, s->misc, s->own, &s->ticket))
+    if (npacked == n) {
+        if (sayuri_hip_submit_packed(g->ctx, n, s->packed, BinaryPlanes(), s->bsz.data(), s->prob, s->pass, s->misc, s->own, &s->ticket))
+            ThrowHip("sayuri_hip_submit_packed");
+    } else if (sayuri_hip_submit(g->ctx, n, s->planes, s->bsz.data(), s->prob, s->pass, s->misc, s->own, &s->ticket)) {
         ThrowHip("sayuri_hip_submit");
+    }
     s->n_inflight = n;
     pump_ns_[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -333,7 +374,7 @@ void HipForwardPipe::FinishBatch(Graph* g, Staging* s, int n) {
             s->fin_pos[i] = count;
             s->fin_list[count++] = i;
         } else {  // asynchronous Submit(): filled and signalled here
-            if (rc == 0) FillOutput(s, i, *r.input, true, r.output);
+            if (rc == 0) FillOutput(s, i, r.echo, true, r.output);
             r.done->store(rc == 0 ? 1 : -1, std::memory_order_release);
             FutexWakeAll(r.done);
         }
@@ -550,9 +591,12 @@ void HipForwardPipe::PumpLoop(Graph* g) {
     }
 }
 
-HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputResult* out, std::atomic<int>* done, bool self_serve, bool fiber) {
+HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData* input, const PackedPlanes* packed, OutputResult* out,
+                                               std::atomic<int>* done, bool self_serve, bool fiber) {
     if (graphs_.empty()) throw std::runtime_error("HipForwardPipe is not constructed");
-    if (input.board_size < 2 || input.board_size > board_size_)
+    const Echo echo = input ? Echo{input->board_size, input->offset, input->komi}
+                            : Echo{packed->board_size, static_cast<PolicyBufferOffset>(packed->offset), packed->komi};
+    if (echo.board_size < 2 || echo.board_size > board_size_)
         throw std::runtime_error("InputData board size does not fit the NN board");
     done->store(0, std::memory_order_relaxed);
     Graph* g = graphs_[next_graph_.fetch_add(1, std::memory_order_relaxed) % graphs_.size()].get();
@@ -566,8 +610,11 @@ HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputRes
             const unsigned r = s.reserved.fetch_add(1, std::memory_order_acq_rel);
             if (!(r & Staging::kClosed) && r < cap) {
                 const int slot = static_cast<int>(r);
-                StageInput(&s, slot, input, false);  // the one copy of the planes, by the calling thread
-                s.reqs[slot] = Request{&input, out, done, self_serve, fiber};
+                // the one copy of the planes, by the calling thread
+                if (input) StageInput(&s, slot, *input, false);
+                else StagePacked(&s, slot, *packed);
+                s.is_packed[slot] = input ? 0 : 1;
+                s.reqs[slot] = Request{echo, out, done, self_serve, fiber};
                 s.ready.fetch_add(1, std::memory_order_release);
                 if (r == 0 || r + 1 >= want) g->cv.notify_one();
                 return Ticket{g, &s, slot};
@@ -581,16 +628,22 @@ HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData& input, OutputRes
 }
 
 void HipForwardPipe::Submit(const InputData& input, OutputResult* out, std::atomic<int>* done) {
-    Reserve(input, out, done, false);
+    Reserve(&input, nullptr, out, done, false);
 }
 
-OutputResult HipForwardPipe::Forward(const InputData& input) {
+OutputResult HipForwardPipe::Forward(const InputData& input) { return ForwardAny(&input, nullptr); }
+
+OutputResult HipForwardPipe::ForwardPacked(const PackedPlanes& input) { return ForwardAny(nullptr, &input); }
+
+OutputResult HipForwardPipe::ForwardAny(const InputData* in, const PackedPlanes* pk) {
     OutputResult out;
     std::atomic<int> done{0};
+    const Echo input = in ? Echo{in->board_size, in->offset, in->komi}
+                          : Echo{pk->board_size, static_cast<PolicyBufferOffset>(pk->offset), pk->komi};
     if (sayuri_fiber::InFiber()) {
         fibers_seen_.store(true, std::memory_order_relaxed);
         // M:N game scheduling (fiber.h): hand the request over and run this thread's other games until the batch is back
-        const Ticket t = Reserve(input, nullptr, &done, false, true);
+        const Ticket t = Reserve(in, pk, nullptr, &done, false, true);
         sayuri_fiber::WaitWhileEqual(&done, 0);
         Staging& s = *t.s;
         const int status = done.load(std::memory_order_acquire);
@@ -599,7 +652,7 @@ OutputResult HipForwardPipe::Forward(const InputData& input) {
         if (status < 0) throw std::runtime_error("HIP forward pipe failed while evaluating a batch");
         return out;
     }
-    const Ticket t = Reserve(input, nullptr, &done, true);
+    const Ticket t = Reserve(in, pk, nullptr, &done, true);
     int st;
     while ((st = done.load(std::memory_order_acquire)) == 0) FutexWait(&done, 0);
     if (st < 0) throw std::runtime_error("HIP forward pipe failed while evaluating a batch");
@@ -640,7 +693,7 @@ std::vector<OutputResult> HipForwardPipe::BatchForward(int gpu, const std::vecto
         if (sayuri_hip_forward(g->ctx, n, s.planes, s.bsz.data(), s.prob, s.pass, s.misc, s.own))
             ThrowHip("sayuri_hip_forward");
     }
-    for (int i = 0; i < n; ++i) FillOutput(&s, i, inputs[i], false, &outs[i]);
+    for (int i = 0; i < n; ++i) FillOutput(&s, i, Echo{inputs[i].board_size, inputs[i].offset, inputs[i].komi}, false, &outs[i]);
     batches_.fetch_add(1, std::memory_order_relaxed);
     evals_.fetch_add(static_cast<size_t>(n), std::memory_order_relaxed);
     return outs;

@@ -26,13 +26,18 @@
 // Built inside the reference tree: the reference's own plugin types (global namespace).
 #include "neural/description.h"
 #include "neural/network_basic.h"
+#include "packed_planes.h"
+using sayuri_host::PackedPlanes;
 #define SAYURI_HOST_BEGIN
 #define SAYURI_HOST_END
+#define SAYURI_EXT_OVERRIDE  // the reference's NetworkForwardPipe has no packed entry points: plain members there
 #else
+#include "packed_planes.h"
 #include "pipe_api.h"
 #include "weights_model.h"
 #define SAYURI_HOST_BEGIN namespace sayuri_host {
 #define SAYURI_HOST_END }
+#define SAYURI_EXT_OVERRIDE override
 #endif
 
 struct sayuri_hip_ctx;
@@ -63,6 +68,13 @@ public:
     bool Valid() const override;
     int GetNumWorkers() const override { return static_cast<int>(graphs_.size()); }
 
+    // The compact-input flavour of Forward (packed_planes.h): same collector, same result
+    // bit for bit, 1.8 KB of bit planes per request through staging and PCIe instead of 62 KB of fp32 planes.  A batch
+    // made of packed requests only goes to the GPU packed (sayuri_hip_submit_packed); in a mixed batch the pump expands
+    // the packed ones into the fp32 staging first.
+    OutputResult ForwardPacked(const PackedPlanes& input) SAYURI_EXT_OVERRIDE;
+    bool AcceptsPacked() const SAYURI_EXT_OVERRIDE { return true; }
+
     // batch_forward_pipe.h:27-28.  `inputs` are already re-padded into the NN grid.
     std::vector<OutputResult> BatchForward(int gpu, const std::vector<InputData>& inputs);
 
@@ -87,8 +99,13 @@ public:
     }
 
 private:
+    struct Echo {  // what FillOutput needs of the request once its planes are staged
+        int board_size;
+        PolicyBufferOffset offset;
+        float komi;
+    };
     struct Request {
-        const InputData* input;
+        Echo echo;
         OutputResult* output;
         std::atomic<int>* done;
         bool self_serve;  // a blocking Forward() caller: woken through the tree, takes its result itself
@@ -101,6 +118,8 @@ private:
     struct Staging {
         static constexpr unsigned kClosed = 1u << 31;
         float* planes{nullptr};
+        std::uint32_t* packed{nullptr};      // packed records of the slots filled through ForwardPacked (pinned)
+        std::vector<std::uint8_t> is_packed;  // per slot: its planes are in `packed`, not in `planes`
         float *prob{nullptr}, *pass{nullptr}, *misc{nullptr}, *own{nullptr};
         std::vector<int> bsz;
         std::vector<Request> reqs;
@@ -140,7 +159,11 @@ private:
     };
 
     struct Ticket { Graph* g; Staging* s; int slot; };
-    Ticket Reserve(const InputData& input, OutputResult* out, std::atomic<int>* done, bool self_serve, bool fiber = false);
+    // exactly one of input / packed is non-null
+    Ticket Reserve(const InputData* input, const PackedPlanes* packed, OutputResult* out, std::atomic<int>* done, bool self_serve,
+                   bool fiber = false);
+    OutputResult ForwardAny(const InputData* input, const PackedPlanes* packed);
+    int BinaryPlanes() const;
     void Reopen(Graph* g, Staging* s);
     void BuildGraphs();
     void DestroyGraphs();
@@ -148,7 +171,9 @@ private:
     void SubmitBatch(Graph* g, Staging* s, int n);
     void FinishBatch(Graph* g, Staging* s, int n);
     void StageInput(Staging* s, int slot, const InputData& in, bool already_padded);
-    void FillOutput(const Staging* s, int slot, const InputData& in, bool unpad, OutputResult* out) const;
+    void StagePacked(Staging* s, int slot, const PackedPlanes& in);
+    void ExpandPacked(Staging* s, int slot);
+    void FillOutput(const Staging* s, int slot, const Echo& in, bool unpad, OutputResult* out) const;
 
     HipPipeConfig cfg_;
     int board_size_{0};

@@ -9,7 +9,10 @@
 
 #include <array>
 #include <memory>
+#include <stdexcept>
 #include <string>
+
+#include "packed_planes.h"
 
 #ifndef MAX_BOARD_SIZE
 #define MAX_BOARD_SIZE (19)  // reference src/game/types.h:5-7
@@ -90,6 +93,10 @@ public:
     virtual void Destroy() = 0;
     virtual bool Valid() const = 0;
     virtual int GetNumWorkers() const { return 0; }
+    // Extension over network_basic.h:132-161: a pipe that takes the compact planes of
+    // packed_planes.h says so, and the engine's encoder then never materialises the 43 fp32 planes.
+    virtual bool AcceptsPacked() const { return false; }
+    virtual OutputResult ForwardPacked(const PackedPlanes&) { throw std::runtime_error("this pipe does not take packed planes"); }
     std::string GetName() const;
     int GetVersion() const;
     std::shared_ptr<DNNWeights> weights_{nullptr};

@@ -45,6 +45,8 @@ class GoApi:
         self.info = fn("info", None, vp, vp)
         self.scalars = fn("scalars", None, vp, vp)
         self.planes = fn("planes", ci, vp, ci, ci, vp)
+        # product engine only (the reference tap has no compact encoder)
+        self.planes_packed = fn("planes_packed", ci, vp, ci, ci, vp) if hasattr(lib, prefix + "planes_packed") else None
         self.maps = fn("maps", None, vp, vp)
         self.set_helper = fn("set_territory_helper_from_ownership", None, vp)
 
@@ -118,8 +120,50 @@ class Game:
         self._a.maps(self._h, out.ctypes.data)
         return out
 
+    def planes_packed(self, symmetry: int = 0, weights_version: int = 4):
+        """The compact encoder (csrc/host/packed_planes.h): (record uint32[binary*12 + 8], binary plane count)."""
+        rec = np.zeros(40 * 12 + 8, np.uint32)
+        binary = self._a.planes_packed(self._h, symmetry, weights_version, rec.ctypes.data)
+        return rec[:binary * 12 + 8].copy(), binary
+
     def planes(self, symmetry: int = 0, weights_version: int = 4) -> np.ndarray:
         channels = 38 if weights_version in (1, 2) else 43
         out = np.zeros((channels, self.n), np.float32)
         self._a.planes(self._h, symmetry, weights_version, out.ctypes.data)
         return out
+
+
+PACKED_WORDS = 12    # uint32 words per bit plane (19 x 19 cells)
+PACKED_SCALARS = 8   # float slots behind the bit planes
+
+
+def expand_packed(record: np.ndarray, binary: int, board_size: int, channels: int = 43) -> np.ndarray:
+    """fp32 planes [channels][board_size^2] of a packed record (PackedPlanes::Expand, csrc/host/packed_planes.h)."""
+    n = board_size * board_size
+    rec = np.ascontiguousarray(record, np.uint32)
+    bits = rec[:binary * PACKED_WORDS].reshape(binary, PACKED_WORDS)
+    scal = rec[binary * PACKED_WORDS:binary * PACKED_WORDS + PACKED_SCALARS].view(np.float32)
+    idx = np.arange(n)
+    out = np.empty((channels, n), np.float32)
+    out[:binary] = (bits[:, idx >> 5] >> (idx & 31).astype(np.uint32)) & 1
+    for c in range(binary, channels):
+        out[c] = scal[c - binary]
+    return out
+
+
+def pack_planes(planes: np.ndarray, binary: int = 37) -> np.ndarray:
+    """Packed record of fp32 planes [channels][n] whose first `binary` planes are 0/1 and whose other planes are
+    constant over the board (the shape of every encoder output and of the synthetic bench planes)."""
+    planes = np.asarray(planes, np.float32)
+    channels, n = planes.shape
+    head = planes[:binary]
+    if not np.all((head == 0) | (head == 1)) or not np.all(planes[binary:] == planes[binary:, :1]):
+        raise ValueError("planes are not packable (binary planes must be 0/1, the others constant)")
+    rec = np.zeros(binary * PACKED_WORDS + PACKED_SCALARS, np.uint32)
+    bits = rec[:binary * PACKED_WORDS].reshape(binary, PACKED_WORDS)
+    idx = np.arange(n)
+    for c in range(binary):
+        on = idx[head[c] != 0]
+        np.bitwise_or.at(bits[c], on >> 5, (np.uint32(1) << (on & 31).astype(np.uint32)))
+    rec[binary * PACKED_WORDS:binary * PACKED_WORDS + channels - binary] = planes[binary:, 0].view(np.uint32)
+    return rec

@@ -150,6 +150,12 @@ class HipForwardPipe:
         """n concurrent blocking Forward() calls through the batching queue."""
         return self._eval(1, planes, board_sizes, komi, offsets)
 
+    def ForwardPacked(self, planes, board_sizes, komi=None, offsets=None, mixed: bool = False):
+        """The same through ForwardPacked() (csrc/host/packed_planes.h): the planes are packed into bit planes + scalars on
+        the way in (they must be packable: 0/1 binary planes, constant scalar planes).  mixed: odd requests packed, even
+        ones fp32, so that batches hold both kinds."""
+        return self._eval(3 if mixed else 2, planes, board_sizes, komi, offsets)
+
 
 def hip_forward_raw(ctx: int, planes_grid: np.ndarray, board_sizes, board: int, prob_ch: int = 5, pass_outs: int = 5,
                     misc_outs: int = 15):
@@ -163,5 +169,24 @@ def hip_forward_raw(ctx: int, planes_grid: np.ndarray, board_sizes, board: int, 
     misc = np.zeros((n, misc_outs), np.float32)
     own = np.zeros((n, board * board), np.float32)
     if lib.sayuri_hip_forward(ctx, n, _fp(planes_grid), _ip(bsz), _fp(prob), _fp(pas), _fp(misc), _fp(own)):
+        raise RuntimeError(lib.sayuri_hip_last_error().decode())
+    return prob, pas, misc, own
+
+
+def hip_forward_packed_raw(ctx: int, records: np.ndarray, binary: int, board_sizes, board: int, prob_ch: int = 5, pass_outs: int = 5,
+                           misc_outs: int = 15):
+    """sayuri_hip_forward_packed on packed records [n][binary*12 + 8] (uint32) -> prob, pass, misc, own."""
+    lib = _lib.hip()
+    lib.sayuri_hip_forward_packed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, _lib.c_int_p, _lib.c_float_p,
+                                              _lib.c_float_p, _lib.c_float_p, _lib.c_float_p]
+    records = np.ascontiguousarray(records, np.uint32)
+    n = records.shape[0]
+    assert records.shape[1] == binary * 12 + 8
+    bsz = np.asarray(board_sizes, np.int32)
+    prob = np.zeros((n, prob_ch, board * board), np.float32)
+    pas = np.zeros((n, pass_outs), np.float32)
+    misc = np.zeros((n, misc_outs), np.float32)
+    own = np.zeros((n, board * board), np.float32)
+    if lib.sayuri_hip_forward_packed(ctx, n, records.ctypes.data, binary, _ip(bsz), _fp(prob), _fp(pas), _fp(misc), _fp(own)):
         raise RuntimeError(lib.sayuri_hip_last_error().decode())
     return prob, pas, misc, own

@@ -19,6 +19,7 @@
 struct job {
     int n, state; /* 0 free, 1 queued, 2 done */
     const float* planes;
+    float* owned; /* planes expanded from packed records (freed when the job is done) */
     const int* bsz;
     float *prob, *pass, *misc, *own;
     struct timespec due;
@@ -52,6 +53,26 @@ static void fake_eval(const sayuri_hip_ctx* c, int n, const float* planes, const
     }
 }
 
+/* packed records (csrc/host/packed_planes.h) -> NN-grid fp32 planes, what the device kernel pack_bits_kernel does */
+static float* expand_records(const sayuri_hip_ctx* c, int n, const unsigned* rec, int binary, const int* bsz) {
+    const int B = c->board, B2 = B * B, C = c->desc.input_channels, words = binary * 12 + 8;
+    float* out = (float*)calloc((size_t)n * C * B2, sizeof(float));
+    for (int i = 0; i < n; ++i) {
+        const unsigned* r = rec + (size_t)i * words;
+        const int bs = bsz ? bsz[i] : B;
+        for (int ch = 0; ch < C; ++ch)
+            for (int y = 0; y < bs; ++y)
+                for (int x = 0; x < bs; ++x) {
+                    const int cell = y * bs + x;
+                    float v;
+                    if (ch < binary) v = (float)((r[ch * 12 + (cell >> 5)] >> (cell & 31)) & 1u);
+                    else memcpy(&v, &r[binary * 12 + (ch - binary)], sizeof v);
+                    out[((size_t)i * C + ch) * B2 + y * B + x] = v;
+                }
+    }
+    return out;
+}
+
 static void* worker_main(void* arg) {
     sayuri_hip_ctx* c = (sayuri_hip_ctx*)arg;
     pthread_mutex_lock(&c->mu);
@@ -64,6 +85,8 @@ static void* worker_main(void* arg) {
         pthread_mutex_unlock(&c->mu);
         clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &due, NULL);
         fake_eval(c, j->n, j->planes, j->bsz, j->prob, j->pass, j->misc, j->own);
+        free(j->owned);
+        j->owned = NULL;
         pthread_mutex_lock(&c->mu);
         j->state = 2;
         c->order[0] = c->order[1];
@@ -117,7 +140,29 @@ int sayuri_hip_forward(sayuri_hip_ctx* c, int n, const float* planes, const int*
     fake_eval(c, n, planes, bsz, prob, pass, misc, own);
     return 0;
 }
+static int submit_any(sayuri_hip_ctx* c, int n, const float* planes, float* owned, const int* bsz, float* prob, float* pass,
+                      float* misc, float* own, int* ticket);
 int sayuri_hip_submit(sayuri_hip_ctx* c, int n, const float* planes, const int* bsz, float* prob, float* pass,
+                      float* misc, float* own, int* ticket) {
+    return submit_any(c, n, planes, NULL, bsz, prob, pass, misc, own, ticket);
+}
+int sayuri_hip_forward_packed(sayuri_hip_ctx* c, int n, const unsigned* records, int binary, const int* bsz, float* prob,
+                              float* pass, float* misc, float* own) {
+    if (!c || !records || n <= 0 || n > c->max_batch) return -1;
+    float* x = expand_records(c, n, records, binary, bsz);
+    fake_eval(c, n, x, bsz, prob, pass, misc, own);
+    free(x);
+    return 0;
+}
+int sayuri_hip_submit_packed(sayuri_hip_ctx* c, int n, const unsigned* records, int binary, const int* bsz, float* prob,
+                             float* pass, float* misc, float* own, int* ticket) {
+    if (!c || !records || n <= 0 || n > c->max_batch) return -1;
+    float* x = expand_records(c, n, records, binary, bsz);
+    const int rc = submit_any(c, n, x, x, bsz, prob, pass, misc, own, ticket);
+    if (rc) free(x);
+    return rc;
+}
+static int submit_any(sayuri_hip_ctx* c, int n, const float* planes, float* owned, const int* bsz, float* prob, float* pass,
                       float* misc, float* own, int* ticket) {
     if (!c || n <= 0 || n > c->max_batch) return -1;
     pthread_mutex_lock(&c->mu);
@@ -125,7 +170,7 @@ int sayuri_hip_submit(sayuri_hip_ctx* c, int n, const float* planes, const int* 
     struct job* j = &c->jobs[t];
     if (j->state != 0) { pthread_mutex_unlock(&c->mu); return -1; } /* more than two batches in flight */
     c->next ^= 1;
-    j->n = n; j->planes = planes; j->bsz = bsz; j->prob = prob; j->pass = pass; j->misc = misc; j->own = own;
+    j->n = n; j->planes = planes; j->owned = owned; j->bsz = bsz; j->prob = prob; j->pass = pass; j->misc = misc; j->own = own;
     clock_gettime(CLOCK_MONOTONIC, &j->due);
     j->due.tv_nsec += (c->delay_us % 1000000) * 1000;
     j->due.tv_sec += c->delay_us / 1000000 + j->due.tv_nsec / 1000000000;

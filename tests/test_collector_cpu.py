@@ -63,6 +63,24 @@ DRIVER = textwrap.dedent(r"""
         if n <= 16:
             check(pipe.BatchForward(planes, bsz, offsets=offs), cases, f"batch round {rnd}")
         total += n
+    # packed planes (bit planes + scalars, csrc/host/packed_planes.h): all-packed batches go to the device packed, mixed
+    # batches are expanded by the pump; the replies must be those of the fp32 route
+    def make_packable(n):
+        cases = []
+        for _ in range(n):
+            bs = int(rng.choice([19, 19, 13, 9, 7]))
+            p = np.zeros((C, bs * bs), np.float32)
+            p[:C - 6] = rng.integers(0, 2, size=(C - 6, bs * bs))
+            p[C - 6:] = rng.normal(size=(6, 1)).astype(np.float32)
+            cases.append((p, bs, int(rng.integers(0, 5))))
+        return cases
+    for n in (1, 16, 37, 120):
+        cases = make_packable(n)
+        planes, bsz, offs = [c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases]
+        check(pipe.ForwardPacked(planes, bsz, offsets=offs), cases, f"packed n={n}")
+        check(pipe.ForwardPacked(planes, bsz, offsets=offs, mixed=True), cases, f"mixed n={n}")
+        check(pipe.Forward(planes, bsz, offsets=offs), cases, f"fp32 of packable n={n}")
+        total += 3 * n
     # two Python threads driving the queue at once (each call spawns its own callers), plus the async Submit path
     errs = []
     def worker(seed):

@@ -15,7 +15,7 @@ import pytest
 
 from go_replay import GAME_CONFIGS, RNG_SEEDS, choose_move, digest
 from sayuri_amd import _lib
-from sayuri_amd.engine import INFO_NAMES, MAP_NAMES, Game, GoApi
+from sayuri_amd.engine import INFO_NAMES, MAP_NAMES, Game, GoApi, expand_packed
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden", "go_games.npz")
@@ -44,6 +44,11 @@ def test_golden_replay(golden, gi):
         assert np.array_equal(sc, scalars[step]), f"game {gi} step {step}: scalars {sc} vs {scalars[step]}"
         assert digest(maps) == digests[step][:20].tobytes(), f"game {gi} step {step}: analysis maps differ"
         assert digest(planes) == digests[step][20:].tobytes(), f"game {gi} step {step}: input planes differ"
+        # the compact encoder (bit planes + broadcast scalars) expands to the same 43 / 38 planes, bit for bit
+        rec, binary = g.planes_packed(int(symms[step]), cfg["version"])
+        assert binary == (34 if cfg["version"] in (1, 2) else 37)
+        expanded = expand_packed(rec, binary, cfg["board"], planes.shape[0])
+        assert np.array_equal(expanded.view(np.uint32), planes.view(np.uint32)), f"game {gi} step {step}: packed planes differ"
         if step < len(moves):
             op, move = int(moves[step][0]), int(moves[step][1])
             if op == 0:

@@ -225,6 +225,54 @@ def test_heads_fused_kernel_matches_the_separate_head_kernels(name, tmp_weights_
         assert any(np.abs(outs["1"][i] - outs["0"][i]).max() > 0 for i in range(len(bsz))), "the switch did not change the path"
 
 
+@pytest.mark.parametrize("name,fp16", [("net_20b256", True), ("tiny_res", False), ("tiny_all", True)])
+def test_packed_planes_give_identical_outputs(name, fp16, tmp_weights_dir):
+    """the planes as bit planes + broadcast scalars (csrc/host/packed_planes.h, 1.8 KB instead of 62 KB per
+    sample) expanded by pack_bits_kernel give the network the same activations as the fp32 planes through pack_input_kernel:
+    the raw outputs of sayuri_hip_forward_packed and sayuri_hip_forward are bit-identical (mixed board sizes, caller order),
+    and so are ForwardPacked / Forward through the queue, all-packed and mixed batches."""
+    from sayuri_amd.engine import pack_planes
+    from sayuri_amd.pipe import hip_forward_packed_raw, hip_forward_raw
+    g = Golden(name, tmp_weights_dir)
+    bsz = [19, 9, 13, 19, 7, 19, 13, 19, 19, 9, 19]
+    planes = W.synthetic_planes(len(bsz), bsz, seed=31337)
+    for p in planes:  # rule and wave planes away from 0 too
+        p[37] = 1.0
+        p[38] = 0.25
+    B = 19
+    grid = np.zeros((len(bsz), 43, B * B), np.float32)
+    for i, (p, bs) in enumerate(zip(planes, bsz)):
+        grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+    records = np.stack([pack_planes(p, 37) for p in planes])
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=16, fp16=fp16)
+    try:
+        ctx = pipe.ctx(0)
+        a = hip_forward_raw(ctx, grid, bsz, B)
+        b = hip_forward_packed_raw(ctx, records, 37, bsz, B)
+        for x, y, what in zip(a, b, ("prob", "pass", "misc", "own")):
+            assert np.array_equal(x, y), what
+        assert np.abs(a[0]).max() > 0
+        # through the queue the batches form as the callers arrive; a full-size board's result does not depend on its
+        # batch mates, so those compare exactly, the small boards (which may or may not share a tile) within the gate
+        q_fp32 = pipe.Forward(planes, bsz)
+        q_pack = pipe.ForwardPacked(planes, bsz)
+        q_mix = pipe.ForwardPacked(planes, bsz, mixed=True)
+        oracle = PortNet(g.weights_path)
+        tol = fp16_tol if fp16 else (lambda e: FP32_ATOL)
+        for i, bs in enumerate(bsz):
+            if bs == B:
+                assert np.array_equal(q_fp32[i], q_pack[i]), i
+                assert np.array_equal(q_fp32[i], q_mix[i]), i
+            else:
+                exp = oracle.forward(planes[i], bs)
+                for q in (q_fp32, q_pack, q_mix):
+                    assert np.abs(q[i] - exp).max() <= tol(exp), i
+        exp = oracle.forward(planes[0], bsz[0])
+        assert np.abs(q_pack[0] - exp).max() <= tol(exp)
+    finally:
+        pipe.Destroy()
+
+
 @pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
 def test_40b384_golden_parity(fp16, tmp_weights_dir):
     """BASELINE.json configs[4] network (40 blocks x 384 filters) on 19 / 13 / 9 boards against the reference's own
