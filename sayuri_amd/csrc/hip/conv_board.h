@@ -218,6 +218,20 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint3
                  : "memory");
 }
 
+// 16 bytes per lane from sbase + voff(l) into registers, as an asm statement: no compiler-inserted s_waitcnt follows it --
+// the caller waits (s_waitcnt vmcnt) before it reads dst.
+__device__ __forceinline__ void gload16_s(f16x8& dst, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
+// s_waitcnt vmcnt(N) that the ND asm-loaded registers depend on (the compiler may not read them before it)
+template <int N, int ND, int NA> __device__ __forceinline__ void wait_vm_regs(f16x8 (&r)[NA]) {
+    static_assert(ND == 0 || ND == 2 || ND == 4, "0, 2 or 4 register pieces");
+    if constexpr (ND == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+    else if constexpr (ND == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // The main loop: returns with the accumulators (bias included) of this wave's (WMT x 12) output tiles.
 // `full` = the wave's 12th column tile is in use (else its MFMAs are skipped; other unused tiles are computed on
 // whatever the padded pixel slots point at and never stored).
@@ -433,6 +447,13 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
         f16x8 rrd[ND > 0 ? ND : 1];
         const bool with_res = gres != nullptr;
         const uint32_t my_lds = (uint32_t)(uintptr_t)smem + wave * kWaveLds;
+        // Column tiles [0, JH) are finished while the residual rows of [JH, nj) are still on their way.  Issue order: the LDS
+        // pieces of the first half, the LDS pieces of the second half, last the pieces that go to registers (they belong to
+        // the first tiles of the second half).  Only loads are outstanding at the first wait and they retire in issue
+        // order, so "at most `late` outstanding" = the first half has landed; that wait touches no register (a wait that
+        // names the asm-loaded registers inside a branch makes hipcc copy them BEFORE it); the second wait is vmcnt(0).
+        constexpr int JH = NJ / 2, NRT = ND / NPAIR;  // register tiles: [JH, JH + NRT)
+        auto lds_slot = [](int j, int pr) { return (j < JH ? j : j - NRT) * NPAIR + pr; };
         if (with_res) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave is done with the rings
@@ -441,29 +462,39 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
             auto roff = [&](int j, int pr) -> uint32_t {  // byte offset of this lane's 8 residual channels
                 return (orow[j] >= 0 && cb[pr] < p.cout_s) ? ((uint32_t)orow[j] * (uint32_t)p.cout_s + (uint32_t)cb[pr]) * 2u : 0u;
             };
+            static_for<NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j < JH || j >= JH + NRT) {
+                    if (j < nj) {
 #pragma unroll
-            for (int k = 0; k < ND; ++k) rrd[k] = *(const f16x8*)((const unsigned char*)gres + roff(k / NPAIR, k % NPAIR));
-            static_for<kPieces - ND>([&](auto kc) {
-                constexpr int k = decltype(kc)::value + ND;
-                if (k / NPAIR < nj) glds16_s(roff(k / NPAIR, k % NPAIR), gres, my_lds + (k - ND) * 1024);
+                        for (int pr = 0; pr < NPAIR; ++pr) glds16_s(roff(j, pr), gres, my_lds + lds_slot(j, pr) * 1024);
+                    }
+                }
             });
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // one wait: every residual piece of this wave has landed
+#pragma unroll
+            for (int k = 0; k < ND; ++k) gload16_s(rrd[k], roff(JH + k / NPAIR, k % NPAIR), gres);
+            // loads younger than the first half: the register pieces (always issued) + the issued LDS pieces of the second half
+            const int late = ND + (nj > JH + NRT ? nj - (JH + NRT) : 0) * NPAIR;
+            static_for<(NJ - JH - NRT) + 1>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if (late == ND + t * NPAIR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND + t * NPAIR) : "memory");
+            });
         } else {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) orow[j] = j < nj ? pix[j * 16].y : -1;
         }
         static_for<NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
+            if constexpr (j == JH) {
+                if (with_res) wait_vm_regs<0, ND>(rrd);  // the second half's rows (and the first half's stores)
+            }
             if (j < nj) {  // wave-uniform
 #pragma unroll
                 for (int pr = 0; pr < NPAIR; ++pr) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
-                    const int k = j * NPAIR + pr;
                     f16x8 rr = {0, 0, 0, 0, 0, 0, 0, 0};
                     if (with_res) {
-                        if (k < ND) rr = rrd[k < ND ? k : 0];
-                        else rr = *(const f16x8*)(smem + wave * kWaveLds + (k - ND) * 1024 + lane * 16);
+                        if constexpr (j >= JH && j < JH + NRT) rr = rrd[(j - JH) * NPAIR + pr];
+                        else rr = *(const f16x8*)(smem + wave * kWaveLds + lds_slot(j, pr) * 1024 + lane * 16);
                     }
                     const bool ok = orow[j] >= 0 && cb[pr] < p.cout_s;
                     board_store_pair<ACT>(acc[2 * pr][j], acc[2 * pr + 1][j], with_res, rr,
