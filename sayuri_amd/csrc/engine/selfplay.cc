@@ -458,6 +458,12 @@ int UsableCores(int affinity_cpus) {
         }
         apply(quota, period);
     }
+    // one process per GPU on a node (torch.distributed.run / torchrun export LOCAL_WORLD_SIZE): the quota -- or the
+    // machine -- is shared by that many engines
+    if (const char* lw = std::getenv("LOCAL_WORLD_SIZE")) {
+        const int n = std::atoi(lw);
+        if (n > 1) cores = std::max(1, cores / n);
+    }
     return cores;
 }
 } // namespace
