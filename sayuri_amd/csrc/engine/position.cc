@@ -743,7 +743,33 @@ void Position::InnerRegions(int v, int c, const Groups& regions, bool* inner) co
 }
 
 bool Position::RegionPassDead(int v, int c, const std::uint8_t* feat, const Groups& regions) const {
-    // `c` tries to live inside this region; it needs two separate potential eyes
+    // `c` tries to live inside this region; it needs two separate potential eyes.
+    // Shortcut (same answer): an enclosed group only ever turns a diagonal neighbour into a friendly one, so a point that is
+    // an eye without that knowledge is an eye with it; three such points settle the question (the adjacency rule below
+    // only concerns exactly two) and the enclosed groups -- a classification of the whole board per region -- are not needed.
+    // Open regions of ordinary positions leave here after a handful of points.
+    {
+        int quick = 0;
+        int p = v;
+        do {
+            bool eye = cell_[p] != c;
+            if (eye) {
+                for (int k = 0; k < 4 && eye; ++k)
+                    if (feat[p + dir_[k]] == Opp(c)) eye = false;
+            }
+            if (eye) {
+                int wall = 0, opp = 0;
+                for (int k = 4; k < 8; ++k) {
+                    const int f = feat[p + dir_[k]];
+                    wall += f == kWall;
+                    opp += f == Opp(c);
+                }
+                if (wall == 0 ? opp > 1 : opp > 0) eye = false;
+            }
+            if (eye && ++quick >= 3) return false;
+            p = regions.next[p];
+        } while (p != v);
+    }
     bool inner[kMaxVertices];
     InnerRegions(v, c, regions, inner);
     int eyes[kMaxPoints], ne = 0;
