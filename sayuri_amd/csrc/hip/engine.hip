@@ -263,8 +263,10 @@ static const BoardEntry* pick_board(const BoardPlan& bp, int ko_pad, int* kot_ti
     // ties go to the larger tile (the halo is staged once per workgroup)
     const BoardEntry* best = nullptr;
     long best_cost = 0;
+    static const char* force = getenv("SAYURI_BOARD_KOT");  // experiments: only this channel tile
     for (const auto& e : kBoardEntries) {
         if (ko_pad % e.kot != 0 || e.lds(bp.npos) > kMaxLds) continue;
+        if (force && atoi(force) != e.kot) continue;
         const long kts = ko_pad / e.kot, rounds = (bp.ntiles * kts + kNumCU - 1) / kNumCU, cost = rounds * e.kot;
         if (!best || cost < best_cost) { best = &e; best_cost = cost; *kot_tiles = (int)kts; }
     }
