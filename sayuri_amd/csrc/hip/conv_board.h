@@ -42,6 +42,9 @@ struct BoardParams {
     int npos;              // halo positions per tile of this launch (multiple of 64, <= 512)
     int uniform_info;      // >= 0: every tile's tab_cols entry has this value (a uniform batch: one table read less)
     unsigned long long* dbg;  // DBG kernels only: s_memtime timeline [workgroup < 4][wave][8]
+    int arith;                // 1: every tile is ONE sample and all samples have one size (tile = sample): the kernels compute
+                              // the table entries they need (a few VALU ops) instead of waiting for them at the head of the
+                              // prologue and of the epilogue
 };
 
 // Which samples share a tile: consecutive samples OF ONE BOARD SIZE, greedily, while pixels <= 384, halo positions
@@ -280,14 +283,34 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
     // every table read goes out before the halo DMA (whose "memory" clobber keeps them above it): the halo sources are
     // waited for first, the pixel positions and the bias arrive while the DMA is being issued
     int src[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave + 8 * i;
-        src[i] = q < nbinstr ? bp.tab_src[(size_t)tile * npos + (q >> 2) * 64 + lane] : -1;
-    }
     int lp[NJ];
+    if (bp.arith) {
+        // what board_setup_kernel wrote for a one-sample tile, recomputed: position -> (halo row, column), pixel -> position
+        // (x / n as (int)((x + 0.5) * rcp(n)): x < 512, n >= 4 -- the quotient is never within 0.02 of an integer boundary)
+        const int w2 = bs + 2, npix = bs * bs;
+        const float r_w2 = __builtin_amdgcn_rcpf((float)w2), r_bs = __builtin_amdgcn_rcpf((float)bs);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) lp[j] = bp.tab_pix[(size_t)tile * kBoardPT + (col0 + j) * 16 + (lane & 15)].x;
+        for (int i = 0; i < 4; ++i) {
+            const int q = wave + 8 * i, pos = (q >> 2) * 64 + lane;
+            const int r = (int)(((float)pos + 0.5f) * r_w2), xc = pos - r * w2;
+            const bool in = q < nbinstr && r >= 1 && r <= bs && xc >= 1 && xc <= bs;
+            src[i] = in ? tile * p.g.slot_pix + (r - 1) * bs + (xc - 1) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int px = (col0 + j) * 16 + (lane & 15);
+            const int y = (int)(((float)px + 0.5f) * r_bs), x = px - y * bs;
+            lp[j] = px < npix ? (y + 1) * w2 + x + 1 : w2 + 1;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wave + 8 * i;
+            src[i] = q < nbinstr ? bp.tab_src[(size_t)tile * npos + (q >> 2) * 64 + lane] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) lp[j] = bp.tab_pix[(size_t)tile * kBoardPT + (col0 + j) * 16 + (lane & 15)].x;
+    }
     f32x4 b4[WMT];
 #pragma unroll
     for (int i = 0; i < WMT; ++i) b4[i] = *(const f32x4*)(p.bias + kt * KO_T + (wave_m * WMT + i) * 16 + 4 * kg);
@@ -453,12 +476,24 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
         // order, so "at most `late` outstanding" = the first half has landed; that wait touches no register (a wait that
         // names the asm-loaded registers inside a branch makes hipcc copy them BEFORE it); the second wait is vmcnt(0).
         constexpr int JH = NJ / 2, NRT = ND / NPAIR;  // register tiles: [JH, JH + NRT)
+        auto load_orow = [&] {  // output activation row of this lane's pixel in each column tile (-1 = none)
+            if (bp.arith) {
+                const int npix = (bp.uniform_info >> 8) * (bp.uniform_info >> 8);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int pxl = (col0 + j) * 16 + px;
+                    orow[j] = (j < nj && pxl < npix) ? tile * p.g.slot_pix + pxl : -1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) orow[j] = j < nj ? pix[j * 16].y : -1;
+            }
+        };
         auto lds_slot = [](int j, int pr) { return (j < JH ? j : j - NRT) * NPAIR + pr; };
         if (with_res) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave is done with the rings
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) orow[j] = j < nj ? pix[j * 16].y : -1;
+            load_orow();
             auto roff = [&](int j, int pr) -> uint32_t {  // byte offset of this lane's 8 residual channels
                 return (orow[j] >= 0 && cb[pr] < p.cout_s) ? ((uint32_t)orow[j] * (uint32_t)p.cout_s + (uint32_t)cb[pr]) * 2u : 0u;
             };
@@ -471,17 +506,19 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
                     }
                 }
             });
+            // a register piece is only requested when its tile is in use: on a path that never reads the registers the
+            // compiler would hand them out again while the load is still on its way to them
 #pragma unroll
-            for (int k = 0; k < ND; ++k) gload16_s(rrd[k], roff(JH + k / NPAIR, k % NPAIR), gres);
-            // loads younger than the first half: the register pieces (always issued) + the issued LDS pieces of the second half
-            const int late = ND + (nj > JH + NRT ? nj - (JH + NRT) : 0) * NPAIR;
-            static_for<(NJ - JH - NRT) + 1>([&](auto tc) {
+            for (int k = 0; k < ND; ++k)
+                if (JH + k / NPAIR < nj) gload16_s(rrd[k], roff(JH + k / NPAIR, k % NPAIR), gres);
+            // loads younger than the first half = the pieces of the column tiles [JH, nj)
+            const int late = (nj > JH ? nj - JH : 0) * NPAIR;
+            static_for<(NJ - JH) + 1>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                if (late == ND + t * NPAIR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND + t * NPAIR) : "memory");
+                if (late == t * NPAIR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(t * NPAIR) : "memory");
             });
         } else {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) orow[j] = j < nj ? pix[j * 16].y : -1;
+            load_orow();
         }
         static_for<NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -616,7 +653,7 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
     for (int i = 0; i < WMT; ++i) { s4[i] = f32x4{0.f, 0.f, 0.f, 0.f}; m4[i] = f32x4{-5000.f, -5000.f, -5000.f, -5000.f}; }
     // a one-sample tile has its unused pixel slots at the end: only the wave's LAST column tile can hold any, so only
     // that one is masked (the others are summed with packed adds)
-    const bool last_valid = nj > 0 ? pix[(nj - 1) * 16].y >= 0 : false;
+    const bool last_valid = nj <= 0 ? false : sp.b.arith ? (col0 + nj - 1) * 16 + px < bs * bs : pix[(nj - 1) * 16].y >= 0;
     static_for<NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nj) {

@@ -1035,6 +1035,7 @@ private:
         BoardParams& bp = sp.b;
         bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos; bp.dbg = nullptr;
         bp.uniform_info = board_plan_.uniform_info;
+        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && !getenv("SAYURI_NO_ARITH")) ? 1 : 0;
         ConvParams& p = bp.c;
         p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
         p.g = dgeom();
@@ -1065,6 +1066,7 @@ private:
             bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos;
             bp.dbg = nullptr;
             bp.uniform_info = board_plan_.uniform_info;
+        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && !getenv("SAYURI_NO_ARITH")) ? 1 : 0;
             auto fn = be->fn;
             if (be->kot == 256 && getenv("SAYURI_BOARD_DBG") && !strcmp(name, "conv3x3_tower")) {
                 // in-kernel timeline of the SAYURI_BOARD_DBG-th tower convolution of the forward (1 = first)
@@ -1634,6 +1636,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
                 BoardParams bp;
                 bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos; bp.dbg = nullptr;
                 bp.uniform_info = plan.uniform_info;
+                bp.arith = (plan.single && plan.uniform_info >= 0) ? 1 : 0;
                 ConvParams& p = bp.c;
                 p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
                 p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;
