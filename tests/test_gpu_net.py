@@ -273,6 +273,29 @@ def test_packed_planes_give_identical_outputs(name, fp16, tmp_weights_dir):
         pipe.Destroy()
 
 
+def test_computed_table_entries_match_the_tables(tmp_weights_dir, monkeypatch):
+    """Uniform batches of one-sample tiles (BoardParams::arith): the board kernels compute position -> source row and
+    pixel -> position / output row instead of reading the tables board_setup_kernel built.  SAYURI_NO_ARITH=1 reads the
+    tables: bit-identical outputs, on 19x19 (one board per tile) and on 13x13 as the NN board (one board per tile too)."""
+    g = Golden("net_20b256", tmp_weights_dir)
+    for board, n in ((19, 160), (19, 40), (13, 24)):
+        planes = W.synthetic_planes(n, board, seed=99 + board)
+        outs = {}
+        for mode in ("0", "1"):
+            if mode == "1":
+                monkeypatch.setenv("SAYURI_NO_ARITH", "1")
+            else:
+                monkeypatch.delenv("SAYURI_NO_ARITH", raising=False)
+            pipe = HipForwardPipe(g.weights_path, board_size=board, batch_size=n, fp16=True)  # 160: the 256-channel tile, 40: two 128-channel tiles
+            try:
+                outs[mode] = pipe.BatchForward(planes, [board] * n)
+            finally:
+                pipe.Destroy()
+        for a, b in zip(outs["0"], outs["1"]):
+            assert np.array_equal(a, b)
+        assert np.abs(outs["0"][0]).max() > 0
+
+
 @pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
 def test_40b384_golden_parity(fp16, tmp_weights_dir):
     """BASELINE.json configs[4] network (40 blocks x 384 filters) on 19 / 13 / 9 boards against the reference's own
