@@ -1,10 +1,12 @@
 #!/bin/bash
-# A/B of two builds of libsayuri_hip.so on one box (boxes differ by several per cent): old new old new
+# A/B of two builds of libsayuri_hip.so on one box (boxes differ by several per cent): old new old new ...
+# (build the two variants to sayuri_amd/lib/libsayuri_hip_{old,new}.so first)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 for v in old new old new old new; do
 cp sayuri_amd/lib/libsayuri_hip_$v.so sayuri_amd/lib/libsayuri_hip.so
-timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --selfplay-seconds 0 --no-pump > gpurun_out/ab.json 2> gpurun_out/ab.err
+timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --selfplay-seconds 0 --no-pump --profile > gpurun_out/ab.json 2> gpurun_out/ab.err
 python -c "import json;d=json.load(open('gpurun_out/ab.json'));print('$v', 'evals/s', d['value'], 'tower us', d['roofline']['avg_launch_us'], 'frac', d['roofline']['frac'])"
+grep "conv3x3_tower_se" gpurun_out/ab.err
 done
 cp sayuri_amd/lib/libsayuri_hip_new.so sayuri_amd/lib/libsayuri_hip.so
