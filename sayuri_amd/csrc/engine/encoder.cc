@@ -39,7 +39,7 @@ void Encoder::Planes(const GameState& state, int symmetry, int weights_version, 
     float* libs;
     if (version == 1) {
         bool safe[kMaxPoints];
-        b.SafeArea(safe, false);
+        state.SafeAreaCached(safe);
         for (int i = 0; i < n; ++i)
             if (safe[i]) area[i] = 1.f;
         libs = area + n;
@@ -48,7 +48,7 @@ void Encoder::Planes(const GameState& state, int symmetry, int weights_version, 
         if (state.GetScoringRule() != kTerritoryScoring) {
             int owner[kMaxPoints];
             bool safe[kMaxPoints];
-            b.ScoreAndSafeArea(owner, safe);
+            state.ScoreAndSafeAreaCached(owner, safe);
             for (int i = 0; i < n; ++i) {
                 if (safe[i]) {
                     if (owner[i] == me) area[i] = 1.f;
@@ -151,7 +151,7 @@ void Encoder::Packed(const GameState& state, int symmetry, int weights_version, 
     ++plane;
     if (version == 1) {
         bool safe[kMaxPoints];
-        b.SafeArea(safe, false);
+        state.SafeAreaCached(safe);
         for (int i = 0; i < n; ++i)
             if (safe[i]) mask[i] |= bit(plane);
         plane += 1;
@@ -159,7 +159,7 @@ void Encoder::Packed(const GameState& state, int symmetry, int weights_version, 
         if (state.GetScoringRule() != kTerritoryScoring) {
             int owner[kMaxPoints];
             bool safe[kMaxPoints];
-            b.ScoreAndSafeArea(owner, safe);
+            state.ScoreAndSafeAreaCached(owner, safe);
             for (int i = 0; i < n; ++i) {
                 if (safe[i]) {
                     if (owner[i] == me) mask[i] |= bit(plane);

@@ -191,8 +191,46 @@ float GameState::FinalScoreWith(int color, const int* territory_helper) const {
 
 std::vector<bool> GameState::GetStrictSafeArea() const {
     bool buf[kMaxPoints];
-    board_.SafeArea(buf, false);
+    SafeAreaCached(buf);
     return std::vector<bool>(buf, buf + GetNumIntersections());
+}
+
+void GameState::SafeAreaCached(bool* safe) const {
+    const int n = GetNumIntersections();
+    const std::uint64_t key = board_.KoHash();
+    if (area_key_ == key && (area_have_ & 1)) {
+        for (int i = 0; i < n; ++i) safe[i] = (area_safe_[i >> 6] >> (i & 63)) & 1;
+        return;
+    }
+    board_.SafeArea(safe, false);
+    if (area_key_ != key) area_have_ = 0;
+    area_key_ = key;
+    for (auto& w : area_safe_) w = 0;
+    for (int i = 0; i < n; ++i)
+        if (safe[i]) area_safe_[i >> 6] |= std::uint64_t{1} << (i & 63);
+    area_have_ |= 1;
+}
+
+void GameState::ScoreAndSafeAreaCached(int* owner, bool* safe) const {
+    const int n = GetNumIntersections();
+    const std::uint64_t key = board_.KoHash();
+    if (area_key_ == key && (area_have_ & 3) == 3) {
+        for (int i = 0; i < n; ++i) {
+            safe[i] = (area_safe_[i >> 6] >> (i & 63)) & 1;
+            owner[i] = ((area_black_[i >> 6] >> (i & 63)) & 1) ? kBlack : ((area_white_[i >> 6] >> (i & 63)) & 1) ? kWhite : kEmpty;
+        }
+        return;
+    }
+    board_.ScoreAndSafeArea(owner, safe);
+    area_key_ = key;
+    for (int k = 0; k < 6; ++k) area_safe_[k] = area_black_[k] = area_white_[k] = 0;
+    for (int i = 0; i < n; ++i) {
+        const std::uint64_t bit = std::uint64_t{1} << (i & 63);
+        if (safe[i]) area_safe_[i >> 6] |= bit;
+        if (owner[i] == kBlack) area_black_[i >> 6] |= bit;
+        else if (owner[i] == kWhite) area_white_[i >> 6] |= bit;
+    }
+    area_have_ = 3;
 }
 
 std::vector<int> GameState::GetOwnership() const {

@@ -69,6 +69,11 @@ public:
     float GetFinalScore(int color) const { return FinalScoreWith(color, territory_helper_.data()); }
     float GetFinalScore(int color, const std::vector<int>& territory_helper) const { return FinalScoreWith(color, territory_helper.data()); }
     std::vector<bool> GetStrictSafeArea() const;
+    // The pass-alive analysis of the current stones, computed once per position: the encoder and the node expansion of the
+    // same leaf both need it (the reference runs it twice: encoder.cc:206-262 and node.cc:150).  Keyed by the stones-only
+    // Zobrist hash; the results are Position::SafeArea(false) / Position::ScoreAndSafeArea bit for bit.
+    void SafeAreaCached(bool* safe) const;
+    void ScoreAndSafeAreaCached(int* owner, bool* safe) const;
     std::vector<int> GetOwnership() const;    // pass-alive aware Tromp-Taylor owner per intersection
     std::vector<int> GetRawOwnership() const; // plain Tromp-Taylor reach
     void RemoveDeadStrings(const std::vector<int>& dead) { board_.RemoveMarked(dead.data(), static_cast<int>(dead.size())); }
@@ -139,6 +144,10 @@ private:
     int move_number_ = 0;
     std::uint64_t komi_hash_ = 0, scoring_hash_ = 0;
     int winner_ = kUndecided;
+    // cache of the pass-alive analysis (bit sets: 361 cells; owner as two planes black / white)
+    mutable std::uint64_t area_key_ = 0;
+    mutable std::uint8_t area_have_ = 0;  // bit 0: safe, bit 1: owner
+    mutable std::uint64_t area_safe_[6] = {}, area_black_[6] = {}, area_white_[6] = {};
 };
 
 } // namespace sayuri_go

@@ -519,32 +519,42 @@ int Position::ReachGroup(int start, int spread, bool* seen) const {
 }
 
 void Position::ReachArea(int* out) const {
-    // Tromp-Taylor: a point belongs to a colour when it is that colour or reaches only that colour through empties
-    bool reach[2][kMaxVertices];
-    for (int c = 0; c < 2; ++c) {
-        std::memset(reach[c], 0, sizeof(reach[c]));
-        int queue[kMaxVertices], qh = 0, qt = 0;
-        for (int i = 0; i < points_; ++i) {
-            const int v = IndexToVertex(i);
-            if (cell_[v] == c) {
-                reach[c][v] = true;
-                queue[qt++] = v;
-            }
+    // Tromp-Taylor: a point belongs to a colour when it is that colour or reaches only that colour through empties --
+    // i.e. an empty region belongs to the one colour it borders (reference board.cc:1547-1579 does two breadth-first
+    // searches from the stones; one flood fill per empty region gives the same map)
+    bool seen[kMaxVertices];
+    std::memset(seen, 0, sizeof(seen));
+    int stack[kMaxVertices], members[kMaxPoints];
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        const int c = cell_[v];
+        if (c == kBlack || c == kWhite) {
+            out[i] = c;
+            continue;
         }
-        while (qh < qt) {
-            const int v = queue[qh++];
+        if (seen[v]) continue;
+        int sp = 0, nm = 0;
+        unsigned border = 0;
+        stack[sp++] = v;
+        seen[v] = true;
+        while (sp) {
+            const int p = stack[--sp];
+            members[nm++] = p;
             for (int k = 0; k < 4; ++k) {
-                const int a = v + dir_[k];
-                if (!reach[c][a] && cell_[a] == kEmpty) {
-                    reach[c][a] = true;
-                    queue[qt++] = a;
+                const int a = p + dir_[k];
+                const int ca = cell_[a];
+                if (ca == kEmpty) {
+                    if (!seen[a]) {
+                        seen[a] = true;
+                        stack[sp++] = a;
+                    }
+                } else if (ca == kBlack || ca == kWhite) {
+                    border |= 1u << ca;
                 }
             }
         }
-    }
-    for (int i = 0; i < points_; ++i) {
-        const int v = IndexToVertex(i);
-        out[i] = (reach[kBlack][v] && !reach[kWhite][v]) ? kBlack : (reach[kWhite][v] && !reach[kBlack][v]) ? kWhite : kEmpty;
+        const int owner = border == (1u << kBlack) ? kBlack : border == (1u << kWhite) ? kWhite : kEmpty;
+        for (int m = 0; m < nm; ++m) out[VertexToIndex(members[m])] = owner;
     }
 }
 
@@ -843,7 +853,20 @@ void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_p
         }
     }
 
-    Classify(color, occ, *chains);
+    // the chains of `color`: the board's own chain rings (ids = head vertex; which stone is the head and the order of the
+    // ring do not matter below -- Benson's fixpoint is the same whatever order the chains are tested and dropped in)
+    for (int v = 0; v < kMaxVertices; ++v) chains->id[v] = -1;
+    chains->count = 0;
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        if (cell_[v] == color) {
+            chains->id[v] = static_cast<std::int16_t>(head_[v]);
+            chains->next[v] = next_[v];
+            if (head_[v] == v) chains->heads[chains->count++] = static_cast<std::uint16_t>(v);
+        } else {
+            chains->id[v] = 0;
+        }
+    }
     int alive_count = chains->count;
     for (bool changed = true; changed;) {
         changed = false;
@@ -896,7 +919,27 @@ void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_p
         }
     }
     if (mark_pass_dead) {
-        Classify(kEmpty, occ, *regions);
+        bool all_empty = alive_count == 0;
+        for (int i = 0; i < points_ && all_empty; ++i) all_empty = occ[IndexToVertex(i)] == kEmpty;
+        if (all_empty) {
+            // nothing of `color` is pass-alive (the usual case): every chain was dropped and no region stayed vital, occ is
+            // empty all over -- the classification is one region holding every point (members ascending, each linking to
+            // its predecessor, the lowest to the highest, as Classify links them)
+            for (int v = 0; v < kMaxVertices; ++v) regions->id[v] = -1;
+            int prev = -1, first = -1;
+            for (int i = 0; i < points_; ++i) {
+                const int v = IndexToVertex(i);
+                regions->id[v] = 1;
+                if (prev >= 0) regions->next[v] = static_cast<std::uint16_t>(prev);
+                else first = v;
+                prev = v;
+            }
+            regions->next[first] = static_cast<std::uint16_t>(prev);
+            regions->heads[0] = static_cast<std::uint16_t>(first);
+            regions->count = 1;
+        } else {
+            Classify(kEmpty, occ, *regions);
+        }
         for (int r = 0; r < regions->count; ++r) {
             const int h = regions->heads[r];
             if (!RegionPassDead(h, Opp(color), occ, *regions)) continue;
