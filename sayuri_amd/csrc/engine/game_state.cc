@@ -35,8 +35,7 @@ void FrameLog::Freeze() {
 // ---------------------------------------------------------------------------------------------
 void GameState::PushFrame(int vtx, int color) {
     Frame f;
-    const int n = board_.NumPoints();
-    for (int i = 0; i < n; ++i) f.stones[i] = static_cast<std::uint8_t>(board_.At(board_.IndexToVertex(i)));
+    board_.CopyStones(f.stones);
     f.last_move = static_cast<std::int16_t>(board_.LastMove());
     f.move_vertex = static_cast<std::int16_t>(vtx);
     f.move_color = static_cast<std::int8_t>(color);

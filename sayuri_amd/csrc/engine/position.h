@@ -94,6 +94,10 @@ public:
     int ReachGroup(int start, int spread, bool* seen /*[NumVertices]*/) const;  // board.cc:264-300
 
     int ChainMembers(int v, int* out) const; // GetStringList, board.cc:1510-1524
+    // the stones in index order (out[y * size + x] = At(vertex)): one row copy per board row
+    void CopyStones(std::uint8_t* out) const {
+        for (int y = 0; y < size_; ++y) std::memcpy(out + y * size_, cell_ + (y + 1) * letter_ + 1, static_cast<size_t>(size_));
+    }
 
 private:
     // cells
