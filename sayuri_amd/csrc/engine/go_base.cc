@@ -96,4 +96,23 @@ const SymmetryTables& SymmetryTables::Get() {
     return t;
 }
 
+IndexTables::IndexTables() {
+    for (auto& b : i2v)
+        for (auto& v : b) v = 0;
+    for (auto& b : v2i)
+        for (auto& v : b) v = -1;
+    for (int n = kMinBoard; n <= kMaxBoard; ++n)
+        for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x) {
+                const int i = y * n + x, v = (y + 1) * (n + 2) + x + 1;
+                i2v[n][i] = static_cast<std::int16_t>(v);
+                v2i[n][v] = static_cast<std::int16_t>(i);
+            }
+}
+
+const IndexTables& IndexTables::Get() {
+    static const IndexTables t;
+    return t;
+}
+
 } // namespace sayuri_go

@@ -93,4 +93,16 @@ private:
     std::uint16_t vtx_[kMaxBoard + 1][kCount][kMaxVertices];
 };
 
+// ---------------------------------------------------------------------------------------------
+// index (y * size + x) <-> vertex ((y + 1) * (size + 2) + x + 1) per board size: the board analyses walk the board by
+// index and look the vertex up -- a table read instead of a division and a modulo by a run-time size in every loop
+struct IndexTables {
+    static const IndexTables& Get();
+    std::int16_t i2v[kMaxBoard + 1][kMaxPoints];
+    std::int16_t v2i[kMaxBoard + 1][kMaxVertices];  // -1 off the board
+
+private:
+    IndexTables();
+};
+
 } // namespace sayuri_go

@@ -25,6 +25,8 @@ void Position::Reset(int board_size) {
     letter_ = static_cast<std::int16_t>(board_size + 2);
     points_ = static_cast<std::int16_t>(board_size * board_size);
     vertices_ = static_cast<std::int16_t>(letter_ * letter_);
+    i2v_ = IndexTables::Get().i2v[board_size];
+    v2i_ = IndexTables::Get().v2i[board_size];
 
     for (int v = 0; v < kMaxVertices; ++v) {
         cell_[v] = kWall;

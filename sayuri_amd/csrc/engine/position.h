@@ -30,8 +30,8 @@ public:
     int Index(int x, int y) const { return y * size_ + x; }
     int X(int v) const { return v % letter_ - 1; }
     int Y(int v) const { return v / letter_ - 1; }
-    int IndexToVertex(int i) const { return Vertex(i % size_, i / size_); }
-    int VertexToIndex(int v) const { return Index(X(v), Y(v)); }
+    int IndexToVertex(int i) const { return i2v_[i]; }  // tables of this board size (go_base.h IndexTables)
+    int VertexToIndex(int v) const { return v2i_[v]; }
     int IndexToVertexOrPass(int i) const { return i == points_ ? kPassMove : IndexToVertex(i); }
     int VertexToIndexOrPass(int v) const { return v == kPassMove ? points_ : VertexToIndex(v); }
     int Step(int k) const { return dir_[k]; } // 0..3 orthogonal, 4..7 diagonal
@@ -112,6 +112,8 @@ private:
     std::uint16_t stones_[kMaxVertices + 1];
 
     std::uint64_t hash_, ko_hash_;
+    const std::int16_t* i2v_;  // static tables: a Position stays trivially copyable
+    const std::int16_t* v2i_;
     std::int16_t dir_[8];
     std::int16_t size_, letter_, points_, vertices_;
     std::int16_t to_move_, last_move_, last_move2_, ko_move_, passes_;
