@@ -45,15 +45,59 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(LIB, exist_ok=True)
-    srcs = _files(HIP_SRC, (".hip", ".h")) + [os.path.join(ROOT, "include", "sayuri_hip.h")]
-    if force or _newer(HIP_SO, srcs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               os.path.join(HIP_SRC, "engine.hip"), "-o", HIP_SO]
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
+    """The persistent tower kernels (csrc/hip/conv_tower.h): tower.hip -> gfx950 assembly -> tower_seam.py closes the
+    layer loop in it -> code object -> a host object that carries it as the byte array `sayuri_tower_hsaco`."""
+    objdir = os.path.join(LIB, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    blob = os.path.join(objdir, "tower_blob.o")
+    seam = os.path.join(HIP_SRC, "tower_seam.py")
+    srcs = [os.path.join(HIP_SRC, f) for f in ("tower.hip", "conv_tower.h", "conv_board.h", "conv_glds.h", "conv_mfma.h",
+                                               "small_ops.h", "common.h")] + [seam]
+    if not (force or _newer(blob, srcs)):
+        return blob
+    asm, seamed = os.path.join(objdir, "tower.s"), os.path.join(objdir, "tower_seamed.s")
+    elf, hsaco, stub = os.path.join(objdir, "tower_dev.o"), os.path.join(objdir, "tower.hsaco"), os.path.join(objdir, "tower_blob.S")
+    cmds = [
+        [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-w",
+         os.path.join(HIP_SRC, "tower.hip"), "-o", asm],
+        [sys.executable, seam, asm, seamed] + (["--inv"] if os.environ.get("SAYURI_TOWER_INV") else []),
+        [os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", seamed, "-o", elf],
+        [os.path.join(LLVM_BIN, "ld.lld"), "-shared", elf, "-o", hsaco],
+    ]
+    for cmd in cmds:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    with open(stub, "w") as f:
+        f.write('\t.section .rodata\n\t.globl sayuri_tower_hsaco\n\t.type sayuri_tower_hsaco,@object\n\t.balign 4096\n'
+                'sayuri_tower_hsaco:\n\t.incbin "%s"\n\t.size sayuri_tower_hsaco, .-sayuri_tower_hsaco\n'
+                '\t.section .note.GNU-stack,"",@progbits\n' % hsaco)
+    cmd = ["gcc", "-c", stub, "-o", blob]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return blob
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIB, exist_ok=True)
+    srcs = _files(HIP_SRC, (".hip", ".h", ".py")) + [os.path.join(ROOT, "include", "sayuri_hip.h")]
+    if force or _newer(HIP_SO, srcs):
+        blob = build_tower_blob(force, verbose)
+        obj = os.path.join(LIB, "obj", "engine_hip.o")
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-c",
+               os.path.join(HIP_SRC, "engine.hip"), "-o", obj]
+        if os.environ.get("SAYURI_EXPERIMENTS"):  # in-kernel timelines and forced variants (measuring builds only)
+            cmd.insert(1, "-DSAYURI_EXPERIMENTS")
+        link = [_hipcc(), "--offload-arch=gfx950", "-shared", obj, blob, "-o", HIP_SO]
+        for c in (cmd, link):
+            if verbose:
+                print(" ".join(c), file=sys.stderr)
+            subprocess.check_call(c)
     return HIP_SO
 
 

@@ -24,6 +24,7 @@
 #include "conv_mfma.h"
 #include "conv_glds.h"
 #include "conv_board.h"
+#include "conv_tower.h"
 #include "head_board.h"
 #include "small_ops.h"
 
@@ -128,16 +129,46 @@ static void enable_big_lds_glds() {
         if (e.fn_se) (void)hipFuncSetAttribute((const void*)e.fn_se, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     }
 }
-// SAYURI_CONV=v0 | glds[:wnt] | board   (A/B switch for tests and tuning; default: board where it applies, else glds)
+// Switches of one engine, read from the environment ONCE, in sayuri_hip_create (and per call in the layer-level test
+// taps): nothing on the launch path calls getenv.  They select between product paths that give the same results (A/B
+// measurements, tests that check one path against the other).  The measuring-only switches (in-kernel timelines, forced
+// activation / channel tile) exist only in builds with -DSAYURI_EXPERIMENTS.
+//   SAYURI_CONV=v0 | glds[:wnt]   3x3 layers on the generic / the LDS-DMA-tiles-across-samples kernel instead of one workgroup per board
+//   SAYURI_TOWER=0                one launch per convolution instead of one persistent launch per run of board convolutions
+//   SAYURI_SE_FUSED=0             SE unit as se_pool / se_fc / se_scale instead of inside the convolution
+//   SAYURI_HEADS_FUSED=0          conv1x1 x2 + head_tail instead of head_board_kernel
+//   SAYURI_NO_ARITH=1             board kernels read their index tables instead of computing the entries
+//   SAYURI_COMPUTE_STREAMS=2      the two tickets' forwards on two streams
 struct ConvOverride { bool v0 = false, no_board = false; int wnt = 0; };
-static ConvOverride conv_override() {
-    ConvOverride o;
-    const char* e = getenv("SAYURI_CONV");
-    if (!e) return o;
-    if (!strncmp(e, "v0", 2)) { o.v0 = true; o.no_board = true; return o; }
-    if (!strncmp(e, "glds", 4)) { o.no_board = true; (void)sscanf(e, "glds:%d", &o.wnt); }
-    return o;
-}
+struct EngineFlags {
+    ConvOverride conv;
+    bool tower = true, se_fused = true, heads_fused = true, arith = true;
+    int compute_streams = 1;
+    int board_kot = 0;                 // experiments: only this channel tile
+    int act_override = -1;             // experiments: activation of every board convolution
+    int board_dbg = 0, heads_dbg = 0;  // experiments: in-kernel timelines
+    static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
+    static EngineFlags from_env() {
+        EngineFlags f;
+        if (const char* e = getenv("SAYURI_CONV")) {
+            if (!strncmp(e, "v0", 2)) { f.conv.v0 = true; f.conv.no_board = true; }
+            else if (!strncmp(e, "glds", 4)) { f.conv.no_board = true; (void)sscanf(e, "glds:%d", &f.conv.wnt); }
+        }
+        f.tower = !off("SAYURI_TOWER");
+        f.se_fused = !off("SAYURI_SE_FUSED");
+        f.heads_fused = !off("SAYURI_HEADS_FUSED");
+        f.arith = !getenv("SAYURI_NO_ARITH");
+        if (const char* e = getenv("SAYURI_COMPUTE_STREAMS")) f.compute_streams = atoi(e) == 2 ? 2 : 1;
+#ifdef SAYURI_EXPERIMENTS
+        if (const char* e = getenv("SAYURI_BOARD_KOT")) f.board_kot = atoi(e);
+        if (const char* e = getenv("SAYURI_ACT_OVERRIDE")) f.act_override = atoi(e);
+        if (const char* e = getenv("SAYURI_BOARD_DBG")) f.board_dbg = atoi(e);
+        if (getenv("SAYURI_HEADS_DBG")) f.heads_dbg = 1;
+        if (f.board_dbg || f.heads_dbg || f.act_override >= 0) f.tower = false;
+#endif
+        return f;
+    }
+};
 
 // allow > 64 KiB of dynamic LDS on the current device
 template <typename T> static void enable_big_lds() {
@@ -198,9 +229,8 @@ struct HostGeom {
 
 // Choose the tuned LDS-DMA kernel variant for an fp16 3x3 layer with `ko_pad` weight rows on
 // this batch geometry; nullptr when none applies (the generic conv_mfma kernel is used then).
-static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_out) {
+static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_out, const ConvOverride& ov) {
     if (ko_pad % 128 != 0) return nullptr;
-    const ConvOverride ov = conv_override();  // read per geometry change, so a test can switch it between pipes
     if (ov.v0) return nullptr;
     const int wmt = ko_pad % 256 == 0 ? 8 : 4;
     const int kot_tiles = ko_pad / (wmt * 32);
@@ -228,9 +258,8 @@ struct BoardPlan {
     int uniform_info = -1;            // every tile has this (column tiles | board size << 8), or -1
     double fill = 0;
 };
-static BoardPlan board_plan(const HostGeom& geom) {
+static BoardPlan board_plan(const HostGeom& geom, const ConvOverride& ov) {
     BoardPlan bp;
-    const ConvOverride ov = conv_override();
     if (ov.no_board || geom.n <= 0) return bp;
     BoardPack pk;
     int max_pos = 0, info0 = -2;
@@ -257,16 +286,15 @@ static BoardPlan board_plan(const HostGeom& geom) {
     bp.ok = true;
     return bp;
 }
-static const BoardEntry* pick_board(const BoardPlan& bp, int ko_pad, int* kot_tiles) {
+static const BoardEntry* pick_board(const BoardPlan& bp, int ko_pad, int* kot_tiles, int force = 0) {
     if (!bp.ok) return nullptr;
     // the channel tile that needs the fewest rounds of workgroups over the 256 CUs (time of a round ~ its channel count);
     // ties go to the larger tile (the halo is staged once per workgroup)
     const BoardEntry* best = nullptr;
     long best_cost = 0;
-    static const char* force = getenv("SAYURI_BOARD_KOT");  // experiments: only this channel tile
     for (const auto& e : kBoardEntries) {
         if (ko_pad % e.kot != 0 || e.lds(bp.npos) > kMaxLds) continue;
-        if (force && atoi(force) != e.kot) continue;
+        if (force && force != e.kot) continue;
         const long kts = ko_pad / e.kot, rounds = (bp.ntiles * kts + kNumCU - 1) / kNumCU, cost = rounds * e.kot;
         if (!best || cost < best_cost) { best = &e; best_cost = cost; *kot_tiles = (int)kts; }
     }
@@ -317,12 +345,17 @@ public:
     virtual size_t device_bytes() const = 0;
 };
 
+}  // namespace sayuri
+// the code object of the persistent tower kernels (tower.hip -> tower_seam.py -> clang -> ld.lld), linked in as a blob
+extern "C" const unsigned char sayuri_tower_hsaco[];
+namespace sayuri {
+
 template <typename T> class Engine : public EngineBase {
 public:
     struct TileTabs { int* src = nullptr; int2* pix = nullptr; bool fresh = false; };
     struct BoardTabs { int* src = nullptr; int2* pix = nullptr; int* cols = nullptr; int npos_built = 0; bool fresh = false; };
-    Engine(int device, const sayuri_hip_netdesc& d, int max_batch, int board)
-        : device_(device), desc_(d), max_batch_(max_batch), board_(board) {
+    Engine(int device, const sayuri_hip_netdesc& d, int max_batch, int board, const EngineFlags& flags)
+        : flags_(flags), device_(device), desc_(d), max_batch_(max_batch), board_(board) {
         blocks_.assign(d.blocks, d.blocks + d.residual_blocks);
         desc_.blocks = blocks_.data();
     }
@@ -337,8 +370,7 @@ public:
         // 48.0 k vs 54.0 k evals/s through the queue, two graphs evict each other's weights and activations from L2.
         compute_[0] = stream_;
         compute_[1] = stream_;
-        const char* cs_env = getenv("SAYURI_COMPUTE_STREAMS");
-        if (cs_env && atoi(cs_env) == 2) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
+        if (flags_.compute_streams == 2) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
         HIP_OK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
         HIP_OK(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking));
         for (int t = 0; t < 2; ++t) {
@@ -349,6 +381,7 @@ public:
         HIP_OK(hipEventCreate(&ev1_));
         enable_big_lds<T>();
         if (sizeof(T) == 2) enable_big_lds_glds();
+        if (sizeof(T) == 2 && flags_.tower && tower_load()) return -1;
         return describe_layers();
     }
 
@@ -718,10 +751,7 @@ private:
 
     static bool is_tiny_head_conv(int id) { return id == SAYURI_L_PROB_CONV || id == SAYURI_L_V_OWNERSHIP; }
 
-    static bool heads_fused_enabled() {
-        const char* sw = getenv("SAYURI_HEADS_FUSED");  // A/B switch, read per call
-        return !(sw && atoi(sw) == 0);
-    }
+    bool heads_fused_enabled() const { return flags_.heads_fused; }
     // Stacked [policy | value] head-convolution image for head_board_kernel (fp16 engine, normal policy head).
     int build_head_image() {
         const sayuri_hip_netdesc& d = desc_;
@@ -863,6 +893,14 @@ private:
         allocs_.clear();
         if (h_geom_) (void)hipHostFree(h_geom_);
         h_geom_ = nullptr;
+        for (TowerSlot& ts : tower_)
+            for (int i = 0; i < 2; ++i) {
+                if (ts.stage[i]) (void)hipHostFree(ts.stage[i]);
+                if (ts.staged[i]) (void)hipEventDestroy(ts.staged[i]);
+                ts.stage[i] = nullptr; ts.staged[i] = nullptr;
+            }
+        if (tower_mod_) (void)hipModuleUnload(tower_mod_);
+        tower_mod_ = nullptr;
         for (hipEvent_t& e : tick_ev_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
         pool_.clear();
@@ -890,6 +928,7 @@ private:
         return 0;
     }
     template <typename F> int timed(const char* name, double flops, double bytes, F&& launch) {
+        if (!run_.empty() && tower_flush()) return -1;  // the pending run of board convolutions goes first (stream order)
         if (!profiling_) {
             // light mode: un-synchronised event pairs around runs of the dominant kernel class only
             const bool match = light_ && light_name_ == name;
@@ -980,7 +1019,7 @@ private:
         auto it = glds_cache_.find(key);
         if (it == glds_cache_.end()) {
             GldsChoice c{nullptr, 0};
-            c.e = pick_glds(geom_, L.ko_pad, &c.ntiles);
+            c.e = pick_glds(geom_, L.ko_pad, &c.ntiles, flags_.conv);
             it = glds_cache_.emplace(key, c).first;
         }
         return it->second.e ? &it->second : nullptr;
@@ -1008,16 +1047,15 @@ private:
     // the one-workgroup-per-board kernel applies to fp16 3x3 layers whose boards fit a tile and fill it reasonably
     const BoardEntry* choose_board(const ConvLayerDev& L, int* kot_tiles) {
         if (sizeof(T) != 2 || L.k != 3) return nullptr;
-        if (!board_plan_valid_) { board_plan_ = board_plan(geom_); board_plan_valid_ = true; }
+        if (!board_plan_valid_) { board_plan_ = board_plan(geom_, flags_.conv); board_plan_valid_ = true; }
         if (!board_plan_.ok || board_plan_.fill < 0.55) return nullptr;
-        return pick_board(board_plan_, L.ko_pad, kot_tiles);
+        return pick_board(board_plan_, L.ko_pad, kot_tiles, flags_.board_kot);
     }
 
     // A block's last 3x3 convolution with the squeeze-and-excitation unit that follows it inside the kernel
     // (conv_board.h).  Returns 1 when the fused kernel does not apply (the caller then runs conv + se_unit), 0 / -1.
     int conv_se(const ConvLayerDev& L, const FcLayerDev& sq, const FcLayerDev& ex, const T* in, T* out, const T* res, int C, int act) {
-        const char* sw = getenv("SAYURI_SE_FUSED");  // A/B switch, read per call so that a test can flip it between pipes
-        const bool off = sw && atoi(sw) == 0;
+        const bool off = !flags_.se_fused;
         int bkt = 0;
         const BoardEntry* be = nullptr;
         // the variant whose channel tile covers the whole layer, whatever the batch size: a position's result must not
@@ -1035,22 +1073,23 @@ private:
         BoardParams& bp = sp.b;
         bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos; bp.dbg = nullptr;
         bp.uniform_info = board_plan_.uniform_info;
-        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && !getenv("SAYURI_NO_ARITH")) ? 1 : 0;
+        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && flags_.arith) ? 1 : 0;
         ConvParams& p = bp.c;
         p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
         p.g = dgeom();
         p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
         p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = board_plan_.ntiles;
         sp.squeeze = sq.dev(); sp.excite = ex.dev(); sp.C = C;
-        if (const char* dv = getenv("SAYURI_BOARD_DBG")) {  // negative n: timeline of the n-th SE convolution of the forward
-            if (atoi(dv) < 0) {
-                if (!d_dbg_ && dev_alloc(&d_dbg_, 4 * 8 * 8)) return -1;
-                if (++dbg_se_call_ == -atoi(dv)) { bp.dbg = d_dbg_; dbg_is_se_ = true; }
-            }
+#ifdef SAYURI_EXPERIMENTS
+        if (flags_.board_dbg < 0) {  // negative n: timeline of the n-th SE convolution of the forward
+            if (!d_dbg_ && dev_alloc(&d_dbg_, 4 * 8 * 8)) return -1;
+            if (++dbg_se_call_ == -flags_.board_dbg) { bp.dbg = d_dbg_; dbg_is_se_ = true; }
         }
+#endif
         const double px = geom_.total;
         const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out);
         const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
+        if (tower_ok(be->kot) && !bp.dbg) return tower_append(be->kot, sp, true, flops, bytes);
         const auto fn = be->fn_se;
         const size_t lds = be->lds(board_plan_.npos);
         const int grid = board_plan_.ntiles;
@@ -1066,25 +1105,34 @@ private:
             bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos;
             bp.dbg = nullptr;
             bp.uniform_info = board_plan_.uniform_info;
-        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && !getenv("SAYURI_NO_ARITH")) ? 1 : 0;
+        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && flags_.arith) ? 1 : 0;
             auto fn = be->fn;
-            if (be->kot == 256 && getenv("SAYURI_BOARD_DBG") && !strcmp(name, "conv3x3_tower")) {
+#ifdef SAYURI_EXPERIMENTS
+            if (be->kot == 256 && flags_.board_dbg > 0 && !strcmp(name, "conv3x3_tower")) {
                 // in-kernel timeline of the SAYURI_BOARD_DBG-th tower convolution of the forward (1 = first)
                 if (!d_dbg_ && dev_alloc(&d_dbg_, 4 * 8 * 8)) return -1;
-                if (++dbg_call_ == atoi(getenv("SAYURI_BOARD_DBG"))) {
+                if (++dbg_call_ == flags_.board_dbg) {
                     bp.dbg = d_dbg_;
                     fn = &conv_board_kernel<4, true>;
                 }
             }
+#endif
             ConvParams& p = bp.c;
             p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
             p.g = dgeom();
             p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
             p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = board_plan_.ntiles;
-            { static const char* na = getenv("SAYURI_ACT_OVERRIDE"); if (na) p.act = atoi(na); }  // timing experiments only
+#ifdef SAYURI_EXPERIMENTS
+            if (flags_.act_override >= 0) p.act = flags_.act_override;  // timing experiments only
+#endif
             const double px = geom_.total;
             const double flops = 2.0 * px * L.cin * L.cout * 9;
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
+            if (bkt == 1 && tower_ok(be->kot) && !bp.dbg) {
+                BoardSeParams sp{};
+                sp.b = bp;
+                return tower_append(be->kot, sp, false, flops, bytes);
+            }
             const size_t lds = be->lds(board_plan_.npos);
             const int grid = board_plan_.ntiles * bkt;
             return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, bp); });
@@ -1100,7 +1148,6 @@ private:
             p.g = dgeom();
             p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
             p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = gc->ntiles;
-            { static const char* na = getenv("SAYURI_ACT_OVERRIDE"); if (na) p.act = atoi(na); }  // timing experiments only
             gp.zeros = d_zeros_;
             const double px = geom_.total;
             const double flops = 2.0 * px * L.cin * L.cout * 9;
@@ -1184,6 +1231,8 @@ private:
         for (int i = 0; i < kNumBufs; ++i) busy_[i] = false;
         dbg_call_ = 0;
         dbg_se_call_ = 0;
+        run_.clear();
+        table_used_ = 0;
 
         int x = take();
         {
@@ -1286,10 +1335,12 @@ private:
             // FCs and the per-pixel planes (head_board.h)
             HeadBoardParams hp;
             hp.dbg = nullptr;
-            if (getenv("SAYURI_HEADS_DBG")) {
+#ifdef SAYURI_EXPERIMENTS
+            if (flags_.heads_dbg) {
                 if (!d_hdbg_ && dev_alloc(&d_hdbg_, 4 * 8)) return -1;
                 hp.dbg = d_hdbg_;
             }
+#endif
             hp.trunk = bufs_[x]; hp.w = head_img_; hp.w2 = head_img2_; hp.bias = head_bias_; hp.g = g; hp.cs = csC; hp.PT = head_pt_; hp.VT = head_vt_; hp.h = h;
             const auto fn = head_fn_;
             {
@@ -1317,6 +1368,85 @@ private:
             hipLaunchKernelGGL(head_tail_kernel<T>, dim3(2 * geom_.n), dim3(256), smem, stream_, pc, vc, g, h);
         });
     }
+
+    // -------------------------------------------------------------- the persistent tower launch (conv_tower.h)
+    // Consecutive board convolutions whose channel tile covers the layer are not launched one by one: conv() / conv_se()
+    // append them to run_, and the first launch of anything else (timed()) -- in practice the heads -- sends the whole run
+    // as ONE launch that walks a table of TowerLayer in device memory.  The table of a slot is re-uploaded only when its
+    // contents change (another batch geometry; the buffers and weights of a slot never move).
+    static constexpr int kTowerCap = 512;  // table elements per slot
+    struct TowerSlot {
+        TowerLayer* dev = nullptr;
+        TowerLayer* stage[2] = {nullptr, nullptr};  // pinned staging, alternating
+        hipEvent_t staged[2] = {nullptr, nullptr};   // the last copy out of stage[i]
+        int next_stage = 0;
+        std::vector<TowerLayer> cache;               // what dev holds
+    };
+    int tower_load() {
+        HIP_OK(hipModuleLoadData(&tower_mod_, sayuri_tower_hsaco));
+        HIP_OK(hipModuleGetFunction(&tower_fn_[0], tower_mod_, "_ZN6sayuri17conv_tower_kernelILi4ELb0EEEvPKNS_10TowerLayerE"));
+        HIP_OK(hipModuleGetFunction(&tower_fn_[1], tower_mod_, "_ZN6sayuri17conv_tower_kernelILi2ELb0EEEvPKNS_10TowerLayerE"));
+        return 0;
+    }
+    bool tower_ok(int kot) const { return tower_mod_ && !profiling_ && (kot == 256 || kot == 128); }
+    int tower_append(int kot, const BoardSeParams& sp, bool has_se, double flops, double bytes) {
+        if (!run_.empty() && (run_kot_ != kot || (int)run_.size() + table_used_ >= kTowerCap) && tower_flush()) return -1;
+        if (run_.empty()) { run_kot_ = kot; run_flops_ = run_bytes_ = 0; }
+        TowerLayer t;
+        std::memset(&t, 0, sizeof(t));
+        t.sp = sp;
+        t.has_se = has_se ? 1 : 0;
+        run_.push_back(t);
+        run_flops_ += flops;
+        run_bytes_ += bytes;
+        return 0;
+    }
+    int tower_flush() {
+        std::vector<TowerLayer> run;
+        run.swap(run_);  // timed() below must not see a pending run
+        TowerSlot& ts = tower_[cur_slot_];
+        if (!ts.dev) {
+            if (dev_alloc(&ts.dev, kTowerCap)) return -1;
+            for (int i = 0; i < 2; ++i) {
+                HIP_OK(hipHostMalloc((void**)&ts.stage[i], sizeof(TowerLayer) * kTowerCap, hipHostMallocDefault));
+                HIP_OK(hipEventCreateWithFlags(&ts.staged[i], hipEventDisableTiming));
+            }
+            ts.cache.assign(kTowerCap, TowerLayer{});
+        }
+        const int n = (int)run.size(), first = table_used_;
+        if (first + n > kTowerCap) return fail("tower table overflow");
+        for (int i = 0; i < n; ++i) {
+            run[i].self = ts.dev + first + i;
+            run[i].last = i + 1 == n ? 1 : 0;
+        }
+        if (std::memcmp(run.data(), ts.cache.data() + first, sizeof(TowerLayer) * n) != 0) {
+            const int st = ts.next_stage;
+            ts.next_stage ^= 1;
+            HIP_OK(hipEventSynchronize(ts.staged[st]));  // the copy that last read this staging area (never recorded: returns at once)
+            std::memcpy(ts.stage[st], run.data(), sizeof(TowerLayer) * n);
+            HIP_OK(hipMemcpyAsync(ts.dev + first, ts.stage[st], sizeof(TowerLayer) * n, hipMemcpyHostToDevice, stream_));
+            HIP_OK(hipEventRecord(ts.staged[st], stream_));
+            std::memcpy(ts.cache.data() + first, run.data(), sizeof(TowerLayer) * n);
+        }
+        table_used_ += n;
+        const hipFunction_t fn = tower_fn_[run_kot_ == 256 ? 0 : 1];
+        const TowerLayer* arg = ts.dev + first;
+        const int grid = board_plan_.ntiles;
+        hipError_t lrc = hipSuccess;
+        const int rc = timed("tower_run", run_flops_, run_bytes_, [&] {
+            void* params[] = {(void*)&arg};
+            lrc = hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, 0, stream_, params, nullptr);
+        });
+        if (lrc != hipSuccess) return fail(std::string("hipModuleLaunchKernel(conv_tower_kernel): ") + hipGetErrorString(lrc));
+        return rc;
+    }
+    EngineFlags flags_;
+    hipModule_t tower_mod_ = nullptr;
+    hipFunction_t tower_fn_[2] = {nullptr, nullptr};
+    TowerSlot tower_[2];
+    std::vector<TowerLayer> run_;
+    int run_kot_ = 0, table_used_ = 0;
+    double run_flops_ = 0, run_bytes_ = 0;
 
     int device_;
     sayuri_hip_netdesc desc_;
@@ -1425,12 +1555,13 @@ sayuri_hip_ctx* sayuri_hip_create(int device, const sayuri_hip_netdesc* desc, in
     }
     auto ctx = std::make_unique<sayuri_hip_ctx>();
     int rc;
+    const EngineFlags flags = EngineFlags::from_env();
     if (use_fp16) {
-        auto e = std::make_unique<Engine<f16>>(device, *desc, max_batch, board);
+        auto e = std::make_unique<Engine<f16>>(device, *desc, max_batch, board, flags);
         rc = e->init();
         ctx->eng = std::move(e);
     } else {
-        auto e = std::make_unique<Engine<float>>(device, *desc, max_batch, board);
+        auto e = std::make_unique<Engine<float>>(device, *desc, max_batch, board, flags);
         rc = e->init();
         ctx->eng = std::move(e);
     }
@@ -1624,7 +1755,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         bool board_done = false;
         if (sizeof(T) == 2 && k == 3) {
             enable_big_lds_glds();
-            const BoardPlan plan = board_plan(hg);
+            const BoardPlan plan = board_plan(hg, EngineFlags::from_env().conv);
             int kot_tiles = 0;
             const BoardEntry* be = plan.fill >= 0.55 ? pick_board(plan, ko_pad, &kot_tiles) : nullptr;
             if (be) {
@@ -1650,7 +1781,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         }
         if (sizeof(T) == 2 && k == 3 && !board_done) {
             enable_big_lds_glds();
-            ge = pick_glds(hg, ko_pad, &g_ntiles);
+            ge = pick_glds(hg, ko_pad, &g_ntiles, EngineFlags::from_env().conv);
         }
         if (ge) {
             float* dz = (float*)dalloc(256);

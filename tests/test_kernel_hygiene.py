@@ -88,3 +88,51 @@ def test_no_spill_inside_the_mfma_streams(tmp_path):
     assert hit, "conv_board_kernel<4,false> not found in the metadata"
     m = re.search(r"\.vgpr_spill_count:\s+(\d+)", hit[0])
     assert m and int(m.group(1)) == 0, f"conv_board_kernel<4,false> spills {m.group(1) if m else '?'} vector registers"
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="needs the ROCm llvm tools")
+def test_persistent_tower_code_object():
+    """The persistent tower launch (conv_tower.h) is hipcc's single-layer kernels with the layer loop closed in assembly
+    (tower_seam.py).  The code object that ships inside libsayuri_hip.so must (i) be the one the build produced,
+    (ii) carry the entry stub, the dispatch and one seam per body, (iii) keep every compiled body free of scratch traffic
+    inside its MFMA stream, and (iv) declare the resources of both bodies in the launch kernel's descriptor."""
+    so = _build.HIP_SO
+    if not os.path.exists(so):
+        _build.build_hip()
+    hsaco = os.path.join(_build.LIB, "obj", "tower.hsaco")
+    assert os.path.exists(hsaco), "build_tower_blob() leaves the code object next to the objects"
+    blob = open(hsaco, "rb").read()
+    assert blob in open(so, "rb").read(), "libsayuri_hip.so does not embed lib/obj/tower.hsaco"
+    asm = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", hsaco], capture_output=True, text=True, check=True).stdout
+    sections = {}
+    name = None
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            name = m.group(1)
+            sections[name] = []
+        elif name and line.strip():
+            sections[name].append(line.strip())
+    for w in (4, 2):
+        entry = f"_ZN6sayuri17conv_tower_kernelILi{w}ELb0EEEvPKNS_10TowerLayerE"
+        assert entry in sections and f"tower{w}_dispatch" in sections, "entry stub / dispatch missing"
+        stub = sections[entry]
+        assert stub[0].startswith("s_load_dwordx2") and "s[0:1]" in stub[0], stub[0]
+        disp = sections[f"tower{w}_dispatch"]
+        assert any(i.startswith("s_mov_b64 exec, -1") for i in disp) and any(i.startswith("v_mbcnt_hi") for i in disp)
+        assert any(i.startswith("s_setpc_b64") for i in disp), "far jump to the SE body"
+        for body in (f"tower{w}_body_plain", f"tower{w}_body_se"):
+            ins = sections[body]
+            mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
+            assert len(mf) > 100, f"{body}: no MFMA stream"
+            inside = [x for x in ins[mf[0]:mf[-1] + 1] if x.startswith("scratch_")]
+            assert not inside, f"{body}: {len(inside)} scratch accesses inside the MFMA stream, e.g. {inside[:3]}"
+            # the seam: every exit of the body goes through  vmcnt(0) -> s_barrier -> (end | next element)
+            ends = [i for i, x in enumerate(ins) if x.startswith("s_endpgm")]
+            assert len(ends) == 1, f"{body}: {len(ends)} s_endpgm (the seam owns the only one)"
+            tail = ins[ends[0] - 16:ends[0]]
+            assert any(x.startswith("s_waitcnt vmcnt(0)") for x in tail) and any(x.startswith("s_barrier") for x in tail), tail
+            assert any(x.startswith("s_setpc_b64") for x in tail), "far jump back to the dispatch"
+    notes = subprocess.run([READELF, "--notes", hsaco], capture_output=True, text=True, check=True).stdout
+    blocks = [b for b in notes.split(".agpr_count") if "conv_tower_kernelILi4ELb0" in b]
+    assert blocks and re.search(r"\.group_segment_fixed_size:\s+163840", blocks[0]), "launch kernel: static 160 KiB of LDS"

@@ -23,6 +23,17 @@ __global__ __launch_bounds__(256) void calib_write_kernel(u32x4* __restrict__ ds
     for (; i < n16; i += stride) dst[i] = u32x4{seed, (unsigned)i, seed ^ 1u, 7u};
 }
 
+// The board convolution's store pattern: a wave-instruction writes 16 B per lane, four lanes cover 64 contiguous bytes of
+// one 512-byte NHWC pixel row (256 channels of fp16), the 16 lane groups go to 16 consecutive pixel rows.  Covers the
+// buffer exactly once: block = 16 rows, its 8 waves write the 8 64-byte pieces of each row.
+__global__ __launch_bounds__(512) void calib_write64_kernel(unsigned char* __restrict__ dst, size_t rows, unsigned seed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t r0 = (size_t)blockIdx.x * 16; r0 < rows; r0 += (size_t)gridDim.x * 16) {
+        const size_t row = r0 + (lane >> 2);
+        *(u32x4*)(dst + row * 512 + wave * 64 + (lane & 3) * 16) = u32x4{seed, (unsigned)row, seed ^ 1u, 7u};
+    }
+}
+
 int main() {
     const size_t bytes = (size_t)1 << 30, n16 = bytes / 16;
     u32x4 *a, *b;
@@ -33,8 +44,9 @@ int main() {
     for (int r = 0; r < 3; ++r) {
         calib_read_kernel<<<4096, 256>>>(r & 1 ? a : b, sink, n16);
         calib_write_kernel<<<4096, 256>>>(r & 1 ? b : a, n16, r);
+        calib_write64_kernel<<<4096, 512>>>((unsigned char*)(r & 1 ? a : b), bytes / 512, r);
     }
     hipDeviceSynchronize();
-    printf("calibration: 3 x read 1 GiB + 3 x write 1 GiB done\n");
+    printf("calibration: 3 x (read 1 GiB, write 1 GiB, write 1 GiB in 64-byte pieces) done\n");
     return 0;
 }

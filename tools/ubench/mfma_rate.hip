@@ -3,6 +3,7 @@
 // Answers: how much faster per flop is the 32x32x16 form under the chip's power limit?
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -62,7 +63,7 @@ template <typename K> double run(K kern, const f16x8* d, float* o, int iters, co
     return ms;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const size_t n = 256 * 512 * 8;
     std::vector<f16x8> h(n);
     unsigned s = 12345;
@@ -71,6 +72,15 @@ int main() {
     f16x8* d; float* o;
     hipMalloc(&d, n * sizeof(f16x8)); hipMalloc(&o, 256 * 512 * 4);
     hipMemcpy(d, h.data(), n * sizeof(f16x8), hipMemcpyHostToDevice);
+    if (argc > 1) {
+        // sustained mode: `mfma_rate.so <seconds> [zero]` keeps the 16x16x32 loop running (one line per ~0.25 s burst) so that
+        // rocm-smi can be sampled beside it (tools/gpu/r03_evidence.sh)
+        const double secs = atof(argv[1]);
+        if (argc > 2) hipMemset(d, 0, n * sizeof(f16x8));
+        double total = 0;
+        while (total < secs * 1e3) total += run(k16, d, o, 200000, argc > 2 ? "sustained 16x16x32 f16, zero operands" : "sustained 16x16x32 f16, random operands");
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run(k16, d, o, 4000, "16x16x32 f16, 2 waves/SIMD");
         run(k32, d, o, 4000, "32x32x16 f16, 2 waves/SIMD");
