@@ -64,7 +64,8 @@ def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
     cmds = [
         [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-w",
          os.path.join(HIP_SRC, "tower.hip"), "-o", asm],
-        [sys.executable, seam, asm, seamed] + (["--inv"] if os.environ.get("SAYURI_TOWER_INV") else []),
+        [sys.executable, seam, asm, seamed] + (["--inv"] if os.environ.get("SAYURI_TOWER_INV") else []) +
+        (["--sleep=" + os.environ["SAYURI_TOWER_SLEEP"]] if os.environ.get("SAYURI_TOWER_SLEEP") else []),
         [os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", seamed, "-o", elf],
         [os.path.join(LLVM_BIN, "ld.lld"), "-shared", elf, "-o", hsaco],
     ]

@@ -177,7 +177,13 @@ bool Search::AdvanceToNewRootState(int tag) {
 
 void Search::PrepareRootNode(ComputationResult& result, int tag) {
     const bool reused = AdvanceToNewRootState(tag);
-    if (!reused) root_.reset(new (&shared_) Node(active_, &shared_, kPassMove, 1.0f));
+    if (!reused) {
+        // a fresh root (the first move of a game, or a position the old tree does not contain): the old tree goes first, and
+        // with the arena empty its slabs above the cap go back to the system (tree_arena.h)
+        root_.reset();
+        arena_.Reset(kArenaKeepBytes);
+        root_.reset(new (&shared_) Node(active_, &shared_, kPassMove, 1.0f));
+    }
     playouts_ = 0;
     root_evals_ = NodeEvals{};
     const bool fresh = root_->PrepareRootNode(network_, root_state_, root_evals_, caller_rng_);

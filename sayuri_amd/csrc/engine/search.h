@@ -112,6 +112,7 @@ private:
     GameState& root_state_;
     GameState last_state_;
     Network& network_;
+    static constexpr std::size_t kArenaKeepBytes = std::size_t(8) << 20;  // slabs a game keeps across fresh roots
     TreeArena arena_;             // before root_: the tree is destroyed first, its blocks go back into a living arena
     std::unique_ptr<Node> root_;
     NodeEvals root_evals_;

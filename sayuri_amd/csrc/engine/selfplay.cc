@@ -506,30 +506,15 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
     int fiber_threads = 0;
     if (opt_.selfplay.game_threads > 0) fiber_threads = std::min(opt_.selfplay.game_threads, games);
     else if (opt_.selfplay.game_threads == 0 && games >= 256) fiber_threads = std::min(games, std::max(8, 4 * cores));
-    const int games_per_thread = fiber_threads > 0 ? (games + fiber_threads - 1) / fiber_threads : 1;
-    auto thread_start = [this, &cpus, games_per_thread](int idx) {
+    auto thread_start = [&cpus](int idx) {
         if (cpus.size() > 1) {
             cpu_set_t one;
             CPU_ZERO(&one);
             CPU_SET(cpus[static_cast<size_t>(idx) % cpus.size()], &one);
             pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
         }
-        // Grow this thread's malloc arena once to about the size of the search trees it will hold (a node plus its edge
-        // list is ~7 KB, one per playout; one tree per game of this thread) and pre-fault it.  Otherwise the arena grows in
-        // page-sized mprotect steps while the first trees are built -- thousands of address-space write locks per thread,
-        // all of them contending with every other game thread's page faults (measured: 12 cores of system time and a
-        // tenth of the throughput while 2048 games build their first trees).  In chunks below the mmap threshold so that
-        // the memory stays in the arena when it is freed.
-        const size_t per_game = static_cast<size_t>(std::max(opt_.search.playouts, 64)) * 8192 + (1u << 20);
-        const size_t chunk = size_t(8) << 20;
-        std::vector<void*> warm;
-        for (size_t done = 0; done < per_game * static_cast<size_t>(games_per_thread); done += chunk) {
-            void* p = std::malloc(std::min(chunk, per_game * static_cast<size_t>(games_per_thread) - done));
-            if (!p) break;
-            std::memset(p, 0, std::min(chunk, per_game * static_cast<size_t>(games_per_thread) - done));
-            warm.push_back(p);
-        }
-        for (void* p : warm) std::free(p);
+        // (no malloc warm-up: the search trees live in per-game TreeArenas that map their own slabs -- tree_arena.h -- and
+        // what is left on the heap per game is small)
     };
     auto game_loop = [this, games, &started](int g) {
         try {

@@ -50,6 +50,24 @@ public:
         h->owner->ReleaseImpl(h);
     }
     std::size_t slab_bytes() const { return slabs_.size() * kSlabBytes; }
+    std::size_t live_blocks() const { return live_; }
+
+    // With no live block left: unmap the big blocks and every slab above `keep_bytes`, and start carving the kept slabs
+    // from the beginning again.  A no-op while anything is still allocated.
+    void Reset(std::size_t keep_bytes) {
+        if (live_ != 0) return;
+        for (auto& b : big_) munmap(b.first, b.second);
+        big_.clear();
+        const std::size_t keep = keep_bytes / kSlabBytes;
+        while (slabs_.size() > keep) {
+            munmap(slabs_.back(), kSlabBytes);
+            slabs_.pop_back();
+        }
+        used_slabs_ = 0;
+        for (auto& f : free_) f = nullptr;
+        bump_ = nullptr;
+        bump_left_ = 0;
+    }
 
 private:
     struct Header {
@@ -69,6 +87,7 @@ private:
             void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (m == MAP_FAILED) throw std::bad_alloc();
             big_.emplace_back(m, len);
+            ++live_;
             Header* h = static_cast<Header*>(m);
             h->owner = this;
             h->cls = kClasses;  // not recycled
@@ -78,13 +97,15 @@ private:
         if (!free_[c]) Refill(c, std::size_t(1) << shift);
         FreeBlock* b = free_[c];
         free_[c] = b->next;
+        ++live_;
         Header* h = reinterpret_cast<Header*>(b);
         h->owner = this;
         h->cls = static_cast<std::uint64_t>(c);
         return h + 1;
     }
     void ReleaseImpl(Header* h) noexcept {
-        if (h->cls >= static_cast<std::uint64_t>(kClasses)) return;  // big blocks live until the arena dies
+        --live_;
+        if (h->cls >= static_cast<std::uint64_t>(kClasses)) return;  // big blocks are unmapped by Reset / with the arena
         FreeBlock* b = reinterpret_cast<FreeBlock*>(h);
         const int c = static_cast<int>(h->cls);
         b->next = free_[c];
@@ -92,9 +113,15 @@ private:
     }
     void Refill(int c, std::size_t block) {
         if (!bump_ || bump_left_ < block) {
-            void* m = mmap(nullptr, kSlabBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (m == MAP_FAILED) throw std::bad_alloc();
-            slabs_.push_back(m);
+            void* m;
+            if (used_slabs_ < slabs_.size()) {
+                m = slabs_[used_slabs_];  // a slab kept by Reset
+            } else {
+                m = mmap(nullptr, kSlabBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+                if (m == MAP_FAILED) throw std::bad_alloc();
+                slabs_.push_back(m);
+            }
+            ++used_slabs_;
             // (what was left of the previous slab -- less than one block of this class -- is given up)
             bump_ = static_cast<unsigned char*>(m);
             bump_left_ = kSlabBytes;
@@ -114,6 +141,8 @@ private:
     unsigned char* bump_ = nullptr;
     std::size_t bump_left_ = 0;
     std::vector<void*> slabs_;
+    std::size_t used_slabs_ = 0;  // slabs_[0 .. used_slabs_) have been handed to the bump pointer since the last Reset
+    std::size_t live_ = 0;        // blocks handed out and not released yet
     std::vector<std::pair<void*, std::size_t>> big_;
 };
 

@@ -599,6 +599,17 @@ struct BoardSeParams {
     BoardParams b;
     FcDev squeeze, excite;  // transposed [in][out] fp32 weights (small_ops.h)
     int C;                  // real channel count of the block
+    // fp16 images of the two FCs for LDS staging (build_se_images in engine.hip), or null: the FCs then read the fp32
+    // weights above from L2.
+    //   w1h: [2C rows][se] fp16 -- rows 0..C-1 multiply the channel means, rows C..2C-1 the channel maxima.  The
+    //        reference's pooled vector is (mean, mean * (B-14)/10, max) (GlobalPooling<false>, se_unit.cc:9-40): the
+    //        second third is a multiple of the first, so its weights are folded in, W' = W_mean + (B-14)/10 * W_scaled --
+    //        ONE IMAGE PER BOARD SIZE, w1h + (B - 2) * w1_bytes -- which takes a third off the bytes to stage
+    //   w2h: [se/4][2C][4] fp16, then excite bias [2C] fp32, then squeeze bias [se] fp32
+    // both padded to whole 1 KiB DMA pieces (w1_bytes / w2_bytes)
+    const void* w1h;
+    const void* w2h;
+    int w1_bytes, w2_bytes;
 };
 
 // rotate by `n` lanes inside each row of 16 lanes (DPP row_ror) -- four of them make an all-reduce over a row
@@ -636,8 +647,11 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
     const ConvParams& p = sp.b.c;
     const int tid = wave * 64 + lane, q = lane >> 4, px = lane & 15, wave_m = wave & 3, wave_n = wave >> 2;
     const int C = sp.C, so = sp.squeeze.out;
-    // LDS (the K loop's rings are dead): [2][KO_T] sums, [2][KO_T] maxima, pool[3C], red[2048], mid[so], gate[2*KO_T]
-    float* psum = (float*)smem;
+    const bool staged = sp.w1h != nullptr;
+    // LDS (the K loop's rings are dead): the two weight images first (staged form), then
+    // [2][KO_T] sums, [2][KO_T] maxima, pool[3 KO_T], red[2048], mid[512], gate[2 KO_T]
+    const int w_bytes = staged ? sp.w1_bytes + sp.w2_bytes : 0;
+    float* psum = (float*)(smem + w_bytes);
     float* pmax = psum + 2 * KO_T;
     float* pool = pmax + 2 * KO_T;
     float* red = pool + 3 * KO_T;  // [slices][outputs] of an FC: 512 threads x 4 floats
@@ -645,6 +659,16 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
     float* gate = mid + 512;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with the rings
+    if (staged) {
+        // both images on their way into LDS while the accumulators are being pooled: linear 1 KiB pieces, the squeeze
+        // image of this tile's board size first (it is needed first)
+        const int n1 = sp.w1_bytes >> 10, n2 = sp.w2_bytes >> 10;
+        const unsigned char* g1 = (const unsigned char*)sp.w1h + (size_t)(bs - 2) * sp.w1_bytes;
+        const unsigned char* g2 = (const unsigned char*)sp.w2h;
+        const uint32_t l0 = (uint32_t)(uintptr_t)smem;
+        for (int k = wave; k < n1; k += 8) glds16_s(lane * 16, g1 + k * 1024, l0 + k * 1024);
+        for (int k = wave; k < n2; k += 8) glds16_s(lane * 16, g2 + k * 1024, l0 + sp.w1_bytes + k * 1024);
+    }
 
     // ---- pooling: per lane over its column tiles (valid pixels only), then over the 16 pixel lanes of a row
     const int2* pix = sp.b.tab_pix + (size_t)tile * kBoardPT + col0 * 16 + px;
@@ -694,40 +718,82 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
             *(f32x4*)(pmax + wave_n * KO_T + c0) = m4[i];
         }
     }
+    if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the images have landed
     __syncthreads();
     if (dbg) dbg[2] = __builtin_amdgcn_s_memtime();  // pooled partials exchanged
     const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
-    for (int c = tid; c < C; c += 512) {
-        const float mean = (psum[c] + psum[KO_T + c]) / npix;
-        pool[c] = mean;
-        pool[C + c] = mean * (bd / 10.f);
-        pool[2 * C + c] = fmaxf(pmax[c], pmax[KO_T + c]);
-    }
-    __syncthreads();
-    // ---- the two FCs (se_fc4 above): squeeze with the unit's activation, excite into the gate
-    se_fc4(sp.squeeze, pool, red, tid);
-    __syncthreads();
-    for (int o = tid; o < so; o += 512) {
-        float a = sp.squeeze.b[o];
-        const int parts = 512 / (so / 4);
-        for (int k = 0; k < parts; ++k) a += red[k * so + o];
-        mid[o] = activate(a, p.act);
-    }
-    __syncthreads();
-    if (dbg) dbg[3] = __builtin_amdgcn_s_memtime();  // squeeze FC done
-    se_fc4(sp.excite, mid, red, tid);
-    __syncthreads();
-    {
-        const int eo = sp.excite.out, parts = 512 / (eo / 4);
-        for (int o = tid; o < eo; o += 512) {
-            float a = sp.excite.b[o];
-            for (int k = 0; k < parts; ++k) a += red[k * eo + o];
-            // gate[c] = sigmoid(gamma_c), gate[KO_T + c] = beta_c
-            gate[o < C ? o : KO_T + (o - C)] = o < C ? 1.0f / (1.0f + fast_exp(-a)) : a;
+    if (staged) {
+        // ---- squeeze FC out of LDS: thread = (4 consecutive outputs, every parts-th row); a row's pooled value is folded
+        // from the two wave columns' partials on the fly (mean rows: (s0 + s1) / npix, max rows: max(m0, m1))
+        const int quads = so >> 2, parts = 512 / quads, oq = tid % quads, part = tid / quads;
+        const float inv = 1.0f / npix;
+        const unsigned char* w1 = smem + oq * 8;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (part < parts) {
+            for (int r = part; r < 2 * C; r += parts) {
+                const f16x4 w = *(const f16x4*)(w1 + (size_t)r * so * 2);
+                const float x = r < C ? (psum[r] + psum[KO_T + r]) * inv : fmaxf(pmax[r - C], pmax[KO_T + r - C]);
+                a[0] += x * (float)w[0]; a[1] += x * (float)w[1]; a[2] += x * (float)w[2]; a[3] += x * (float)w[3];
+            }
+            *(f32x4*)(red + part * so + oq * 4) = a;
         }
+        __syncthreads();
+        const unsigned char* w2 = smem + sp.w1_bytes;
+        const float* b2 = (const float*)(w2 + (size_t)so * 2 * C * 2);
+        const float* b1 = b2 + 2 * C;
+        for (int o = tid; o < so; o += 512) {
+            float t = b1[o];
+            for (int k = 0; k < parts; ++k) t += red[k * so + o];
+            mid[o] = activate(t, p.act);
+        }
+        __syncthreads();
+        if (dbg) dbg[3] = __builtin_amdgcn_s_memtime();  // squeeze FC done
+        // ---- excite FC out of LDS: thread = one output, 4 inputs per 8-byte read
+        for (int o = tid; o < 2 * C; o += 512) {
+            float t = b2[o];
+            for (int i = 0; i < so; i += 4) {
+                const f16x4 w = *(const f16x4*)(w2 + ((size_t)(i >> 2) * 2 * C + o) * 8);
+                const f32x4 m = *(const f32x4*)(mid + i);
+                t += m[0] * (float)w[0] + m[1] * (float)w[1] + m[2] * (float)w[2] + m[3] * (float)w[3];
+            }
+            // gate[c] = sigmoid(gamma_c), gate[KO_T + c] = beta_c
+            gate[o < C ? o : KO_T + (o - C)] = o < C ? 1.0f / (1.0f + fast_exp(-t)) : t;
+        }
+        __syncthreads();
+        if (dbg) dbg[4] = __builtin_amdgcn_s_memtime();  // excite FC done, gate in LDS
+    } else {
+        for (int c = tid; c < C; c += 512) {
+            const float mean = (psum[c] + psum[KO_T + c]) / npix;
+            pool[c] = mean;
+            pool[C + c] = mean * (bd / 10.f);
+            pool[2 * C + c] = fmaxf(pmax[c], pmax[KO_T + c]);
+        }
+        __syncthreads();
+        // ---- the two FCs (se_fc4 above): squeeze with the unit's activation, excite into the gate
+        se_fc4(sp.squeeze, pool, red, tid);
+        __syncthreads();
+        for (int o = tid; o < so; o += 512) {
+            float a = sp.squeeze.b[o];
+            const int parts = 512 / (so / 4);
+            for (int k = 0; k < parts; ++k) a += red[k * so + o];
+            mid[o] = activate(a, p.act);
+        }
+        __syncthreads();
+        if (dbg) dbg[3] = __builtin_amdgcn_s_memtime();  // squeeze FC done
+        se_fc4(sp.excite, mid, red, tid);
+        __syncthreads();
+        {
+            const int eo = sp.excite.out, parts = 512 / (eo / 4);
+            for (int o = tid; o < eo; o += 512) {
+                float a = sp.excite.b[o];
+                for (int k = 0; k < parts; ++k) a += red[k * eo + o];
+                // gate[c] = sigmoid(gamma_c), gate[KO_T + c] = beta_c
+                gate[o < C ? o : KO_T + (o - C)] = o < C ? 1.0f / (1.0f + fast_exp(-a)) : a;
+            }
+        }
+        __syncthreads();
+        if (dbg) dbg[4] = __builtin_amdgcn_s_memtime();  // excite FC done, gate in LDS
     }
-    __syncthreads();
-    if (dbg) dbg[4] = __builtin_amdgcn_s_memtime();  // excite FC done, gate in LDS
     // ---- x <- sigmoid(gamma) x + beta on the accumulators (pad channels: weights and bias are 0, x stays 0 * g + b:
     // their gate entries are never written, so they are masked here)
 #pragma unroll

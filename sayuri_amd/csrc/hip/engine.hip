@@ -322,6 +322,8 @@ struct FcLayerDev {
     std::vector<float> hw, hb;
     float* wt = nullptr;  // [in][out]
     float* b = nullptr;
+    void* img16 = nullptr;  // SE units of the fp16 engine: the LDS-staging image of conv_board.h (BoardSeParams::w1h / w2h)
+    int img_bytes = 0;      // bytes of one image (whole 1 KiB pieces)
     FcDev dev() const { return FcDev{wt, b, in, out}; }
 };
 
@@ -846,6 +848,7 @@ private:
             std::vector<float>().swap(L.hw);
             std::vector<float>().swap(L.hb);
         }
+        if (build_se_images()) return -1;
         for (auto& kv : fcs_) {
             FcLayerDev& L = kv.second;
             if (L.hw.empty() || L.hb.empty()) return fail("missing tensors for fc layer " + std::to_string(kv.first));
@@ -886,6 +889,48 @@ private:
     }
 
     static T from_float_host(float v) { return (T)v; }
+
+    // fp16 images of the SE units' two FCs, laid out for the LDS-DMA staging of board_se_stage (conv_board.h): the squeeze
+    // weights once per board size 2..board with the scaled-mean third of the pooled vector folded into the mean third
+    // (reference GlobalPooling<false>, se_unit.cc:9-40: pool = (mean, mean * (B-14)/10, max)), the excite weights with
+    // both bias vectors behind them.  Units whose images do not fit the LDS keep reading fp32 weights from L2.
+    int build_se_images() {
+        if (sizeof(T) != 2) return 0;
+        const int C = desc_.residual_channels;
+        for (int b = 0; b < desc_.residual_blocks; ++b) {
+            if (!blocks_[b].apply_se) continue;
+            FcLayerDev& sq = fcs_.at(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE));
+            FcLayerDev& ex = fcs_.at(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE));
+            const int se = sq.out;
+            if (sq.hw.empty() || ex.hw.empty() || sq.hb.empty() || ex.hb.empty()) continue;  // finalize() reports it
+            if (sq.in != 3 * C || ex.in != se || ex.out != 2 * C || se % 4 || se > 512 || 2 * C > 512) continue;
+            const int w1_bytes = round_up(2 * C * se * 2, 1024), w2_bytes = round_up(se * 2 * C * 2 + (2 * C + se) * 4, 1024);
+            if ((size_t)w1_bytes + w2_bytes + 20 * 1024 > kMaxLds) continue;
+            std::vector<f16> img1((size_t)(board_ - 1) * (w1_bytes / 2), (f16)0.f);
+            for (int bs = 2; bs <= board_; ++bs) {
+                const float sc = ((float)bs - 14.f) / 10.f;
+                f16* d = img1.data() + (size_t)(bs - 2) * (w1_bytes / 2);
+                for (int r = 0; r < 2 * C; ++r)
+                    for (int o = 0; o < se; ++o) {
+                        const float* w = sq.hw.data() + (size_t)o * 3 * C;
+                        d[(size_t)r * se + o] = (f16)(r < C ? w[r] + sc * w[C + r] : w[2 * C + (r - C)]);
+                    }
+            }
+            std::vector<unsigned char> img2(w2_bytes, 0);
+            f16* h = (f16*)img2.data();
+            for (int i = 0; i < se; ++i)
+                for (int o = 0; o < 2 * C; ++o) h[((size_t)(i >> 2) * 2 * C + o) * 4 + (i & 3)] = (f16)ex.hw[(size_t)o * se + i];
+            float* bias = (float*)(img2.data() + (size_t)se * 2 * C * 2);
+            std::copy(ex.hb.begin(), ex.hb.end(), bias);
+            std::copy(sq.hb.begin(), sq.hb.end(), bias + 2 * C);
+            f16* d1 = nullptr;
+            unsigned char* d2 = nullptr;
+            if (dev_upload(&d1, img1) || dev_upload(&d2, img2)) return -1;
+            sq.img16 = d1; sq.img_bytes = w1_bytes;
+            ex.img16 = d2; ex.img_bytes = w2_bytes;
+        }
+        return 0;
+    }
 
     void release() {
         (void)hipSetDevice(device_);
@@ -1065,11 +1110,13 @@ private:
             for (const auto& e : kBoardEntries)
                 if (e.fn_se && e.kot == L.ko_pad && e.lds(board_plan_.npos) <= kMaxLds) be = &e;
         if (!be || !board_plan_.single || C > be->kot) return 1;
-        if (sq.out % 4 || sq.out > 512 || ex.out % 4 || ex.out > 2048 || 512 % (sq.out / 4) || 512 % (ex.out / 4)) return 1;
+        const bool staged = sq.img16 && ex.img16;
+        if (!staged && (sq.out % 4 || sq.out > 512 || ex.out % 4 || ex.out > 2048 || 512 % (sq.out / 4) || 512 % (ex.out / 4))) return 1;
         if constexpr (sizeof(T) != 2) return 1;
         const BoardTabs* tabs = nullptr;
         if (board_tabs(&tabs)) return -1;
         BoardSeParams sp;
+        std::memset(&sp, 0, sizeof(sp));  // padding too: the tower table is compared bytewise with its cached copy
         BoardParams& bp = sp.b;
         bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos; bp.dbg = nullptr;
         bp.uniform_info = board_plan_.uniform_info;
@@ -1080,6 +1127,8 @@ private:
         p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
         p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = board_plan_.ntiles;
         sp.squeeze = sq.dev(); sp.excite = ex.dev(); sp.C = C;
+        sp.w1h = staged ? sq.img16 : nullptr; sp.w2h = staged ? ex.img16 : nullptr;
+        sp.w1_bytes = sq.img_bytes; sp.w2_bytes = ex.img_bytes;
 #ifdef SAYURI_EXPERIMENTS
         if (flags_.board_dbg < 0) {  // negative n: timeline of the n-th SE convolution of the forward
             if (!d_dbg_ && dev_alloc(&d_dbg_, 4 * 8 * 8)) return -1;
@@ -1102,6 +1151,7 @@ private:
             const BoardTabs* tabs = nullptr;
             if (board_tabs(&tabs)) return -1;
             BoardParams bp;
+            std::memset(&bp, 0, sizeof(bp));
             bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos;
             bp.dbg = nullptr;
             bp.uniform_info = board_plan_.uniform_info;
@@ -1129,7 +1179,8 @@ private:
             const double flops = 2.0 * px * L.cin * L.cout * 9;
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
             if (bkt == 1 && tower_ok(be->kot) && !bp.dbg) {
-                BoardSeParams sp{};
+                BoardSeParams sp;
+                std::memset(&sp, 0, sizeof(sp));
                 sp.b = bp;
                 return tower_append(be->kot, sp, false, flops, bytes);
             }
@@ -1238,7 +1289,7 @@ private:
         {
             const ConvLayerDev& L = cv(SAYURI_L_INPUT_CONV);
             const int in = take();
-            const int grid = (int)(((size_t)geom_.total * (L.cin_s / ElemTraits<T>::kPieceElems) + 255) / 256);
+            const int grid = geom_.n * kPackSplit;  // kPackSplit workgroups per sample
             const double px = geom_.total;
             T* dst = bufs_[in];
             const int cin = d.input_channels, cs = L.cin_s, board = board_;
@@ -1251,11 +1302,15 @@ private:
                                            (const int*)d_perm_);
                     }))
                     return -1;
-            } else if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
-                    hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(256), 0, stream_,
-                                       (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_);
-                }))
-                return -1;
+            } else {
+                const int chunk = pack_input_chunk(slot_pix_, cs, (int)sizeof(T));
+                const size_t lds = (size_t)chunk * (cs * sizeof(T) + 16);
+                if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
+                        hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(kPackThreads), lds, stream_,
+                                           (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_, chunk);
+                    }))
+                    return -1;
+            }
             if (conv("conv3x3_input", L, bufs_[in], bufs_[x], nullptr, act)) return -1;
             give(in);
         }

@@ -11,66 +11,100 @@
 //                      and ownership, written straight into the NN-grid fp32 output tensors
 //                      (cuda_forward_pipe.cc:930-981)
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace sayuri {
 
+// kPackSplit workgroups per sample (grid = n_samples * kPackSplit, each a range of the sample's pixels).  The planes are read along pixels (thread = pixel, eight planes
+// per 16-byte piece: every load of a wave is 256 contiguous bytes), transposed through LDS ([pixel][cs] with a 16-byte pad per
+// row: 16-byte writes of consecutive pixels then fall on distinct banks) and leave as whole NHWC rows (consecutive lanes
+// write consecutive 16-byte pieces).  15.9 MB in + 11.8 MB out for a 256-batch: a streaming kernel.
+constexpr int kPackThreads = 128;
+constexpr int kPackSplit = 4;  // workgroups per sample (pixel ranges): several per CU, so that one's loads overlap another's stores
 template <typename T>
-__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ planes, T* __restrict__ out,
-                                                         BatchGeom g, int cin, int cs, int board, const int* __restrict__ perm) {
+__global__ __launch_bounds__(kPackThreads) void pack_input_kernel(const float* __restrict__ planes, T* __restrict__ out,
+                                                                  BatchGeom g, int cin, int cs, int board, const int* __restrict__ perm,
+                                                                  int chunk) {
     constexpr int EPP = ElemTraits<T>::kPieceElems;
-    const int ppr = cs / EPP;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, 16-byte piece)
-    if (idx >= (size_t)g.total_pix * ppr) return;
-    const int gi = (int)(idx / ppr), piece = (int)(idx - (size_t)gi * ppr);
-    int lo = 0, hi = g.n_samples;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (g.sample_off[mid] <= gi) lo = mid; else hi = mid;
-    }
-    const int n = lo, bs = g.bsz[n], pp = gi - g.sample_off[n];
-    const int y = pp / bs, x = pp - y * bs;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
+    const int n = blockIdx.x / kPackSplit, part = blockIdx.x % kPackSplit, tid = threadIdx.x;
+    const int bs = g.bsz[n], npix = bs * bs, ppr = cs / EPP, stride = cs * (int)sizeof(T) + 16;
+    const int per = (npix + kPackSplit - 1) / kPackSplit, pbeg = part * per, pend = min(npix, pbeg + per);
     const size_t B2 = (size_t)board * board;
-    const float* src = planes + (size_t)(perm ? perm[n] : n) * cin * B2 + y * board + x;  // perm: device sample -> caller's slot
-    T v[EPP];
+    const float* src = planes + (size_t)(perm ? perm[n] : n) * cin * B2;  // perm: device sample -> caller's slot
+    T* dst = out + (size_t)n * g.slot_pix * cs;
+    for (int p0 = pbeg; p0 < pend; p0 += chunk) {  // `chunk` pixels fit the LDS
+        const int np = min(chunk, pend - p0);
+        if (p0 != pbeg) __syncthreads();
+        for (int q = tid; q < np; q += kPackThreads) {
+            const int pp = p0 + q, y = pp / bs, x = pp - y * bs;
+            const float* s0 = src + y * board + x;
+            // six pieces (48 planes) at a time: all their loads go out before the first conversion (a thread has its
+            // whole pixel in flight at once -- with one workgroup per CU this kernel lives on memory-level parallelism)
+            for (int pb = 0; pb < ppr; pb += 6) {
+                float f[6 * EPP];
 #pragma unroll
-    for (int e = 0; e < EPP; ++e) {
-        const int c = piece * EPP + e;
-        v[e] = from_float<T>(c < cin ? src[(size_t)c * B2] : 0.f);
+                for (int k = 0; k < 6 * EPP; ++k) {
+                    const int c = pb * EPP + k;
+                    f[k] = c < cin ? s0[(size_t)c * B2] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    if (pb + j < ppr) {
+                        T v[EPP];
+#pragma unroll
+                        for (int e = 0; e < EPP; ++e) v[e] = from_float<T>(f[j * EPP + e]);
+                        *(uint4*)(pk_smem + (size_t)q * stride + (pb + j) * 16) = *(uint4*)v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < np * ppr; it += kPackThreads) {
+            const int q = it / ppr, piece = it - q * ppr;
+            *(uint4*)(dst + ((size_t)p0 * ppr + it) * EPP) = *(const uint4*)(pk_smem + (size_t)q * stride + piece * 16);
+        }
     }
-    *(uint4*)(out + ((size_t)n * g.slot_pix + pp) * cs + piece * EPP) = *(uint4*)v;
+}
+// pixels per pass and the LDS they take (<= 64 KiB: no opt-in needed)
+static inline int pack_input_chunk(int slot_pix, int cs, int elem) {
+    return std::min((slot_pix + kPackSplit - 1) / kPackSplit, (64 * 1024) / (cs * elem + 16));
 }
 
 // The same activations from PACKED planes (csrc/host/packed_planes.h): record of a sample = uint32
 // bits[nbin][12] (bit y*bs+x of a 0/1 plane, the sample's OWN cell order -- no re-padding into the NN grid) followed by 8
 // floats (the value of each broadcast plane).  1.8 KB per sample instead of 62 KB over PCIe and out of HBM.
+// kPackSplit workgroups per sample (pixel ranges): the record goes to LDS with one coalesced load, then thread = (pixel,
+// 16-byte piece) in output order -- every store of a wave is 1 KiB contiguous.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_bits_kernel(const unsigned* __restrict__ records, int rec_words, int nbin,
                                                         T* __restrict__ out, BatchGeom g, int cin, int cs,
                                                         const int* __restrict__ perm) {
     constexpr int EPP = ElemTraits<T>::kPieceElems;
-    const int ppr = cs / EPP;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, 16-byte piece)
-    if (idx >= (size_t)g.total_pix * ppr) return;
-    const int gi = (int)(idx / ppr), piece = (int)(idx - (size_t)gi * ppr);
-    int lo = 0, hi = g.n_samples;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (g.sample_off[mid] <= gi) lo = mid; else hi = mid;
-    }
-    const int n = lo, pp = gi - g.sample_off[n];
-    const unsigned* rec = records + (size_t)(perm ? perm[n] : n) * rec_words;  // perm: device sample -> caller's slot
-    const int word = pp >> 5, sh = pp & 31;
-    T v[EPP];
+    __shared__ unsigned rec[40 * 13 + 8];  // 13 words per plane: the eight planes a wave reads at once fall on different banks
+    const int n = blockIdx.x / kPackSplit, part = blockIdx.x % kPackSplit, tid = threadIdx.x;
+    const int bs = g.bsz[n], npix = bs * bs, ppr = cs / EPP;
+    const int per = (npix + kPackSplit - 1) / kPackSplit, pbeg = part * per, pend = min(npix, pbeg + per);
+    const unsigned* src = records + (size_t)(perm ? perm[n] : n) * rec_words;  // perm: device sample -> caller's slot
+    for (int i = tid; i < rec_words; i += 256) rec[i < nbin * 12 ? (i / 12) * 13 + i % 12 : nbin * 13 + (i - nbin * 12)] = src[i];
+    __syncthreads();
+    T* dst = out + (size_t)n * g.slot_pix * cs;
+    for (int it = pbeg * ppr + tid; it < pend * ppr; it += 256) {
+        const int pp = it / ppr, piece = it - pp * ppr;
+        const int word = pp >> 5, sh = pp & 31;
+        T v[EPP];
 #pragma unroll
-    for (int e = 0; e < EPP; ++e) {
-        const int c = piece * EPP + e;
-        float f = 0.f;
-        if (c < nbin) f = (float)((rec[c * 12 + word] >> sh) & 1u);
-        else if (c < cin) f = __uint_as_float(rec[nbin * 12 + (c - nbin)]);
-        v[e] = from_float<T>(f);
+        for (int e = 0; e < EPP; ++e) {
+            const int c = piece * EPP + e;
+            float f = 0.f;
+            if (c < nbin) f = (float)((rec[c * 13 + word] >> sh) & 1u);
+            else if (c < cin) f = __uint_as_float(rec[nbin * 13 + (c - nbin)]);
+            v[e] = from_float<T>(f);
+        }
+        *(uint4*)(dst + (size_t)it * EPP) = *(uint4*)v;
     }
-    *(uint4*)(out + ((size_t)n * g.slot_pix + pp) * cs + piece * EPP) = *(uint4*)v;
 }
 
 struct FcDev {

@@ -47,6 +47,9 @@ def far_jump(sym, t=4):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     inv = "--inv" in sys.argv
+    # measuring builds only: --sleep=N parks every wave for N x 64 cycles in the seam (what does a stall cost a chip that
+    # runs at its power limit?)
+    sleep = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--sleep=")), 0)
     if len(args) != 2:
         die("usage: tower_seam.py in.s out.s [--inv]")
     lines = open(args[0]).read().split("\n")
@@ -150,6 +153,10 @@ def main():
                     "\ts_barrier"]
             if inv:
                 tail.append("\tbuffer_inv sc1")
+            for _ in range(sleep // 127):
+                tail.append("\ts_sleep 127")
+            if sleep % 127:
+                tail.append(f"\ts_sleep {sleep % 127}")
             tail += ["\ts_cmp_lg_u32 s4, 0",
                      f"\ts_cbranch_scc1 {done}",
                      f"\ts_add_u32 s{B}, s{B}, {STRIDE}",

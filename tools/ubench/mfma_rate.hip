@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -47,6 +48,26 @@ __global__ __launch_bounds__(512, 2) void k32(const f16x8* __restrict__ src, flo
     out[blockIdx.x * 512 + tid] = s;
 }
 
+// the same 48 x 16x16x32 per iteration with EIGHT different B fragments (k16 re-reads three): operand data changes from one
+// MFMA to the next, as in a real K loop -- what do fresh operands cost at the power limit?
+__global__ __launch_bounds__(512, 2) void k16r(const f16x8* __restrict__ src, float* __restrict__ out, int iters) {
+    const int tid = threadIdx.x;
+    f16x8 a[4], b[8];
+    for (int i = 0; i < 4; ++i) a[i] = src[(blockIdx.x * 512 + tid) * 8 + i];
+    for (int i = 0; i < 8; ++i) b[i] = src[((blockIdx.x * 512 + tid) * 8 + 4 + i * 131) % (256 * 512 * 8)];
+    f32x4 acc[48];
+    for (int i = 0; i < 48; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i * 12 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[(j * 4 + i) % 8], acc[i * 12 + j], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < 48; ++i) s += acc[i][0] + acc[i][3];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
 template <typename K> double run(K kern, const f16x8* d, float* o, int iters, const char* name) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -76,8 +97,11 @@ int main(int argc, char** argv) {
         // sustained mode: `mfma_rate.so <seconds> [zero]` keeps the 16x16x32 loop running (one line per ~0.25 s burst) so that
         // rocm-smi can be sampled beside it (tools/gpu/r03_evidence.sh)
         const double secs = atof(argv[1]);
-        if (argc > 2) hipMemset(d, 0, n * sizeof(f16x8));
+        if (argc > 2 && !strcmp(argv[2], "zero")) hipMemset(d, 0, n * sizeof(f16x8));
         double total = 0;
+        const char* mode = argc > 2 ? argv[2] : "random";
+        if (!strcmp(mode, "k32")) { while (total < secs * 1e3) total += run(k32, d, o, 200000, "sustained 32x32x16 f16, random operands"); return 0; }
+        if (!strcmp(mode, "rot")) { while (total < secs * 1e3) total += run(k16r, d, o, 200000, "sustained 16x16x32 f16, random operands, 8 rotating B fragments"); return 0; }
         while (total < secs * 1e3) total += run(k16, d, o, 200000, argc > 2 ? "sustained 16x16x32 f16, zero operands" : "sustained 16x16x32 f16, random operands");
         return 0;
     }
