@@ -200,6 +200,24 @@ int sayuri_hip_test_head_tail(int device, int use_fp16, int n, const int* board_
                               const float* pconv, const float* vconv, const float* const* weights12, float* prob,
                               float* pass, float* misc, float* own);
 
+/* The two fused kernels of the fp16 engine at kernel level (round 3):
+ * sayuri_hip_test_conv_se   a channels -> channels 3x3 convolution (w [C][C][3][3], bias [C]) with the SE unit that follows
+ *   it INSIDE the kernel (conv_board_se_kernel; via_tower != 0: the same stage inside a one-layer run of the persistent
+ *   tower kernel): y = act(sigmoid(gamma) * conv(x) + beta + res), reference SEUnit::Forward on the convolution's output
+ *   (se_unit.cc:70-128).  Tensors as in sayuri_hip_test_conv / sayuri_hip_test_se_unit.
+ * sayuri_hip_test_head_board   both heads of a sample in one workgroup (head_board_kernel): trunk [n][channels][bs*bs],
+ *   p_w [Cp][channels], p_b [Cp], v_w [Cv][channels], v_b [Cv] (the two 1x1 head convolutions, reference
+ *   blas_forward_pipe.cc:449-495), weights12 and outputs as in sayuri_hip_test_head_tail.
+ * Both return 1 (not an error) when the fused kernel does not apply to the arguments: the engine then runs the separate
+ * kernels (several samples per tile / channel counts without a kernel variant). */
+int sayuri_hip_test_conv_se(int device, int n, const int* board_sizes, int max_board, int channels, int se_size, int act,
+                            int via_tower, const float* x, const float* w, const float* bias, const float* res, const float* w1,
+                            const float* b1, const float* w2, const float* b2, float* y);
+int sayuri_hip_test_head_board(int device, int n, const int* board_sizes, int max_board, int channels, int policy_channels,
+                               int value_channels, int prob_channels, int pass_outs, int misc_outs, int act, const float* trunk,
+                               const float* p_w, const float* p_b, const float* v_w, const float* v_b,
+                               const float* const* weights12, float* prob, float* pass, float* misc, float* own);
+
 #ifdef __cplusplus
 }
 #endif

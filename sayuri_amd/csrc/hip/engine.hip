@@ -327,6 +327,94 @@ struct FcLayerDev {
     FcDev dev() const { return FcDev{wt, b, in, out}; }
 };
 
+// ------------------------------------------------------------------ host-side images shared by the engine and the test taps
+// fp16 images of an SE unit's two FCs for the LDS staging of board_se_stage (conv_board.h, BoardSeParams::w1h / w2h):
+// the squeeze weights once per board size 2..board with the scaled-mean third of the pooled vector folded into the mean
+// third (reference GlobalPooling<false>, se_unit.cc:9-40: pool = (mean, mean * (B-14)/10, max)), the excite weights with
+// both bias vectors behind them.  sq_w [se][3C], ex_w [2C][se] as handed over the ABI.  false: the unit does not fit.
+static bool make_se_images(int C, int se, int board, const float* sq_w, const float* sq_b, const float* ex_w, const float* ex_b,
+                           std::vector<f16>* img1, std::vector<unsigned char>* img2, int* w1_bytes_out, int* w2_bytes_out) {
+    if (se <= 0 || se % 4 || se > 512 || 2 * C > 512) return false;
+    const int w1_bytes = round_up(2 * C * se * 2, 1024), w2_bytes = round_up(se * 2 * C * 2 + (2 * C + se) * 4, 1024);
+    if ((size_t)w1_bytes + w2_bytes + 20 * 1024 > kMaxLds) return false;
+    img1->assign((size_t)(board - 1) * (w1_bytes / 2), (f16)0.f);
+    for (int bs = 2; bs <= board; ++bs) {
+        const float sc = ((float)bs - 14.f) / 10.f;
+        f16* d = img1->data() + (size_t)(bs - 2) * (w1_bytes / 2);
+        for (int r = 0; r < 2 * C; ++r)
+            for (int o = 0; o < se; ++o) {
+                const float* w = sq_w + (size_t)o * 3 * C;
+                d[(size_t)r * se + o] = (f16)(r < C ? w[r] + sc * w[C + r] : w[2 * C + (r - C)]);
+            }
+    }
+    img2->assign(w2_bytes, 0);
+    f16* h = (f16*)img2->data();
+    for (int i = 0; i < se; ++i)
+        for (int o = 0; o < 2 * C; ++o) h[((size_t)(i >> 2) * 2 * C + o) * 4 + (i & 3)] = (f16)ex_w[(size_t)o * se + i];
+    float* bias = (float*)(img2->data() + (size_t)se * 2 * C * 2);
+    std::copy(ex_b, ex_b + 2 * C, bias);
+    std::copy(sq_b, sq_b + se, bias + 2 * C);
+    *w1_bytes_out = w1_bytes;
+    *w2_bytes_out = w2_bytes;
+    return true;
+}
+
+// Images of head_board_kernel (head_board.h): the stacked [policy | value] 1x1 head convolutions as one MFMA image
+// (rows: policy channels rounded to a row tile of 16, then the value channels up to an even number of row tiles), the
+// per-pixel weights (policy planes over the policy rows, ownership over the value rows) in the accumulator's channel
+// order, the stacked bias.  Returns the kernel variant that fits, or nullptr (the separate head kernels run then).
+struct HeadImages {
+    std::vector<f16> img, img2;
+    std::vector<float> bias;
+    int PT = 0, VT = 0;
+};
+static HeadFn make_head_images(int C, int Cp, int Cv, int prob_ch, int board, const float* p_w, const float* p_b, const float* v_w,
+                               const float* v_b, const float* prob_w, const float* own_w, HeadImages* out) {
+    if (board * board > kHeadPix || prob_ch > 8) return nullptr;
+    const int PT = round_up(Cp, 16), rows = round_up(PT + Cv, 32), VT = rows - PT, cs = round_up(C, 32), nch = cs / 32;
+    HeadFn fn = nullptr;
+    for (const auto& e : kHeadEntries)
+        if (e.rt * 16 == rows && head_board_fits(rows, nch, e.depth)) { fn = e.fn; break; }
+    if (!fn) return nullptr;
+    // per-pixel weights in the accumulator's channel order: k-group kg of pair t holds stacked rows 32t + 4kg + s (s < 4)
+    // and 32t + 16 + 4kg + (s - 4); row k < prob_ch = policy plane k over the policy rows, row prob_ch = ownership
+    out->img2.assign((size_t)(rows / 32) * 4 * 16 * 8, (f16)0.f);
+    for (int t = 0; t < rows / 32; ++t)
+        for (int kg = 0; kg < 4; ++kg)
+            for (int e = 0; e < 8; ++e) {
+                const int ch = 32 * t + (e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4));
+                for (int k = 0; k < prob_ch; ++k)
+                    if (ch < Cp) out->img2[(((size_t)t * 4 + kg) * 16 + k) * 8 + e] = (f16)prob_w[(size_t)k * Cp + ch];
+                if (ch >= PT && ch - PT < Cv) out->img2[(((size_t)t * 4 + kg) * 16 + prob_ch) * 8 + e] = (f16)own_w[ch - PT];
+            }
+    out->img.assign((size_t)nch * 4 * rows * 8, (f16)0.f);
+    out->bias.assign(rows, 0.f);
+    for (int half = 0; half < 2; ++half) {
+        const float* w = half ? v_w : p_w;
+        const float* b = half ? v_b : p_b;
+        const int cout = half ? Cv : Cp, r0 = half ? PT : 0;
+        for (int ko = 0; ko < cout; ++ko) {
+            out->bias[r0 + ko] = b[ko];
+            for (int c = 0; c < C; ++c)
+                out->img[(((size_t)(c / 32) * 4 + (c % 32) / 8) * rows + r0 + ko) * 8 + c % 8] = (f16)w[(size_t)ko * C + c];
+        }
+    }
+    out->PT = PT;
+    out->VT = VT;
+    return fn;
+}
+
+// the persistent tower kernels (conv_tower.h) out of the embedded code object: [0] 256-channel tile, [1] 128-channel tile
+}  // namespace sayuri
+extern "C" const unsigned char sayuri_tower_hsaco[];
+namespace sayuri {
+static int load_tower_module(hipModule_t* mod, hipFunction_t fn[2]) {
+    HIP_OK(hipModuleLoadData(mod, sayuri_tower_hsaco));
+    HIP_OK(hipModuleGetFunction(&fn[0], *mod, "_ZN6sayuri17conv_tower_kernelILi4ELb0EEEvPKNS_10TowerLayerE"));
+    HIP_OK(hipModuleGetFunction(&fn[1], *mod, "_ZN6sayuri17conv_tower_kernelILi2ELb0EEEvPKNS_10TowerLayerE"));
+    return 0;
+}
+
 class EngineBase {
 public:
     virtual ~EngineBase() {}
@@ -346,11 +434,6 @@ public:
     virtual int timed_stat(sayuri_hip_kernel_stat* row) = 0;
     virtual size_t device_bytes() const = 0;
 };
-
-}  // namespace sayuri
-// the code object of the persistent tower kernels (tower.hip -> tower_seam.py -> clang -> ld.lld), linked in as a blob
-extern "C" const unsigned char sayuri_tower_hsaco[];
-namespace sayuri {
 
 template <typename T> class Engine : public EngineBase {
 public:
@@ -757,49 +840,22 @@ private:
     // Stacked [policy | value] head-convolution image for head_board_kernel (fp16 engine, normal policy head).
     int build_head_image() {
         const sayuri_hip_netdesc& d = desc_;
-        if (sizeof(T) != 2 || d.policy_head_type != 0 || board_ * board_ > kHeadPix) return 0;
+        if (sizeof(T) != 2 || d.policy_head_type != 0) return 0;
         const ConvLayerDev& P = convs_.at(SAYURI_L_P_HD_CONV);
         const ConvLayerDev& V = convs_.at(SAYURI_L_V_HD_CONV);
-        if (P.hw.empty() || V.hw.empty() || P.hb.empty() || V.hb.empty()) return 0;
-        // rows: policy channels rounded to a row tile of 16, then the value channels up to an even number of row tiles
-        const int PT = round_up(P.cout, 16), rows = round_up(PT + V.cout, 32), VT = rows - PT, cs = round_up(P.cin, 32), nch = cs / 32;
-        head_fn_ = nullptr;
-        for (const auto& e : kHeadEntries)
-            if (e.rt * 16 == rows && head_board_fits(rows, nch, e.depth)) { head_fn_ = e.fn; break; }
         const ConvLayerDev& PW = convs_.at(SAYURI_L_PROB_CONV);
         const ConvLayerDev& OW = convs_.at(SAYURI_L_V_OWNERSHIP);
-        if (!head_fn_ || PW.hw.empty() || OW.hw.empty() || d.probabilities_channels > 8) return 0;
-        // per-pixel weights in the accumulator's channel order: k-group kg of pair t holds stacked rows 32t + 4kg + s (s < 4)
-        // and 32t + 16 + 4kg + (s - 4); row k < prob_ch = policy plane k over the policy rows, row prob_ch = ownership
-        std::vector<T> img2((size_t)(rows / 32) * 4 * 16 * 8, from_float_host(0.f));
-        for (int t = 0; t < rows / 32; ++t)
-            for (int kg = 0; kg < 4; ++kg)
-                for (int e = 0; e < 8; ++e) {
-                    const int ch = 32 * t + (e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4));
-                    for (int k = 0; k < d.probabilities_channels; ++k)
-                        if (ch < P.cout) img2[(((size_t)t * 4 + kg) * 16 + k) * 8 + e] = from_float_host(PW.hw[(size_t)k * P.cout + ch]);
-                    if (ch >= PT && ch - PT < V.cout)
-                        img2[(((size_t)t * 4 + kg) * 16 + d.probabilities_channels) * 8 + e] = from_float_host(OW.hw[ch - PT]);
-                }
-        T* w2 = nullptr;
-        if (dev_upload(&w2, img2)) return -1;
+        if (P.hw.empty() || V.hw.empty() || P.hb.empty() || V.hb.empty() || PW.hw.empty() || OW.hw.empty()) return 0;
+        HeadImages hi;
+        head_fn_ = make_head_images(P.cin, P.cout, V.cout, d.probabilities_channels, board_, P.hw.data(), P.hb.data(), V.hw.data(),
+                                    V.hb.data(), PW.hw.data(), OW.hw.data(), &hi);
+        if (!head_fn_) return 0;
+        f16 *w = nullptr, *w2 = nullptr;
+        if (dev_upload(&w2, hi.img2) || dev_upload(&w, hi.img) || dev_upload(&head_bias_, hi.bias)) return -1;
         head_img2_ = w2;
-        std::vector<T> img((size_t)nch * 4 * rows * 8, from_float_host(0.f));
-        std::vector<float> b(rows, 0.f);
-        for (int half = 0; half < 2; ++half) {
-            const ConvLayerDev& L = half ? V : P;
-            const int r0 = half ? PT : 0;
-            for (int ko = 0; ko < L.cout; ++ko) {
-                b[r0 + ko] = L.hb[ko];
-                for (int c = 0; c < L.cin; ++c)
-                    img[(((size_t)(c / 32) * 4 + (c % 32) / 8) * rows + r0 + ko) * 8 + c % 8] = from_float_host(L.hw[(size_t)ko * L.cin + c]);
-            }
-        }
-        T* w = nullptr;
-        if (dev_upload(&w, img) || dev_upload(&head_bias_, b)) return -1;
         head_img_ = w;
-        head_pt_ = PT;
-        head_vt_ = VT;
+        head_pt_ = hi.PT;
+        head_vt_ = hi.VT;
         return 0;
     }
 
@@ -903,26 +959,12 @@ private:
             FcLayerDev& ex = fcs_.at(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE));
             const int se = sq.out;
             if (sq.hw.empty() || ex.hw.empty() || sq.hb.empty() || ex.hb.empty()) continue;  // finalize() reports it
-            if (sq.in != 3 * C || ex.in != se || ex.out != 2 * C || se % 4 || se > 512 || 2 * C > 512) continue;
-            const int w1_bytes = round_up(2 * C * se * 2, 1024), w2_bytes = round_up(se * 2 * C * 2 + (2 * C + se) * 4, 1024);
-            if ((size_t)w1_bytes + w2_bytes + 20 * 1024 > kMaxLds) continue;
-            std::vector<f16> img1((size_t)(board_ - 1) * (w1_bytes / 2), (f16)0.f);
-            for (int bs = 2; bs <= board_; ++bs) {
-                const float sc = ((float)bs - 14.f) / 10.f;
-                f16* d = img1.data() + (size_t)(bs - 2) * (w1_bytes / 2);
-                for (int r = 0; r < 2 * C; ++r)
-                    for (int o = 0; o < se; ++o) {
-                        const float* w = sq.hw.data() + (size_t)o * 3 * C;
-                        d[(size_t)r * se + o] = (f16)(r < C ? w[r] + sc * w[C + r] : w[2 * C + (r - C)]);
-                    }
-            }
-            std::vector<unsigned char> img2(w2_bytes, 0);
-            f16* h = (f16*)img2.data();
-            for (int i = 0; i < se; ++i)
-                for (int o = 0; o < 2 * C; ++o) h[((size_t)(i >> 2) * 2 * C + o) * 4 + (i & 3)] = (f16)ex.hw[(size_t)o * se + i];
-            float* bias = (float*)(img2.data() + (size_t)se * 2 * C * 2);
-            std::copy(ex.hb.begin(), ex.hb.end(), bias);
-            std::copy(sq.hb.begin(), sq.hb.end(), bias + 2 * C);
+            if (sq.in != 3 * C || ex.in != se || ex.out != 2 * C) continue;
+            std::vector<f16> img1;
+            std::vector<unsigned char> img2;
+            int w1_bytes = 0, w2_bytes = 0;
+            if (!make_se_images(C, se, board_, sq.hw.data(), sq.hb.data(), ex.hw.data(), ex.hb.data(), &img1, &img2, &w1_bytes, &w2_bytes))
+                continue;
             f16* d1 = nullptr;
             unsigned char* d2 = nullptr;
             if (dev_upload(&d1, img1) || dev_upload(&d2, img2)) return -1;
@@ -1437,12 +1479,7 @@ private:
         int next_stage = 0;
         std::vector<TowerLayer> cache;               // what dev holds
     };
-    int tower_load() {
-        HIP_OK(hipModuleLoadData(&tower_mod_, sayuri_tower_hsaco));
-        HIP_OK(hipModuleGetFunction(&tower_fn_[0], tower_mod_, "_ZN6sayuri17conv_tower_kernelILi4ELb0EEEvPKNS_10TowerLayerE"));
-        HIP_OK(hipModuleGetFunction(&tower_fn_[1], tower_mod_, "_ZN6sayuri17conv_tower_kernelILi2ELb0EEEvPKNS_10TowerLayerE"));
-        return 0;
-    }
+    int tower_load() { return load_tower_module(&tower_mod_, tower_fn_); }
     bool tower_ok(int kot) const { return tower_mod_ && !profiling_ && (kot == 256 || kot == 128); }
     int tower_append(int kot, const BoardSeParams& sp, bool has_se, double flops, double bytes) {
         if (!run_.empty() && (run_kot_ != kot || (int)run_.size() + table_used_ >= kTowerCap) && tower_flush()) return -1;
@@ -2062,7 +2099,182 @@ static int test_head_tail_impl(int device, int n, const int* board_sizes, int ma
     return 0;
 }
 
+// The convolution with the SE unit inside it (conv_board_se_kernel, or the same stage inside the persistent tower kernel
+// when via_tower != 0): C -> C 3x3 convolution + bias, then the unit's pool -> FC -> FC -> act(sigmoid(g) x + b + res).
+// Returns 1 when the fused kernel does not apply to this batch (several samples per tile, channel tile not 128 / 256).
+static int test_conv_se_impl(int device, int n, const int* board_sizes, int max_board, int C, int se, int act, int via_tower,
+                             const float* x, const float* w, const float* bias, const float* res, const float* w1, const float* b1,
+                             const float* w2, const float* b2, float* y) {
+    typedef f16 T;
+    HIP_OK(hipSetDevice(device));
+    enable_big_lds_glds();
+    TestArena A;
+    TestGeom tg;
+    if (make_test_geom(A, n, board_sizes, max_board, &tg)) return -1;
+    const int cs = round_up(C, 32), wmt = pick_wmt(cs, true), ko_pad = round_up(cs, wmt * 32);
+    const BoardPlan plan = board_plan(tg.hg, ConvOverride{});
+    const BoardEntry* be = nullptr;
+    if (plan.ok)
+        for (const auto& e : kBoardEntries)
+            if (e.fn_se && e.kot == ko_pad && e.lds(plan.npos) <= kMaxLds) be = &e;
+    if (!be || !plan.single || C > be->kot) return 1;
+    std::vector<f16> img1;
+    std::vector<unsigned char> img2;
+    int w1_bytes = 0, w2_bytes = 0;
+    const bool staged = make_se_images(C, se, max_board, w1, b1, w2, b2, &img1, &img2, &w1_bytes, &w2_bytes);
+    if (!staged && (se % 4 || se > 512 || (2 * C) % 4 || 512 % (se / 4) || 512 % (2 * C / 4))) return 1;
+    // activations (with the zero prefix the board kernels read their halo cells from), weights image, tables
+    std::vector<T> hx = nchw_to_nhwc<T>(tg, x, C, cs);
+    T* dx = (T*)A.alloc(hx.size() * sizeof(T) + kZeroPrefix);
+    if (!dx) return fail("test_conv_se: hipMalloc failed");
+    dx += kZeroPrefix / sizeof(T);
+    HIP_OK(hipMemcpy(dx, hx.data(), hx.size() * sizeof(T), hipMemcpyHostToDevice));
+    T* dres = res ? A.upload(nchw_to_nhwc<T>(tg, res, C, cs)) : nullptr;
+    T* dy = (T*)A.alloc((size_t)n * tg.slot * cs * sizeof(T));
+    const int nch = cs / 32;
+    std::vector<T> img((size_t)9 * nch * 4 * ko_pad * 8, (T)0.f);
+    for (int t = 0; t < 9; ++t)
+        for (int ko = 0; ko < C; ++ko)
+            for (int c = 0; c < C; ++c)
+                img[((((size_t)t * nch + c / 32) * 4 + (c % 32) / 8) * ko_pad + ko) * 8 + c % 8] = (T)w[((size_t)ko * C + c) * 9 + t];
+    std::vector<float> hb(ko_pad, 0.f);
+    if (bias) std::copy(bias, bias + C, hb.begin());
+    T* dw = A.upload(img);
+    float* db = A.upload(hb);
+    float* dw1 = A.upload(fc_transposed(w1, 3 * C, se));
+    float* dw2 = A.upload(fc_transposed(w2, se, 2 * C));
+    float* db1 = A.upload(std::vector<float>(b1, b1 + se));
+    float* db2 = A.upload(std::vector<float>(b2, b2 + 2 * C));
+    f16* d1 = staged ? A.upload(img1) : nullptr;
+    unsigned char* d2 = staged ? A.upload(img2) : nullptr;
+    int* tsrc = (int*)A.alloc(sizeof(int) * (size_t)plan.ntiles * plan.npos);
+    int2* tpix = (int2*)A.alloc(sizeof(int2) * (size_t)plan.ntiles * kBoardPT);
+    int* tcols = (int*)A.alloc(sizeof(int) * (size_t)plan.ntiles);
+    if ((res && !dres) || !dy || !dw || !db || !dw1 || !dw2 || !db1 || !db2 || (staged && (!d1 || !d2)) || !tsrc || !tpix || !tcols)
+        return fail("test_conv_se: hipMalloc failed");
+    hipLaunchKernelGGL(board_setup_kernel, dim3(plan.ntiles), dim3(256), 0, 0, tg.g, plan.npos, tsrc, tpix, tcols);
+    BoardSeParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    BoardParams& bp = sp.b;
+    bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos;
+    bp.uniform_info = plan.uniform_info;
+    bp.arith = (plan.single && plan.uniform_info >= 0) ? 1 : 0;
+    ConvParams& p = bp.c;
+    p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = tg.g;
+    p.cin_s = cs; p.cout_s = cs; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.num_pix_tiles = plan.ntiles;
+    sp.squeeze = FcDev{dw1, db1, 3 * C, se};
+    sp.excite = FcDev{dw2, db2, se, 2 * C};
+    sp.C = C;
+    sp.w1h = d1; sp.w2h = d2; sp.w1_bytes = w1_bytes; sp.w2_bytes = w2_bytes;
+    hipModule_t mod = nullptr;
+    if (via_tower) {
+        hipFunction_t fn[2] = {nullptr, nullptr};
+        if (load_tower_module(&mod, fn)) return -1;
+        TowerLayer t;
+        std::memset(&t, 0, sizeof(t));
+        TowerLayer* dt = (TowerLayer*)A.alloc(sizeof(TowerLayer));
+        if (!dt) return fail("test_conv_se: hipMalloc failed");
+        t.self = dt; t.last = 1; t.has_se = 1; t.sp = sp;
+        HIP_OK(hipMemcpy(dt, &t, sizeof(t), hipMemcpyHostToDevice));
+        const TowerLayer* arg = dt;
+        void* params[] = {(void*)&arg};
+        HIP_OK(hipModuleLaunchKernel(fn[be->kot == 256 ? 0 : 1], plan.ntiles, 1, 1, 512, 1, 1, 0, nullptr, params, nullptr));
+    } else {
+        hipLaunchKernelGGL(be->fn_se, dim3(plan.ntiles), dim3(512), be->lds(plan.npos), 0, sp);
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    if (mod) (void)hipModuleUnload(mod);
+    std::vector<T> hy((size_t)n * tg.slot * cs);
+    HIP_OK(hipMemcpy(hy.data(), dy, hy.size() * sizeof(T), hipMemcpyDeviceToHost));
+    size_t so = 0;
+    for (int i = 0; i < n; ++i) {
+        const int S = tg.hg.bsz[i] * tg.hg.bsz[i];
+        for (int c = 0; c < C; ++c)
+            for (int pp = 0; pp < S; ++pp) y[so + (size_t)c * S + pp] = (float)hy[((size_t)i * tg.slot + pp) * cs + c];
+        so += (size_t)C * S;
+    }
+    return 0;
+}
+
+// Both heads of a sample in one workgroup (head_board_kernel): trunk [n][C][bs*bs] -> the four output tensors.
+// Returns 1 when no head_board_kernel variant fits these channel counts (the engine then runs conv1x1 x2 + head_tail).
+static int test_head_board_impl(int device, int n, const int* board_sizes, int max_board, int C, int Cp, int Cv, int prob_ch,
+                                int pass_outs, int misc_outs, int act, const float* trunk, const float* p_w, const float* p_b,
+                                const float* v_w, const float* v_b, const float* const* w, float* prob, float* pass, float* misc,
+                                float* own) {
+    typedef f16 T;
+    HIP_OK(hipSetDevice(device));
+    enable_big_lds_glds();
+    TestArena A;
+    TestGeom tg;
+    if (make_test_geom(A, n, board_sizes, max_board, &tg)) return -1;
+    HeadImages hi;
+    const HeadFn fn = make_head_images(C, Cp, Cv, prob_ch, max_board, p_w, p_b, v_w, v_b, w[8], w[10], &hi);
+    if (!fn) return 1;
+    const int cs = round_up(C, 32), B2 = max_board * max_board;
+    T* dt = A.upload(nchw_to_nhwc<T>(tg, trunk, C, cs));
+    HeadBoardParams hp;
+    std::memset(&hp, 0, sizeof(hp));
+    HeadParams& h = hp.h;
+    float* d_pi = A.upload(fc_transposed(w[0], 3 * Cp, Cp));
+    float* d_pib = A.upload(std::vector<float>(w[1], w[1] + Cp));
+    float* d_pw = A.upload(fc_transposed(w[2], Cp, pass_outs));
+    float* d_pwb = A.upload(std::vector<float>(w[3], w[3] + pass_outs));
+    float* d_vi = A.upload(fc_transposed(w[4], 3 * Cv, 3 * Cv));
+    float* d_vib = A.upload(std::vector<float>(w[5], w[5] + 3 * Cv));
+    float* d_vm = A.upload(fc_transposed(w[6], 3 * Cv, misc_outs));
+    float* d_vmb = A.upload(std::vector<float>(w[7], w[7] + misc_outs));
+    float* d_prw = A.upload(std::vector<float>(w[8], w[8] + (size_t)prob_ch * Cp));
+    float* d_prb = A.upload(std::vector<float>(w[9], w[9] + prob_ch));
+    float* d_ow = A.upload(std::vector<float>(w[10], w[10] + Cv));
+    float* d_ob = A.upload(std::vector<float>(w[11], w[11] + 1));
+    f16* d_img = A.upload(hi.img);
+    f16* d_img2 = A.upload(hi.img2);
+    float* d_bias = A.upload(hi.bias);
+    float* d_prob = (float*)A.alloc(sizeof(float) * (size_t)n * prob_ch * B2);
+    float* d_pass = (float*)A.alloc(sizeof(float) * (size_t)n * pass_outs);
+    float* d_misc = (float*)A.alloc(sizeof(float) * (size_t)n * misc_outs);
+    float* d_own = (float*)A.alloc(sizeof(float) * (size_t)n * B2);
+    if (!dt || !d_pi || !d_pib || !d_pw || !d_pwb || !d_vi || !d_vib || !d_vm || !d_vmb || !d_prw || !d_prb || !d_ow || !d_ob || !d_img ||
+        !d_img2 || !d_bias || !d_prob || !d_pass || !d_misc || !d_own)
+        return fail("test_head_board: hipMalloc failed");
+    h.p_inter = FcDev{d_pi, d_pib, 3 * Cp, Cp};
+    h.pass_fc = FcDev{d_pw, d_pwb, Cp, pass_outs};
+    h.v_inter = FcDev{d_vi, d_vib, 3 * Cv, 3 * Cv};
+    h.v_misc = FcDev{d_vm, d_vmb, 3 * Cv, misc_outs};
+    h.prob_w = d_prw; h.prob_b = d_prb; h.own_w = d_ow; h.own_b = d_ob;
+    h.Cp = Cp; h.cs_p = round_up(Cp, 32); h.Cv = Cv; h.cs_v = round_up(Cv, 32); h.prob_ch = prob_ch; h.act = act; h.board = max_board;
+    h.prob = d_prob; h.pass = d_pass; h.misc = d_misc; h.own = d_own; h.perm = nullptr;
+    hp.trunk = dt; hp.w = d_img; hp.w2 = d_img2; hp.bias = d_bias; hp.g = tg.g; hp.cs = cs; hp.PT = hi.PT; hp.VT = hi.VT; hp.dbg = nullptr;
+    hipLaunchKernelGGL(fn, dim3(n), dim3(512), kMaxLds, 0, hp);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(prob, d_prob, sizeof(float) * (size_t)n * prob_ch * B2, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(pass, d_pass, sizeof(float) * (size_t)n * pass_outs, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(misc, d_misc, sizeof(float) * (size_t)n * misc_outs, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(own, d_own, sizeof(float) * (size_t)n * B2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // namespace sayuri
+
+extern "C" int sayuri_hip_test_conv_se(int device, int n, const int* board_sizes, int max_board, int channels, int se_size, int act,
+                                       int via_tower, const float* x, const float* w, const float* bias, const float* res,
+                                       const float* w1, const float* b1, const float* w2, const float* b2, float* y) {
+    if (!board_sizes || !x || !w || !w1 || !b1 || !w2 || !b2 || !y || n <= 0) return fail("test_conv_se: bad argument");
+    return test_conv_se_impl(device, n, board_sizes, max_board, channels, se_size, act, via_tower, x, w, bias, res, w1, b1, w2, b2, y);
+}
+
+extern "C" int sayuri_hip_test_head_board(int device, int n, const int* board_sizes, int max_board, int channels, int policy_channels,
+                                          int value_channels, int prob_channels, int pass_outs, int misc_outs, int act, const float* trunk,
+                                          const float* p_w, const float* p_b, const float* v_w, const float* v_b,
+                                          const float* const* weights12, float* prob, float* pass, float* misc, float* own) {
+    if (!board_sizes || !trunk || !p_w || !p_b || !v_w || !v_b || !weights12 || !prob || !pass || !misc || !own || n <= 0)
+        return fail("test_head_board: bad argument");
+    return test_head_board_impl(device, n, board_sizes, max_board, channels, policy_channels, value_channels, prob_channels, pass_outs,
+                                misc_outs, act, trunk, p_w, p_b, v_w, v_b, weights12, prob, pass, misc, own);
+}
 
 extern "C" int sayuri_hip_test_se_unit(int device, int use_fp16, int n, const int* board_sizes, int max_board, int channels, int se_size,
                                        int act, const float* x, const float* res, const float* w1, const float* b1, const float* w2,
