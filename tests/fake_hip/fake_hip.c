@@ -7,7 +7,13 @@
  * The "network" is a fixed, cheap function of each sample's own planes (fake_eval below), so a test can tell for
  * every reply whether it belongs to the request that asked for it.  submit() is asynchronous like the real one:
  * a worker thread per context finishes a batch FAKE_HIP_DELAY_US microseconds after it was enqueued, two tickets
- * may be in flight. */
+ * may be in flight.
+ *
+ * Latency model for the multi-rank readiness runs (tools/fake8.py): with FAKE_HIP_SERIAL_US=T the device is SERIAL like
+ * the real one -- a batch occupies it for T microseconds whatever its size (3 800 us = one 256-batch of the 20b x 256
+ * network on an MI355X), the next one starts when the previous has finished -- and FAKE_HIP_CHEAP=1 replaces the
+ * per-plane checksum network by one that costs the host next to nothing (policy = the first bit planes plus a hash of
+ * the position), so that the host cores measured are the engine's, not the stand-in's. */
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -19,6 +25,8 @@
 struct job {
     int n, state; /* 0 free, 1 queued, 2 done */
     const float* planes;
+    const unsigned* records; /* cheap mode: the packed records themselves */
+    int binary;
     float* owned; /* planes expanded from packed records (freed when the job is done) */
     const int* bsz;
     float *prob, *pass, *misc, *own;
@@ -27,7 +35,9 @@ struct job {
 struct sayuri_hip_ctx {
     sayuri_hip_netdesc desc;
     int board, max_batch, next, stop;
-    long delay_us;
+    long delay_us, serial_us;
+    int cheap;
+    struct timespec busy_until; /* serial model: when the device is free again */
     struct job jobs[2];
     int order[2], n_order; /* FIFO of queued tickets */
     pthread_mutex_t mu;
@@ -50,6 +60,37 @@ static void fake_eval(const sayuri_hip_ctx* c, int n, const float* planes, const
         for (int k = 0; k < PP; ++k) pass[(size_t)i * PP + k] = (float)(s * 0.001) + (float)k;
         for (int k = 0; k < VM; ++k) misc[(size_t)i * VM + k] = (float)(s * 0.002) - (float)k + (float)bs;
         for (int p = 0; p < B2; ++p) own[(size_t)i * B2 + p] = x[(size_t)7 * B2 + p] - x[(size_t)8 * B2 + p];
+    }
+}
+
+/* FAKE_HIP_CHEAP: a few operations per output value.  From planes: policy k = plane k; from packed records: policy k =
+ * bit plane k plus a per-position hash in [0, 1) (different positions prefer different moves). */
+static void cheap_eval(const sayuri_hip_ctx* c, int n, const float* planes, const unsigned* rec, int binary, const int* bsz,
+                       float* prob, float* pass, float* misc, float* own) {
+    const int B = c->board, B2 = B * B, C = c->desc.input_channels;
+    const int PC = c->desc.probabilities_channels, PP = c->desc.pass_probability_outputs, VM = c->desc.value_misc_outputs;
+    const int words = binary * 12 + 8;
+    memset(prob, 0, sizeof(float) * (size_t)n * PC * B2);
+    memset(own, 0, sizeof(float) * (size_t)n * B2);
+    for (int i = 0; i < n; ++i) {
+        const int bs = bsz ? bsz[i] : B;
+        unsigned h = 2166136261u;
+        if (rec) for (int k = 0; k < 24; ++k) h = (h ^ rec[(size_t)i * words + k]) * 16777619u;
+        for (int k = 0; k < PC; ++k)
+            for (int y = 0; y < bs; ++y)
+                for (int x = 0; x < bs; ++x) {
+                    float v;
+                    if (rec) {
+                        const int cell = y * bs + x;
+                        unsigned g = (h + (unsigned)cell * 2654435761u) * 2246822519u;
+                        v = (float)((rec[(size_t)i * words + k * 12 + (cell >> 5)] >> (cell & 31)) & 1u) + (float)(g >> 8) * (1.0f / 16777216.0f);
+                    } else {
+                        v = planes[((size_t)i * C + k) * B2 + y * B + x];
+                    }
+                    prob[((size_t)i * PC + k) * B2 + y * B + x] = v;
+                }
+        for (int k = 0; k < PP; ++k) pass[(size_t)i * PP + k] = -2.0f;
+        for (int k = 0; k < VM; ++k) misc[(size_t)i * VM + k] = (float)((h >> (k & 15)) & 255u) * (1.0f / 256.0f) - 0.5f;
     }
 }
 
@@ -84,7 +125,8 @@ static void* worker_main(void* arg) {
         const struct timespec due = j->due;
         pthread_mutex_unlock(&c->mu);
         clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &due, NULL);
-        fake_eval(c, j->n, j->planes, j->bsz, j->prob, j->pass, j->misc, j->own);
+        if (c->cheap) cheap_eval(c, j->n, j->planes, j->records, j->binary, j->bsz, j->prob, j->pass, j->misc, j->own);
+        else fake_eval(c, j->n, j->planes, j->bsz, j->prob, j->pass, j->misc, j->own);
         free(j->owned);
         j->owned = NULL;
         pthread_mutex_lock(&c->mu);
@@ -112,6 +154,9 @@ sayuri_hip_ctx* sayuri_hip_create(int device, const sayuri_hip_netdesc* desc, in
     c->max_batch = max_batch;
     const char* d = getenv("FAKE_HIP_DELAY_US");
     c->delay_us = d ? atol(d) : 200;
+    const char* su = getenv("FAKE_HIP_SERIAL_US");
+    c->serial_us = su ? atol(su) : 0;
+    c->cheap = getenv("FAKE_HIP_CHEAP") != NULL;
     pthread_mutex_init(&c->mu, NULL);
     pthread_cond_init(&c->cv_work, NULL);
     pthread_cond_init(&c->cv_done, NULL);
@@ -142,6 +187,7 @@ int sayuri_hip_forward(sayuri_hip_ctx* c, int n, const float* planes, const int*
 }
 static int submit_any(sayuri_hip_ctx* c, int n, const float* planes, float* owned, const int* bsz, float* prob, float* pass,
                       float* misc, float* own, int* ticket);
+
 int sayuri_hip_submit(sayuri_hip_ctx* c, int n, const float* planes, const int* bsz, float* prob, float* pass,
                       float* misc, float* own, int* ticket) {
     return submit_any(c, n, planes, NULL, bsz, prob, pass, misc, own, ticket);
@@ -157,6 +203,14 @@ int sayuri_hip_forward_packed(sayuri_hip_ctx* c, int n, const unsigned* records,
 int sayuri_hip_submit_packed(sayuri_hip_ctx* c, int n, const unsigned* records, int binary, const int* bsz, float* prob,
                              float* pass, float* misc, float* own, int* ticket) {
     if (!c || !records || n <= 0 || n > c->max_batch) return -1;
+    if (c->cheap) {
+        pthread_mutex_lock(&c->mu);
+        struct job* j = &c->jobs[c->next];
+        j->records = records;
+        j->binary = binary;
+        pthread_mutex_unlock(&c->mu);
+        return submit_any(c, n, NULL, NULL, bsz, prob, pass, misc, own, ticket);
+    }
     float* x = expand_records(c, n, records, binary, bsz);
     const int rc = submit_any(c, n, x, x, bsz, prob, pass, misc, own, ticket);
     if (rc) free(x);
@@ -171,10 +225,18 @@ static int submit_any(sayuri_hip_ctx* c, int n, const float* planes, float* owne
     if (j->state != 0) { pthread_mutex_unlock(&c->mu); return -1; } /* more than two batches in flight */
     c->next ^= 1;
     j->n = n; j->planes = planes; j->owned = owned; j->bsz = bsz; j->prob = prob; j->pass = pass; j->misc = misc; j->own = own;
+    if (planes) j->records = NULL;
     clock_gettime(CLOCK_MONOTONIC, &j->due);
-    j->due.tv_nsec += (c->delay_us % 1000000) * 1000;
-    j->due.tv_sec += c->delay_us / 1000000 + j->due.tv_nsec / 1000000000;
+    long add_us = c->delay_us;
+    if (c->serial_us > 0) { /* serial device: starts when the previous batch has finished */
+        if (c->busy_until.tv_sec > j->due.tv_sec || (c->busy_until.tv_sec == j->due.tv_sec && c->busy_until.tv_nsec > j->due.tv_nsec))
+            j->due = c->busy_until;
+        add_us = c->serial_us;
+    }
+    j->due.tv_nsec += (add_us % 1000000) * 1000;
+    j->due.tv_sec += add_us / 1000000 + j->due.tv_nsec / 1000000000;
     j->due.tv_nsec %= 1000000000;
+    c->busy_until = j->due;
     j->state = 1;
     c->order[c->n_order++] = t;
     ++c->submits;

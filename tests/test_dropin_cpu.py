@@ -1,5 +1,6 @@
 """CPU-side drop-in checks: the host pipe compiles against the REFERENCE's headers when
 /root/reference is mounted (dev container only), and the sharded bench path works under gloo."""
+import json
 import os
 import subprocess
 import sys
@@ -115,3 +116,19 @@ def test_newer_weights_on_one_rank_halt_every_rank_gloo_world2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29535", str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_eight_ranks_on_the_fake_device_halt_together(tmp_path):
+    """Eight gloo ranks, each with its own queue / games (fibers) / cache over the serial fake device (tools/fake8.py, the
+    readiness run of profiles/r03_fake8_*.json in small): every rank takes part in every exchange round, one rank sees a
+    newer network and ALL of them wind down (reference Engine::ShouldHalt + pipe.cc:246-258, made collective)."""
+    out = tmp_path / "fake8.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fake8.py"), "--ranks", "8", "--games", "16", "--playouts", "16",
+                        "--board", "7", "--seconds", "40", "--serial-us", "500", "--halt-rank", "5", "--halt-after", "4", "--out", str(out)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(out.read_text())
+    assert d["ranks_reporting"] == 8 and d["halt_seen_by"] == list(range(8)), d
+    assert d["stopped_early_by_halt"] == list(range(8)), d
+    assert len(set(d["exchange_rounds"])) == 1 and d["exchange_rounds"][0] >= 2, d["exchange_rounds"]
+    assert all(x["nn_evals"] > 0 and x["mean_batch"] > 1 for x in d["per_rank"])
