@@ -1,18 +1,41 @@
 #!/bin/bash
-# round-2 evidence: GPU suite, kernel-trace stats, PMC passes, config 5
+# Evidence pass of a round on one box (TAG=r03 ...): GPU suite, kernel-trace stats, PMC passes (one counter set per run,
+# --kernel-trace only), HBM-side traffic with calibration streams, the default bench line, configs[4], fp32.
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out/prof
+TAG=${TAG:-r03}
+O=gpurun_out/$TAG
+mkdir -p $O/prof
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r02_gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r02_gpu_tests.log
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof/kt -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --selfplay-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/kt.out 2> $GRAFT_REPO_ROOT/gpurun_out/prof/kt.err); echo "kernel-trace rc=$?"
-ls gpurun_out/prof/kt | head; head -12 gpurun_out/prof/kt/p_kernel_stats.csv 2>/dev/null | cut -c1-220
-for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  (cd /tmp && timeout 150 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_$tag -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --selfplay-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_$tag.out 2> $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_$tag.err)
-  echo "pmc $tag rc=$?"
-  python tools/pmc_summary.py gpurun_out/prof/pmc_$tag "conv_board_kernel<4" 2>&1 | tail -9
-done
-timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --selfplay-seconds 0 --config5 > gpurun_out/r02_config5.json 2> gpurun_out/r02_config5.err; echo "config5 rc=$?"
-python -c "import json;d=json.load(open('gpurun_out/r02_config5.json'));print(d['config5'])"
-timeout 300 python bench.py --fp32 --steps 5 --warmup 1 --no-cpu-baseline --selfplay-seconds 0 > gpurun_out/r02_bench_fp32.json 2> gpurun_out/r02_bench_fp32.err; echo "fp32 rc=$?"
-python -c "import json;d=json.load(open('gpurun_out/r02_bench_fp32.json'));print(d['value'], d['roofline'])"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --selfplay-seconds 0 --no-pump"
+if [ -z "$SKIP_TESTS" ]; then
+  timeout 2400 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
+fi
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof/kt -o p --output-format csv -- $B --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$O/prof/kt.out 2> $GRAFT_REPO_ROOT/$O/prof/kt.err); echo "kernel-trace rc=$?"
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --selfplay-seconds 0 --no-pump --steps 20 --warmup 5   ($(date -u +%FT%TZ))"
+  echo "# bench line of the same command:"; tail -1 $O/prof/kt.out | sed 's/^/# /' | cut -c1-1500
+  find $O/prof/kt -name "*kernel_stats.csv" | head -1 | xargs cat; } > $O/rocprofv3_kernel_stats.txt
+head -8 $O/rocprofv3_kernel_stats.txt | cut -c1-220
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
+           "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+           "TCC_WRITE_sum TCC_READ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  # counters are collected on the per-layer launches (SAYURI_TOWER=0: the same K loop, SE stage and epilogue code, one launch
+  # per convolution): under rocprofv3's counter collection the persistent tower launch faults (it does not under --kernel-trace)
+  (cd /tmp && SAYURI_TOWER=0 timeout 100 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof/p$i -o p --output-format csv -- $B --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/$O/prof/p$i.out 2> $GRAFT_REPO_ROOT/$O/prof/p$i.err)
+  echo "## set $i [$set] rc=$?"
+  grep -E "Memory access fault|Segmentation|rror" $O/prof/p$i.err | head -2
+  python tools/pmc_summary.py $O/prof/p$i "conv_board_kernel<4" 2>&1 | tail -n +2
+  python tools/pmc_summary.py $O/prof/p$i "conv_board_se_kernel<4" 2>&1 | tail -n +2
+  if [ $i -ge 3 ]; then
+    (cd /tmp && timeout 150 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof/c$i -o p --output-format csv -- $GRAFT_REPO_ROOT/tools/ubench/hbm_calib.so > $GRAFT_REPO_ROOT/$O/prof/c$i.out 2> $GRAFT_REPO_ROOT/$O/prof/c$i.err)
+    for k in calib_read calib_write_kernel calib_write64; do python tools/pmc_summary.py $O/prof/c$i $k 2>&1 | tail -n +2 | sed "s/^/   $k (1 GiB)  /"; done
+  fi
+done > $O/pmc_raw.txt 2>&1
+cat $O/pmc_raw.txt
+timeout 900 python bench.py --no-cpu-baseline --selfplay-seconds 0 --config5 > $O/config5.json 2> $O/config5.err; echo "config5 rc=$?"
+python -c "import json;d=json.load(open('$O/config5.json'));print(d['value'], d['roofline']['frac'], d['config5'])"
+timeout 300 python bench.py --fp32 --steps 5 --warmup 1 --no-cpu-baseline --selfplay-seconds 0 > $O/bench_fp32.json 2> $O/bench_fp32.err; echo "fp32 rc=$?"
+python -c "import json;d=json.load(open('$O/bench_fp32.json'));print(d['value'], d['roofline'])"
+rm -rf $O/prof/*/p_kernel_trace.csv $O/prof/*/p_agent_info.csv
