@@ -60,17 +60,25 @@ def algorithmic_flops_per_eval(spec, board: int = 19) -> float:
     return 2.0 * mac
 
 
-def hbm_traffic(fp16: bool) -> dict:
-    """HBM-side bytes per launch of the dominant kernel, from the rocprofv3 PMC passes kept under profiles/ (counters
-    cannot be read from inside this process; MI355X_MICROARCH.md HBM section: separate --pmc passes, FETCH_SIZE x 2)."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    algo = 2 * 256 * 361 * 256 * 2 + 256 * 256 * 9 * 2  # in + out + weights of one 256->256 layer, fp16, batch 256
+def hbm_traffic(fp16: bool, dominant: str) -> dict:
+    """HBM-side (fabric) bytes per launch of the dominant kernel, from the rocprofv3 PMC passes kept under profiles/
+    (counters cannot be read from inside this process; MI355X_MICROARCH.md HBM section: separate --pmc passes, requests x
+    calibrated bytes per request).  The passes run on the per-layer launches (SAYURI_TOWER=0; rocprofv3's counter collection
+    faults the persistent launch): one tower launch = the sum over its layers.  `traffic_source` names the file, its age
+    and the commit it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+    layer_algo = 2 * 256 * 361 * 256 * 2 + 256 * 256 * 9 * 2  # in + out + weights of one 256->256 layer, fp16, batch 256
     if not fp16 or not os.path.exists(path):
-        return {"traffic": None, "algorithmic_bytes": algo}
+        return {"traffic": None, "algorithmic_bytes": layer_algo}
     t = json.load(open(path))
-    tot = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
-    return {"traffic": tot, "traffic_read": t["read_bytes_per_launch"], "traffic_write": t["write_bytes_per_launch"],
-            "algorithmic_bytes": algo, "traffic_over_algorithmic": round(tot / algo, 3), "traffic_source": t["source"]}
+    if dominant == "tower_run":
+        rd, wr, algo = t["tower_run"]["read_bytes"], t["tower_run"]["write_bytes"], t["tower_run"]["algorithmic_bytes"]
+    else:
+        rd, wr, algo = t["conv3x3_tower"]["read_bytes"], t["conv3x3_tower"]["write_bytes"], t["conv3x3_tower"]["algorithmic_bytes"]
+    age_h = (time.time() - os.path.getmtime(path)) / 3600.0
+    return {"traffic": rd + wr, "traffic_read": rd, "traffic_write": wr, "algorithmic_bytes": algo,
+            "traffic_over_algorithmic": round((rd + wr) / algo, 3),
+            "traffic_source": f"{os.path.relpath(path, ROOT)} ({t['source']}; measured on commit {t.get('commit', '?')}, file {age_h:.1f} h old)"}
 
 
 def mark_dominant(lib, ctx) -> str:
@@ -245,8 +253,8 @@ def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--fp32", action="store_true", help="strict-parity fp32 engine instead of fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -384,11 +392,13 @@ def main():
                     "seconds": round(el, 2), "nn_evals_per_sec": round(tot["nn_queries"] / el, 1),
                     "playouts_per_sec": round(tot["playouts"] / el, 1), "moves_per_sec": round(moves_per_sec, 2),
                     "games_done": games,
-                    # reference definition: played games / wall (src/selfplay/pipe.cc:272-280)
-                    "games_per_hour": round(games / el * 3600, 1) if games else None,
+                    # the steady-state rate: searched moves per second / moves a finished game had (independent of where the
+                    # pre-rolled openings put the games of the first generation)
+                    "games_per_hour": round(moves_per_sec * 3600 / mean_len, 1) if mean_len else None,
                     "mean_moves_per_finished_game": round(mean_len, 1) if mean_len else None,
-                    # the same rate from the move counter: searched moves per second / moves a finished game had
-                    "games_per_hour_from_move_rate": round(moves_per_sec * 3600 / mean_len, 1) if mean_len else None,
+                    # games that FINISHED inside the window / wall (reference definition, src/selfplay/pipe.cc:272-280, but the
+                    # window's games started at pre-rolled positions: an upper bound, kept for continuity with round 2)
+                    "games_per_hour_prerolled_window": round(games / el * 3600, 1) if games else None,
                     "prerolled_moves": int(fin["moves"]),
                     "mean_batch": round(tot["nn_queries"] / max(tot["nn_batches"], 1), 1),
                     "exchange_rounds": pg.rounds, "halt_seen": bool(pg.any_halt),
@@ -420,7 +430,7 @@ def main():
                                                      "conv_board_kernel<4> (conv3x3_tower: 256->256 3x3, one workgroup per board)" if fp16 else
                                                      "conv_mfma_kernel<float> (conv3x3_tower: 256->256 3x3, v_mfma_f32_16x16x4_f32)"),
                          "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4) if ach else None, **hbm_traffic(fp16),
+                         "frac": round(ach / peak, 4) if ach else None, **hbm_traffic(fp16, dominant),
                          "launches_timed": int(stat.launches),
                          "avg_launch_us": round(stat.total_ms / max(stat.launches, 1) * 1e3, 2),
                          "flops_per_launch": stat.flops / max(stat.launches, 1)},

@@ -672,50 +672,44 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
 
     // ---- pooling: per lane over its column tiles (valid pixels only), then over the 16 pixel lanes of a row
     const int2* pix = sp.b.tab_pix + (size_t)tile * kBoardPT + col0 * 16 + px;
-    f32x4 s4[WMT], m4[WMT];
-#pragma unroll
-    for (int i = 0; i < WMT; ++i) { s4[i] = f32x4{0.f, 0.f, 0.f, 0.f}; m4[i] = f32x4{-5000.f, -5000.f, -5000.f, -5000.f}; }
     // a one-sample tile has its unused pixel slots at the end: only the wave's LAST column tile can hold any, so only
-    // that one is masked (the others are summed with packed adds)
+    // that one is masked (the others are summed with packed adds).  One row tile at a time: eight live temporaries
+    // beside the 192 accumulators instead of thirty-two (hipcc parked accumulators in scratch for the wider form --
+    // 17 MB of spill stores per launch in the PMC pass)
     const bool last_valid = nj <= 0 ? false : sp.b.arith ? (col0 + nj - 1) * 16 + px < bs * bs : pix[(nj - 1) * 16].y >= 0;
-    static_for<NJ>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        if (j < nj) {
-            const bool valid = j + 1 < nj ? true : last_valid;
 #pragma unroll
-            for (int i = 0; i < WMT; ++i) {
+    for (int i = 0; i < WMT; ++i) {
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, m4 = {-5000.f, -5000.f, -5000.f, -5000.f};
+        static_for<NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j < nj) {
                 const f32x4 v = acc[i][j];
                 if (j + 1 < nj) {  // wave-uniform
-                    s4[i] += v;
+                    s4 += v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m4[i][r] = fmaxf(m4[i][r], v[r]);
+                    for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], v[r]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        s4[i][r] += valid ? v[r] : 0.f;
-                        m4[i][r] = valid ? fmaxf(m4[i][r], v[r]) : m4[i][r];
+                        s4[r] += last_valid ? v[r] : 0.f;
+                        m4[r] = last_valid ? fmaxf(m4[r], v[r]) : m4[r];
                     }
                 }
             }
-        }
-    });
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
+        });
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float a = s4[i][r], b = m4[i][r];
+            float a = s4[r], b = m4[r];
             a += row_ror<8>(a); b = fmaxf(b, row_ror<8>(b));
             a += row_ror<4>(a); b = fmaxf(b, row_ror<4>(b));
             a += row_ror<2>(a); b = fmaxf(b, row_ror<2>(b));
             a += row_ror<1>(a); b = fmaxf(b, row_ror<1>(b));
-            s4[i][r] = a; m4[i][r] = b;
+            s4[r] = a; m4[r] = b;
         }
-    if (px == 0) {
-#pragma unroll
-        for (int i = 0; i < WMT; ++i) {
+        if (px == 0) {
             const int c0 = wave_m * WMT * 16 + i * 16 + 4 * q;
-            *(f32x4*)(psum + wave_n * KO_T + c0) = s4[i];
-            *(f32x4*)(pmax + wave_n * KO_T + c0) = m4[i];
+            *(f32x4*)(psum + wave_n * KO_T + c0) = s4;
+            *(f32x4*)(pmax + wave_n * KO_T + c0) = m4;
         }
     }
     if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the images have landed
