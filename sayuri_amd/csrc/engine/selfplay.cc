@@ -8,7 +8,6 @@
 #include <malloc.h>
 #include <pthread.h>
 #include <sched.h>
-#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -257,7 +256,14 @@ std::string SelfplayEngine::SelectWeights() const {
 
 bool SelfplayEngine::ShouldHalt() const {
     if (opt_.selfplay.weights_dir.empty()) return false;
-    return SelectWeights() != opt_.selfplay.weights_file;
+    const std::string newest = SelectWeights();
+    if (newest == opt_.selfplay.weights_file) return false;
+    // two spellings of one file (trailing slash in weights_dir, relative vs absolute path, a symlink) are not a newer
+    // network: compare the files, not the strings
+    struct stat a, b;
+    if (stat(newest.c_str(), &a) == 0 && stat(opt_.selfplay.weights_file.c_str(), &b) == 0 && a.st_dev == b.st_dev && a.st_ino == b.st_ino)
+        return false;
+    return true;
 }
 
 bool SelfplayEngine::Step(int g) {
@@ -563,12 +569,24 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
             std::lock_guard<std::mutex> lock(data_mu_);
             if (error_.empty()) error_ = e.what();
             stop_.store(true);
+        } catch (...) {  // nothing may leave a fiber's entry silently: the main loop would wait for its game forever
+            std::lock_guard<std::mutex> lock(data_mu_);
+            if (error_.empty()) error_ = "self-play worker: unknown exception";
+            stop_.store(true);
         }
     };
     sayuri_fiber::FiberPool pool;
     if (fiber_threads > 0) {
         for (int g = 0; g < games; ++g) pool.Add([&game_loop, g] { game_loop(g); });
-        workers.emplace_back([&pool, fiber_threads, &thread_start] { pool.Run(fiber_threads, thread_start); });
+        workers.emplace_back([this, &pool, fiber_threads, &thread_start] {
+            try {
+                pool.Run(fiber_threads, thread_start);
+            } catch (const std::exception& e) {  // e.g. a fiber stack that could not be mapped: end the run with an error
+                std::lock_guard<std::mutex> lock(data_mu_);
+                if (error_.empty()) error_ = std::string("fiber pool: ") + e.what();
+                stop_.store(true);
+            }
+        });
     } else {
         for (int g = 0; g < games; ++g)
             workers.emplace_back([g, &thread_start, &game_loop] {

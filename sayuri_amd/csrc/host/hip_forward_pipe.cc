@@ -443,6 +443,8 @@ void HipForwardPipe::PumpLoop(Graph* g) {
         const auto t0 = clock::now();
         g->epoch.fetch_add(1, std::memory_order_release);
         FutexWakeAll(&g->epoch);
+        // fibers parked in Reserve() on the epoch word are woken by their scheduler threads, which may be asleep themselves
+        if (fibers_seen_.load(std::memory_order_relaxed)) sayuri_fiber::NotifyAll();
         pump_ns_[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0).count();
     };
     // close the fill set and point callers at the next one of the ring

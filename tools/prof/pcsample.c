@@ -11,6 +11,7 @@
 #include <sys/time.h>
 #include <ucontext.h>
 #include <unistd.h>
+#include <sys/auxv.h>
 
 #define CAP (1 << 22)
 static void** g_pc;
@@ -49,7 +50,21 @@ __attribute__((destructor)) static void stop(void) {
         Dl_info di;
         const char* nm = "?";
         const char* fl = "?";
-        if (dladdr(g_pc[i], &di)) { if (di.dli_sname) nm = di.dli_sname; if (di.dli_fname) fl = di.dli_fname; }
+        static char unk[4096][48];
+        static int nunk;
+        unsigned long vdso = getauxval(AT_SYSINFO_EHDR);
+        if (vdso && (unsigned long)g_pc[i] >= vdso && (unsigned long)g_pc[i] < vdso + 0x4000) { nm = "[vdso] (clock_gettime ...)"; fl = "vdso"; }
+        else if (dladdr(g_pc[i], &di)) {
+            if (di.dli_fname) fl = di.dli_fname;
+            if (di.dli_sname) nm = di.dli_sname;
+            else if (nunk < 4096) {  /* no symbol: bucket by 4 KiB page offset inside the module */
+                snprintf(unk[nunk], sizeof unk[0], "+0x%lx", ((unsigned long)g_pc[i] - (unsigned long)di.dli_fbase) & ~0xfful);
+                int u;
+                for (u = 0; u < nunk; ++u) if (!strcmp(unk[u], unk[nunk])) break;
+                nm = unk[u];
+                if (u == nunk) ++nunk;
+            }
+        }
         int k;
         for (k = 0; k < ne; ++k) if (e[k].name == nm || !strcmp(e[k].name, nm)) break;
         if (k == ne && ne < 65536) { e[ne].name = nm; e[ne].file = fl; ++ne; }
