@@ -146,6 +146,7 @@ private:
     float policy_;
     int visits_{0};
     std::int16_t vertex_;
+    std::int16_t inflated_hi_{0};  // every child at an index >= this is still a bare edge (Inflate keeps it; selection stops there)
     std::uint8_t color_{sayuri_go::kWall}; // side to move here; kWall while there are no children
     Status status_{kActive};
     bool expanded_{false};
