@@ -1,6 +1,8 @@
 #include "tree.h"
 
 #include <algorithm>
+#include <functional>
+#include <cstring>
 #include <cmath>
 #include <limits>
 #include <numeric>
@@ -117,7 +119,31 @@ bool Node::ExpandChildren(Network& network, GameState& state, NodeEvals& evals, 
     // best policy first (ties: higher vertex first).  The reference stable-sorts the reversed range ascending by (policy,
     // vertex); vertices are unique, so that order is total and a plain descending sort gives the same sequence without the
     // merge buffer stable_sort allocates
-    std::sort(list.begin(), list.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a > b; });
+    // Non-negative floats order like their bit patterns, so (policy bits << 16 | vertex) sorted as one integer is that same
+    // order at a third of the cost of comparing pairs (the sort was the largest single item of an expansion); anything
+    // else (a negative or NaN policy: never from a softmax) takes the pair comparison.
+    {
+        std::uint64_t keys[kMaxPoints + 1];
+        bool plain = true;
+        for (int i = 0; i < list_n; ++i) {
+            const float p = list_buf[i].first;
+            std::uint32_t bits;
+            std::memcpy(&bits, &p, sizeof(bits));
+            plain = plain && p >= 0.0f && bits != 0x80000000u && list_buf[i].second >= 0 && list_buf[i].second < 65536;
+            keys[i] = (static_cast<std::uint64_t>(bits) << 16) | static_cast<std::uint64_t>(list_buf[i].second & 0xffff);
+        }
+        if (plain) {
+            std::sort(keys, keys + list_n, std::greater<std::uint64_t>());
+            for (int i = 0; i < list_n; ++i) {
+                const std::uint32_t bits = static_cast<std::uint32_t>(keys[i] >> 16);
+                float p;
+                std::memcpy(&p, &bits, sizeof(p));
+                list_buf[i] = std::make_pair(p, static_cast<int>(keys[i] & 0xffff));
+            }
+        } else {
+            std::sort(list.begin(), list.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a > b; });
+        }
+    }
     children_.reserve(list.size());
     for (const auto& e : list) children_.emplace_back(e.second, e.first);
     expanded_ = true;
