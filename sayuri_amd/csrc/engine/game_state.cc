@@ -194,9 +194,16 @@ std::vector<bool> GameState::GetStrictSafeArea() const {
     return std::vector<bool>(buf, buf + GetNumIntersections());
 }
 
+// The area cache below is written from const methods (mutable members): a GameState may be READ by one thread at a
+// time -- every game, fork and search in this engine owns its states, nothing shares one across threads.  The key mixes
+// the board size into the position hash, so a state that is Reset() to another size cannot meet a stale entry.
+static inline std::uint64_t AreaKey(std::uint64_t ko_hash, int board_size) {
+    return ko_hash ^ (static_cast<std::uint64_t>(board_size) * 0x9e3779b97f4a7c15ULL);
+}
+
 void GameState::SafeAreaCached(bool* safe) const {
     const int n = GetNumIntersections();
-    const std::uint64_t key = board_.KoHash();
+    const std::uint64_t key = AreaKey(board_.KoHash(), GetBoardSize());
     if (area_key_ == key && (area_have_ & 1)) {
         for (int i = 0; i < n; ++i) safe[i] = (area_safe_[i >> 6] >> (i & 63)) & 1;
         return;
@@ -212,7 +219,7 @@ void GameState::SafeAreaCached(bool* safe) const {
 
 void GameState::ScoreAndSafeAreaCached(int* owner, bool* safe) const {
     const int n = GetNumIntersections();
-    const std::uint64_t key = board_.KoHash();
+    const std::uint64_t key = AreaKey(board_.KoHash(), GetBoardSize());
     if (area_key_ == key && (area_have_ & 3) == 3) {
         for (int i = 0; i < n; ++i) {
             safe[i] = (area_safe_[i >> 6] >> (i & 63)) & 1;
