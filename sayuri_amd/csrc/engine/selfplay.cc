@@ -512,11 +512,23 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
     int fiber_threads = 0;
     if (opt_.selfplay.game_threads > 0) fiber_threads = std::min(opt_.selfplay.game_threads, games);
     else if (opt_.selfplay.game_threads == 0 && games >= 256) fiber_threads = std::min(games, std::max(8, 4 * cores));
-    auto thread_start = [&cpus](int idx) {
+    // One process per GPU on a node: every rank would otherwise pin its threads to the same first CPUs of the (shared)
+    // affinity mask.  Each local rank takes its own contiguous slice of the mask.
+    size_t cpu_lo = 0, cpu_n = cpus.size();
+    {
+        const char* lw = std::getenv("LOCAL_WORLD_SIZE");
+        const char* lr = std::getenv("LOCAL_RANK");
+        const int n = lw ? std::atoi(lw) : 1, r = lr ? std::atoi(lr) : 0;
+        if (n > 1 && r >= 0 && r < n && cpus.size() >= static_cast<size_t>(n)) {
+            cpu_n = cpus.size() / static_cast<size_t>(n);
+            cpu_lo = static_cast<size_t>(r) * cpu_n;
+        }
+    }
+    auto thread_start = [&cpus, cpu_lo, cpu_n](int idx) {
         if (cpus.size() > 1) {
             cpu_set_t one;
             CPU_ZERO(&one);
-            CPU_SET(cpus[static_cast<size_t>(idx) % cpus.size()], &one);
+            CPU_SET(cpus[cpu_lo + static_cast<size_t>(idx) % cpu_n], &one);
             pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
         }
         // (no malloc warm-up: the search trees live in per-game TreeArenas that map their own slabs -- tree_arena.h -- and
