@@ -611,8 +611,11 @@ void Search::GatherData(const GameState& state, ComputationResult& result, bool 
     d.score_lead = result.root_score_lead;
     d.score_stddev = result.root_score_stddev;
     d.q_stddev = result.root_eval_stddev;
-    d.planes.resize(static_cast<size_t>(43 * state.GetNumIntersections()));
-    Encoder::Planes(state, 0, -1, d.planes.data());
+    {
+        sayuri_host::PackedPlanes pp;
+        Encoder::Packed(state, 0, -1, &pp);  // the same planes Encoder::Planes(state, 0, -1) fills, bit-packed
+        d.plane_bits.assign(&pp.bits[0][0], &pp.bits[0][0] + static_cast<size_t>(pp.binary_planes) * sayuri_host::PackedPlanes::kWords);
+    }
     d.probabilities = result.target_policy_dist;
     d.wave = state.GetWave();
     d.rule = state.GetScoringRule() == kAreaScoring ? 0.f : 1.f;
@@ -714,15 +717,17 @@ void TrainingData::StreamOut(std::ostream& out) const {
     out << version << std::endl << mode << std::endl;
     out << board_size << std::endl << komi << std::endl << rule << std::endl << wave << std::endl;
     // binary planes, four cells per hex digit (lowest bit first), a trailing 0/1 when the area is not a multiple of 4
-    const size_t channels = 43, saved = channels - 6;
-    const size_t spatial = planes.size() / channels;
+    constexpr size_t kW = sayuri_host::PackedPlanes::kWords;
+    const size_t saved = plane_bits.size() / kW;  // 43 - 6 planes
+    const size_t spatial = static_cast<size_t>(board_size) * static_cast<size_t>(board_size);
+    auto bit = [&](size_t p, size_t i) -> int { return static_cast<int>((plane_bits[p * kW + (i >> 5)] >> (i & 31)) & 1u); };
     for (size_t p = 0; p < saved; ++p) {
         for (size_t i = 0; i + 4 <= spatial; i += 4) {
             int hex = 0;
-            for (int b = 0; b < 4; ++b) hex += static_cast<int>(planes[i + spatial * p + static_cast<size_t>(b)]) << b;
+            for (size_t b = 0; b < 4; ++b) hex += bit(p, i + b) << b;
             out << std::hex << hex;
         }
-        if (spatial % 4 != 0) out << static_cast<bool>(planes[spatial * (p + 1) - 1]);
+        if (spatial % 4 != 0) out << static_cast<bool>(bit(p, spatial - 1));
         out << std::dec << std::endl;
     }
     out << (side_to_move == kBlack ? 1 : 0) << std::endl;

@@ -27,7 +27,11 @@ struct TrainingData {
     int version{2}, mode{0}, board_size{0};
     float komi{0};
     int side_to_move{0};
-    std::vector<float> planes, probabilities, auxiliary_probabilities;
+    // the 37 binary input planes as bit planes, [plane][12 words], bit y*bs+x (what the record writes, 4 cells per hex digit):
+    // 1.8 KB per move instead of 62 KB of fp32 planes -- a game holds its ~375 samples until it ends, which was 12 GB of the
+    // resident set of a 512-game rank (and as much again of malloc arenas that do not shrink)
+    std::vector<std::uint32_t> plane_bits;
+    std::vector<float> probabilities, auxiliary_probabilities;
     std::vector<int> ownership;
     int result{0};
     float q_value{0}, avg_q_value{0}, short_avg_q{0}, middle_avg_q{0}, long_avg_q{0};
@@ -112,6 +116,10 @@ private:
     GameState& root_state_;
     GameState last_state_;
     Network& network_;
+public:
+    std::size_t arena_bytes() const { return arena_.slab_bytes(); }  // memory statistics (SAYURI_MEMSTAT)
+    std::size_t arena_live_blocks() const { return arena_.live_blocks(); }
+private:
     static constexpr std::size_t kArenaKeepBytes = std::size_t(8) << 20;  // slabs a game keeps across fresh roots
     TreeArena arena_;             // before root_: the tree is destroyed first, its blocks go back into a living arena
     std::unique_ptr<Node> root_;

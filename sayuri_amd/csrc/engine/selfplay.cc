@@ -644,6 +644,18 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
         if (seconds > 0 || stop_.load()) stop_.store(true);
     }
     for (auto& w : workers) w.join();
+    if (std::getenv("SAYURI_MEMSTAT")) {  // where the resident set of a long run is (stderr, once, after the workers have ended)
+        std::size_t slabs = 0, live = 0, biggest = 0;
+        for (int g = 0; g < games; ++g) {
+            const std::size_t b = engine_.search(g).arena_bytes();
+            slabs += b;
+            biggest = std::max(biggest, b);
+            live += engine_.search(g).arena_live_blocks();
+        }
+        const struct mallinfo2 mi = mallinfo2();
+        std::fprintf(stderr, "[memstat] games %d: tree arenas %.1f MB (largest %.1f MB, %zu live blocks); malloc: in use %.1f MB, free in arenas %.1f MB, mmapped %.1f MB\n",
+                     games, slabs / 1048576.0, biggest / 1048576.0, live, mi.uordblks / 1048576.0, mi.fordblks / 1048576.0, mi.hblkhd / 1048576.0);
+    }
     if (!timed_out) snapshot(st);
     writer_running_.store(false);
     writer.join();
