@@ -321,14 +321,21 @@ int Position::ChainMembers(int v, int* out) const {
 // ---------------------------------------------------------------------------------------------
 // Ladder reading.
 int Position::ChainLiberties(int v, int* buf, int& n) const {
+    // The chain's liberty count is kept incrementally, so the walk can stop as soon as every liberty has been met (same
+    // entries in the same order as the full walk): into an empty list that is `total` new entries; a chain in atari is done
+    // at its first empty neighbour whatever the list holds.  Ladders walk a growing chain at every step of the chase.
+    const int total = libs_[head_[v]];
+    const bool fresh = n == 0;
     int found = 0, p = v;
     do {
         for (int k = 0; k < 4; ++k) {
             const int a = p + dir_[k];
-            if (cell_[a] == kEmpty && !Contains(buf, n, a)) {
+            if (cell_[a] != kEmpty) continue;
+            if (!Contains(buf, n, a)) {
                 buf[n++] = a;
                 ++found;
             }
+            if (total == 1 || (fresh && found == total)) return found;
         }
         p = next_[p];
     } while (p != v);
