@@ -45,6 +45,11 @@ struct BoardParams {
     int arith;                // 1: every tile is ONE sample and all samples have one size (tile = sample): the kernels compute
                               // the table entries they need (a few VALU ops) instead of waiting for them at the head of the
                               // prologue and of the epilogue
+    // persistent tower launch only (conv_tower.h, CHAIN main loop): w_next = the weights of the run's next layer, whose first
+    // group this layer's last K group brings into ring slot 0 (null: no hand-over); w_ready = 1: the previous layer did that
+    // for this one, the prologue does not ask for group 0 again
+    const void* w_next;
+    int w_ready;
 };
 
 // Which samples share a tile: consecutive samples OF ONE BOARD SIZE, greedily, while pixels <= 384, halo positions
@@ -238,10 +243,11 @@ template <int N, int ND, int NA> __device__ __forceinline__ void wait_vm_regs(f1
 // The main loop: returns with the accumulators (bias included) of this wave's (WMT x 12) output tiles.
 // `full` = the wave's 12th column tile is in use (else its MFMAs are skipped; other unused tiles are computed on
 // whatever the padded pixel slots point at and never stored).
-template <int WMT, bool DBG = false>
+template <int WMT, bool DBG = false, int CHAIN = 0>  // CHAIN: 1 = may find its first weight group in place, 2 = and hands over to the next layer
 __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
                                                int kt, int wave, int lane, int col0, bool full, int bs,
-                                               unsigned long long* dbg = nullptr) {
+                                               unsigned long long* dbg = nullptr,
+                                               const __attribute__((address_space(4))) BoardParams* chain = nullptr) {
     using Cfg = BoardCfg<WMT>;
     using namespace board_sched;
     constexpr int KO_T = Cfg::KO_T, NJ = Cfg::NJ, AI = Cfg::AI, NA = WMT;
@@ -275,10 +281,13 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
         glds16_s(lane16, base, a_ring + (G & 1) * Cfg::A_BYTES + dx * Cfg::A_TAP_BYTES + (kgq * KO_T + part * 64) * 16);
     };
     // the first weight group needs no table: it goes out first and lands while the tables are being read
+    // (CHAIN: unless the previous layer of the run left it in slot 0 already)
+    if (!CHAIN || !bp.w_ready) {
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
+        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int i = 0; i < AI; ++i) issue_a(0, dx, i);
+            for (int i = 0; i < AI; ++i) issue_a(0, dx, i);
+    }
 
     // every table read goes out before the halo DMA (whose "memory" clobber keeps them above it): the halo sources are
     // waited for first, the pixel positions and the bias arrive while the DMA is being issued
@@ -357,7 +366,20 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
                 t_sync += t1 - t0;
                 if (dbg && G == 0) dbg[2] = t1;
             }
-            const bool more_a = G + 1 < ngroups;
+            bool more_a = G + 1 < ngroups;
+            int Gn = G + 1;
+            if constexpr (CHAIN == 2 && row == 2) {
+                // the run's next layer: its first weight group goes into slot 0 while this layer's last group (slot 1: the
+                // host hands over only after an even number of groups) is being multiplied.  The pointer is read here, behind
+                // an opaque point, so that it does not occupy two SGPRs through the K loop.
+                if (!more_a) {
+                    const __attribute__((address_space(4))) BoardParams* bq = chain;
+                    asm volatile("" : "+s"(bq));
+                    const unsigned char* wn = (const unsigned char*)bq->w_next;
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wn)::"memory");  // a scalar load: retired before the counted LDS reads begin
+                    if (wn) { gw = wn; Gn = 0; more_a = true; }
+                }
+            }
             const uint32_t abase = a_ring + (G & 1) * Cfg::A_BYTES + arow_off;
             f16x8 afr[NA], bfr[3];
             ds_read16<0>(bfr[0], bb[0]);
@@ -372,7 +394,7 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
                 // DMA of the next group / chunk, front-loaded: weights at blocks 0, 3, 6, ..., halo pieces at blocks 1
                 // and 4 of rows 0 and 1 (the next chunk's slot is free from the start of this chunk)
                 if constexpr (b % 3 == 0 && b / 3 < 3 * AI) {
-                    if (more_a) issue_a(G + 1, (b / 3) / AI, (b / 3) % AI);
+                    if (more_a) issue_a(Gn, (b / 3) / AI, (b / 3) % AI);
                 }
                 if constexpr ((b == 1 || b == 4) && row < 2) {
                     if (more_b) issue_b(chunk + 1, row * 2 + (b == 4 ? 1 : 0));
@@ -425,7 +447,8 @@ template <int ACT> __device__ __forceinline__ f16x8 board_act8(const float (&v)[
 
 // One (column tile, row-tile pair) of the epilogue: swap, + residual, activation, 16-byte store.
 template <int ACT>
-__device__ __forceinline__ void board_store_pair(f32x4 a, f32x4 b, bool with_res, const f16x8& rr, f16* __restrict__ dst, bool ok) {
+__device__ __forceinline__ void board_store_pair(f32x4 a, f32x4 b, bool with_res, const f16x8& rr, unsigned char* __restrict__ gbase,
+                                                 uint32_t voff, bool ok) {
     swap16(a, b);
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     if (with_res) {
@@ -433,7 +456,7 @@ __device__ __forceinline__ void board_store_pair(f32x4 a, f32x4 b, bool with_res
         for (int q = 0; q < 8; ++q) v[q] += (float)rr[q];
     }
     const f16x8 h = board_act8<ACT>(v);
-    if (ok) *(f16x8*)dst = h;
+    if (ok) *(f16x8*)(gbase + voff) = h;  // uniform base + 32-bit lane offset: one VGPR of address, no 64-bit arithmetic per store
 }
 
 // Epilogue: optional residual, activation, fp16 NHWC store -- straight from the accumulators (bias is in).
@@ -469,6 +492,18 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
         int orow[NJ];
         f16x8 rrd[ND > 0 ? ND : 1];
         const bool with_res = gres != nullptr;
+        // store addresses: output row * row_bytes + channel bytes, all in 32 bits (an activation buffer is far below 4 GiB);
+        // the row pitch sits in a VGPR the compiler cannot re-read from the argument block (it did: one scalar load and
+        // one lgkmcnt(0) per column tile)
+        int row_bytes = p.cout_s * 2;
+        asm volatile("" : "+v"(row_bytes));
+        uint32_t cb2[NPAIR > 0 ? NPAIR : 1];
+        bool cok[NPAIR > 0 ? NPAIR : 1];
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            cb2[pr] = (uint32_t)cb[pr] * 2u;
+            cok[pr] = cb[pr] * 2 < row_bytes;
+        }
         const uint32_t my_lds = (uint32_t)(uintptr_t)smem + wave * kWaveLds;
         // Column tiles [0, JH) are finished while the residual rows of [JH, nj) are still on their way.  Issue order: the LDS
         // pieces of the first half, the LDS pieces of the second half, last the pieces that go to registers (they belong to
@@ -487,6 +522,11 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
             } else {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) orow[j] = j < nj ? pix[j * 16].y : -1;
+                // the table rows have arrived HERE: left pending, hipcc puts an s_waitcnt vmcnt(0) in front of every column
+                // tile's first use -- behind the join with the computed path, so that every path waited for the previous
+                // tile's stores to be acknowledged
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(orow[j]));
             }
         };
         auto lds_slot = [](int j, int pr) { return (j < JH ? j : j - NRT) * NPAIR + pr; };
@@ -533,9 +573,8 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
                         if constexpr (j >= JH && j < JH + NRT) rr = rrd[(j - JH) * NPAIR + pr];
                         else rr = *(const f16x8*)(smem + wave * kWaveLds + lds_slot(j, pr) * 1024 + lane * 16);
                     }
-                    const bool ok = orow[j] >= 0 && cb[pr] < p.cout_s;
-                    board_store_pair<ACT>(acc[2 * pr][j], acc[2 * pr + 1][j], with_res, rr,
-                                          gout + ((size_t)(ok ? orow[j] : 0) * p.cout_s + cb[pr]), ok);
+                    board_store_pair<ACT>(acc[2 * pr][j], acc[2 * pr + 1][j], with_res, rr, (unsigned char*)gout,
+                                          __umul24((unsigned)(orow[j] >= 0 ? orow[j] : 0), (unsigned)row_bytes) + cb2[pr], orow[j] >= 0 && cok[pr]);
                 }
             }
         });
@@ -573,8 +612,8 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
 #pragma unroll
             for (int pr = 0; pr < NPAIR; ++pr) {
                 const bool ok = my >= 0 && cb[pr] < p.cout_s;
-                board_store_pair<ACT>(acc[2 * pr][j], acc[2 * pr + 1][j], gres != nullptr, rr[j & 1][pr],
-                                      gout + ((size_t)(ok ? my : 0) * p.cout_s + cb[pr]), ok);
+                board_store_pair<ACT>(acc[2 * pr][j], acc[2 * pr + 1][j], gres != nullptr, rr[j & 1][pr], (unsigned char*)gout,
+                                      ((uint32_t)(ok ? my : 0) * (uint32_t)p.cout_s + (uint32_t)cb[pr]) * 2u, ok);
             }
             f32x4 v = acc[WMT - 1][j];
             if (gres) {

@@ -27,7 +27,7 @@
 
 namespace sayuri {
 
-constexpr int kTowerStride = 256;  // bytes per TowerLayer in the device table (tower_seam.py: STRIDE)
+constexpr int kTowerStride = 320;  // bytes per TowerLayer in the device table (tower_seam.py: STRIDE)
 
 // One convolution of the run: an element of the device table the launch walks.
 struct alignas(16) TowerLayer {
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(512, 2) void conv_tower_kernel(const TowerLayer* la
     f32x4 acc[WMT][kBoardNJ];
     {
         const BoardParams& bp = *(const BoardParams*)&L->sp.b;
-        board_mainloop<WMT>(bp, smem, acc, tile, 0, wave, lane, col0, nj == kBoardNJ, bs);
+        board_mainloop<WMT, false, SE ? 1 : 2>(bp, smem, acc, tile, 0, wave, lane, col0, nj == kBoardNJ, bs, nullptr,
+                                         (const __attribute__((address_space(4))) BoardParams*)&L->sp.b);
     }
     // everything the SE stage and the epilogue need is derived again from (table element, thread id, workgroup id)
     // behind an opaque point: nothing but those three stays alive across the K loop

@@ -143,6 +143,7 @@ struct ConvOverride { bool v0 = false, no_board = false; int wnt = 0; };
 struct EngineFlags {
     ConvOverride conv;
     bool tower = true, se_fused = true, heads_fused = true, arith = true;
+    bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     int compute_streams = 1;
     int board_kot = 0;                 // experiments: only this channel tile
     int act_override = -1;             // experiments: activation of every board convolution
@@ -155,6 +156,7 @@ struct EngineFlags {
             else if (!strncmp(e, "glds", 4)) { f.conv.no_board = true; (void)sscanf(e, "glds:%d", &f.conv.wnt); }
         }
         f.tower = !off("SAYURI_TOWER");
+        f.tower_chain = !off("SAYURI_TOWER_CHAIN");
         f.se_fused = !off("SAYURI_SE_FUSED");
         f.heads_fused = !off("SAYURI_HEADS_FUSED");
         f.arith = !getenv("SAYURI_NO_ARITH");
@@ -1511,6 +1513,16 @@ private:
             run[i].self = ts.dev + first + i;
             run[i].last = i + 1 == n ? 1 : 0;
         }
+        // weight hand-over (conv_board.h, CHAIN main loop): a plain layer without residual leaves the LDS alone after its K
+        // loop, so its last K group can bring in the next layer's first weight group.  Needs the same weight geometry on
+        // both sides (the piece addresses are computed with this layer's strides) and an even number of 32-channel chunks
+        // (the last group then sits in ring slot 1 and slot 0 is free).
+        for (int i = 0; i + 1 < n && flags_.tower_chain; ++i) {
+            const ConvParams &a = run[i].sp.b.c, &b = run[i + 1].sp.b.c;
+            if (run[i].has_se || a.res || a.cin_s != b.cin_s || a.ko_pad != b.ko_pad || (a.cin_s / kChunk) % 2) continue;
+            run[i].sp.b.w_next = b.w;
+            run[i + 1].sp.b.w_ready = 1;
+        }
         if (std::memcmp(run.data(), ts.cache.data() + first, sizeof(TowerLayer) * n) != 0) {
             const int st = ts.next_stage;
             ts.next_stage ^= 1;
@@ -1857,6 +1869,7 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
                 if (!tsrc || !tpix || !tcols) { cleanup(); return fail("test_conv: hipMalloc failed"); }
                 hipLaunchKernelGGL(board_setup_kernel, dim3(plan.ntiles), dim3(256), 0, 0, g, plan.npos, tsrc, tpix, tcols);
                 BoardParams bp;
+                std::memset(&bp, 0, sizeof(bp));
                 bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos; bp.dbg = nullptr;
                 bp.uniform_info = plan.uniform_info;
                 bp.arith = (plan.single && plan.uniform_info >= 0) ? 1 : 0;

@@ -24,7 +24,7 @@ Fails loudly when the assembly does not look like what it was written against.
 import re
 import sys
 
-STRIDE = 256       # sizeof(TowerLayer), conv_tower.h kTowerStride
+STRIDE = 320       # sizeof(TowerLayer), conv_tower.h kTowerStride
 LAST_OFFSET = 8    # offsetof(TowerLayer, last); has_se follows it
 LDS_BYTES = 160 * 1024
 
@@ -107,8 +107,9 @@ def main():
             f["scratch"], _ = directive(f["name"], "private_segment_fixed_size")
             f["vgprs"], _ = directive(f["name"], "next_free_vgpr")
             f["accum"], _ = directive(f["name"], "accum_offset")
-        if plain["vgprs"] != se["vgprs"] or plain["accum"] != se["accum"]:
-            die(f"width {w}: the two bodies split the register file differently")
+        if plain["accum"] != se["accum"]:
+            die(f"width {w}: the two bodies put their AGPRs at different offsets of the register file")
+        vgprs = max(plain["vgprs"], se["vgprs"])  # same accum_offset: the launch needs the larger of the two totals
         B = (max(plain["sgprs"], se["sgprs"]) + 1) & ~1
         if B + 4 > 102:
             die(f"width {w}: no four SGPRs left above the compiler's {B}")
@@ -167,7 +168,7 @@ def main():
 
         # ---- the launch kernel's descriptor
         scratch = max(plain["scratch"], se["scratch"])
-        for key, val in (("next_free_sgpr", B + 4), ("private_segment_fixed_size", scratch), ("enable_private_segment", 1 if scratch else 0),
+        for key, val in (("next_free_vgpr", vgprs), ("next_free_sgpr", B + 4), ("private_segment_fixed_size", scratch), ("enable_private_segment", 1 if scratch else 0),
                          ("group_segment_fixed_size", LDS_BYTES)):
             _, idx = directive(plain["name"], key)
             edits[idx] = [re.sub(r"\d+\s*$", str(val), lines[idx])]
@@ -185,12 +186,13 @@ def main():
             hi += 1
         seen = set()
         for k in range(lo, hi + 1):
-            for key, val in ((".group_segment_fixed_size:", LDS_BYTES), (".private_segment_fixed_size:", scratch), (".sgpr_count:", B + 4 + 6)):
-                if lines[k].strip().startswith(key):
+            for key, val in ((".group_segment_fixed_size:", LDS_BYTES), (".private_segment_fixed_size:", scratch), (".sgpr_count:", B + 4 + 6), (".vgpr_count:", vgprs),
+                             (".agpr_count:", vgprs - plain["accum"])):
+                if lines[k].strip().lstrip("- ").startswith(key):
                     edits[k] = [re.sub(r"\d+\s*$", str(val), lines[k])]
                     seen.add(key)
-        if len(seen) != 3:
-            die("metadata entry of " + plain["name"] + " lacks " + str(3 - len(seen)) + " expected keys")
+        if len(seen) != 5:
+            die("metadata entry of " + plain["name"] + " lacks " + str(5 - len(seen)) + " expected keys")
 
     out = []
     for k, ln in enumerate(lines):
