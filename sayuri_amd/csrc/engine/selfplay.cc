@@ -524,8 +524,9 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
             cpu_lo = static_cast<size_t>(r) * cpu_n;
         }
     }
-    auto thread_start = [&cpus, cpu_lo, cpu_n](int idx) {
-        if (cpus.size() > 1) {
+    const bool pin = std::getenv("SAYURI_NO_PIN") == nullptr;  // measuring aid: leave the worker threads to the scheduler
+    auto thread_start = [&cpus, cpu_lo, cpu_n, pin](int idx) {
+        if (pin && cpus.size() > 1) {
             cpu_set_t one;
             CPU_ZERO(&one);
             CPU_SET(cpus[cpu_lo + static_cast<size_t>(idx) % cpu_n], &one);

@@ -59,6 +59,7 @@ struct FiberPool::Fiber {
     int wait_value = 0;
     bool finished = false;
     void** scheduler_sp = nullptr;    // where the owning thread's context is saved while this fiber runs
+    long long stamp = 0;              // a word for the fiber's user (FiberStamp)
 };
 
 namespace {
@@ -98,6 +99,7 @@ sayuri_fiber_trampoline:
 )");
 
 bool InFiber() { return t_current != nullptr; }
+long long* FiberStamp() { return t_current ? &t_current->stamp : nullptr; }
 
 void WaitWhileEqual(const std::atomic<int>* addr, int value) {
     FiberPool::Fiber* f = t_current;

@@ -22,6 +22,7 @@ namespace sayuri_fiber {
 
 // True while the calling code runs on a fiber of a FiberPool.
 bool InFiber();
+long long* FiberStamp();  // a word of per-fiber storage (nullptr outside a fiber); the pipe's trace keeps a time stamp there
 // Suspend the calling fiber until *addr != value (checked by its scheduler thread whenever it looks for work).
 // Must only be called when InFiber().
 void WaitWhileEqual(const std::atomic<int>* addr, int value);

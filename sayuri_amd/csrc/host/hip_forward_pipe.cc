@@ -211,11 +211,29 @@ void HipForwardPipe::BuildGraphs() {
         }
         graphs_.push_back(std::move(g));
     }
+    trace_ = std::getenv("SAYURI_PIPE_TRACE") != nullptr;
+    if (const char* e = std::getenv("SAYURI_PIPE_TAIL")) tail_frac_ = std::atof(e);
     running_.store(true);
     for (auto& g : graphs_) g->pump = std::thread([this, gp = g.get()] { PumpLoop(gp); });
 }
 
+void HipForwardPipe::TraceDump() const {
+    std::fprintf(stderr, "[pipe trace] arrivals after the last finished batch, 250 us bins:");
+    for (const auto& a : trace_arrival_) std::fprintf(stderr, " %ld", a.load());
+    std::fprintf(stderr, "\n[pipe trace] fibers, last finished batch -> the game runs again:");
+    for (const auto& a : trace_resume_) std::fprintf(stderr, " %ld", a.load());
+    std::fprintf(stderr, "\n[pipe trace] fibers, the game runs again -> its next request:");
+    for (const auto& a : trace_think_) std::fprintf(stderr, " %ld", a.load());
+    std::fprintf(stderr, "\n[pipe trace] 85 %% rule, age of the running batch at the close:");
+    for (const auto& a : trace_tail_) std::fprintf(stderr, " %ld", a.load());
+    std::fprintf(stderr, "\n[pipe trace] batch sizes /16:");
+    for (const auto& a : trace_size_) std::fprintf(stderr, " %ld", a.load());
+    std::fprintf(stderr, "\n[pipe trace] closed: full %ld, idle-wait %ld, 85%%-rule %ld, stray %ld\n", trace_reason_[0].load(),
+                 trace_reason_[1].load(), trace_reason_[2].load(), trace_reason_[3].load());
+}
+
 void HipForwardPipe::DestroyGraphs() {
+    if (trace_ && !graphs_.empty()) TraceDump();
     running_.store(false);
     for (auto& g : graphs_) {
         {
@@ -448,7 +466,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
         pump_ns_[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0).count();
     };
     // close the fill set and point callers at the next one of the ring
-    auto close_and_rotate = [&] {
+    auto close_and_rotate = [&](int reason) {
         Staging& s = g->st[cur];
         const unsigned prev = s.reserved.fetch_or(Staging::kClosed, std::memory_order_acq_rel);
         const int n = static_cast<int>(std::min<unsigned>(prev & ~Staging::kClosed, static_cast<unsigned>(max_batch_)));
@@ -457,6 +475,10 @@ void HipForwardPipe::PumpLoop(Graph* g) {
             return;
         }
         if (static_cast<unsigned>(n) < want_now()) pump_ns_[5] += 1000;  // counts partial batches (reported /1000)
+        if (trace_) {
+            trace_size_[std::min(n / 16, 16)].fetch_add(1, std::memory_order_relaxed);
+            trace_reason_[reason].fetch_add(1, std::memory_order_relaxed);
+        }
         pending[n_pending] = cur;
         pending_n[n_pending++] = n;
         cur = (cur + 1) % K;
@@ -478,6 +500,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
             const int n = static_cast<int>(std::min<unsigned>(prev & ~Staging::kClosed, static_cast<unsigned>(max_batch_)));
             if (n == 0) { s.reserved.store(0, std::memory_order_release); continue; }
             pump_ns_[5] += 1000;
+            if (trace_) trace_reason_[3].fetch_add(1, std::memory_order_relaxed);
             pending[n_pending] = k;
             pending_n[n_pending++] = n;
             any = true;
@@ -518,6 +541,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
     };
     auto finish_oldest = [&] {
         Staging& s = g->st[inflight[0]];
+        if (trace_) trace_last_done_ns_.store(std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now().time_since_epoch()).count(), std::memory_order_relaxed);
         FinishBatch(g, &s, s.n_inflight);
         const auto now = clock::now();
         const double us = std::chrono::duration<double, std::micro>(now - gpu_busy_since).count();
@@ -548,7 +572,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
         }
         const unsigned c = count(s);
         if (c >= want_now() || (c > 0 && (cfg_.gpu_waittime_ms <= 0 || !running_.load()))) {
-            close_and_rotate();
+            close_and_rotate(0);
             timing = false;
             continue;
         }
@@ -556,7 +580,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
             // partial batch and an idle GPU: give stragglers gpu_waittime_ms, then send what is there
             if (!timing) { timing = true; first_seen = clock::now(); }
             if (clock::now() - first_seen >= std::chrono::milliseconds(cfg_.gpu_waittime_ms)) {
-                close_and_rotate();
+                close_and_rotate(1);
                 timing = false;
                 continue;
             }
@@ -565,8 +589,9 @@ void HipForwardPipe::PumpLoop(Graph* g) {
             // shortly before that batch is expected to finish, so its upload hides under the running batch's tail
             timing = false;
             const double run_us = std::chrono::duration<double, std::micro>(clock::now() - gpu_busy_since).count();
-            if (run_us >= 0.85 * gpu_batch_us) {
-                close_and_rotate();
+            if (run_us >= tail_frac_ * gpu_batch_us) {
+                if (trace_) trace_tail_[std::min(static_cast<int>(run_us / 250.0), 31)].fetch_add(1, std::memory_order_relaxed);
+                close_and_rotate(2);
                 continue;
             }
         } else {
@@ -601,6 +626,14 @@ HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData* input, const Pac
     if (echo.board_size < 2 || echo.board_size > board_size_)
         throw std::runtime_error("InputData board size does not fit the NN board");
     done->store(0, std::memory_order_relaxed);
+    if (trace_) {
+        const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        const long long d = now - trace_last_done_ns_.load(std::memory_order_relaxed);
+        trace_arrival_[std::min<long long>(std::max<long long>(d, 0) / 250000, 31)].fetch_add(1, std::memory_order_relaxed);
+        if (long long* st = sayuri_fiber::FiberStamp()) {
+            if (*st) trace_think_[std::min<long long>(std::max<long long>(now - *st, 0) / 250000, 31)].fetch_add(1, std::memory_order_relaxed);
+        }
+    }
     Graph* g = graphs_[next_graph_.fetch_add(1, std::memory_order_relaxed) % graphs_.size()].get();
     const unsigned cap = static_cast<unsigned>(max_batch_);
     const unsigned want = static_cast<unsigned>(std::min(forward_size_.load(std::memory_order_acquire), max_batch_));
@@ -647,6 +680,12 @@ OutputResult HipForwardPipe::ForwardAny(const InputData* in, const PackedPlanes*
         // M:N game scheduling (fiber.h): hand the request over and run this thread's other games until the batch is back
         const Ticket t = Reserve(in, pk, nullptr, &done, false, true);
         sayuri_fiber::WaitWhileEqual(&done, 0);
+        if (trace_) {
+            const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            const long long d = now - trace_last_done_ns_.load(std::memory_order_relaxed);
+            trace_resume_[std::min<long long>(std::max<long long>(d, 0) / 250000, 31)].fetch_add(1, std::memory_order_relaxed);
+            if (long long* st = sayuri_fiber::FiberStamp()) *st = now;
+        }
         Staging& s = *t.s;
         const int status = done.load(std::memory_order_acquire);
         if (status > 0) FillOutput(&s, t.slot, input, true, &out);

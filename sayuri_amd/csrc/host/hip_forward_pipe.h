@@ -185,6 +185,18 @@ private:
     std::atomic<unsigned> next_graph_{0};
     std::atomic<size_t> batches_{0}, evals_{0};
     mutable std::atomic<long long> pump_ns_[8] = {};
+    // SAYURI_PIPE_TRACE=1 (read once at construction; a measuring aid, printed to stderr when the graphs are destroyed):
+    // when do requests arrive relative to the last finished batch, how full are the batches and why were they closed
+    bool trace_{false};
+    std::atomic<long long> trace_last_done_ns_{0};
+    std::atomic<long> trace_arrival_[32] = {};  // 250 us bins since the last finished batch
+    std::atomic<long> trace_size_[17] = {};     // batch size / 16
+    std::atomic<long> trace_resume_[32] = {};   // fibers: batch finished -> the game runs again
+    std::atomic<long> trace_think_[32] = {};    // fibers: the game runs again -> its next request
+    std::atomic<long> trace_tail_[32] = {};     // 85 % rule: how long the running batch had been running when the set was closed
+    std::atomic<long> trace_reason_[4] = {};
+    double tail_frac_{0.85};                    // SAYURI_PIPE_TAIL (measuring aid): the fraction of a batch's time after which a partial set is enqueued behind it    // closed because: full, GPU idle + wait expired, 85 % of the running batch, stray
+    void TraceDump() const;
 };
 
 SAYURI_HOST_END

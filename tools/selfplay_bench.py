@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--game-threads", type=int, default=0, help="0 = one OS thread per game up to 1024 games, fibers above; N = fibers on N threads; -1 = threads")
+    ap.add_argument("--stagger", type=int, default=0, help="game g of the first generation starts after g * N / games policy-sampled moves (0: all from the empty board)")
     ap.add_argument("--boards", default="", help="comma list of board sizes drawn uniformly per game (mixed-size batches), e.g. 9,13,19")
     args = ap.parse_args()
 
@@ -51,7 +52,7 @@ def main():
                 random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
                 resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
                 selfplay_query=([f"bkp:{b}:7:1" for b in args.boards.split(",")] if args.boards else [f"bkp:{args.board}:7:1"]),
-                target_directory=args.out, game_threads=args.game_threads)
+                target_directory=args.out, game_threads=args.game_threads, stagger_moves=args.stagger)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.time()
