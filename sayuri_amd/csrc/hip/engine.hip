@@ -1349,9 +1349,16 @@ private:
             } else {
                 const int chunk = pack_input_chunk(slot_pix_, cs, (int)sizeof(T));
                 const size_t lds = (size_t)chunk * (cs * sizeof(T) + 16);
+                const size_t flat_lds = pack_input_flat_lds(slot_pix_, cs, (int)sizeof(T));
+                // a sample that fits 64 KiB of LDS whole and whose planes are below 2^16 floats: one workgroup per sample
+                const bool flat = flat_lds <= 64 * 1024 && (size_t)cin * board * board < 65536;
                 if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
-                        hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(kPackThreads), lds, stream_,
-                                           (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_, chunk);
+                        if (flat)
+                            hipLaunchKernelGGL(pack_input_flat_kernel<T>, dim3(geom_.n), dim3(kPackFlatThreads), flat_lds, stream_,
+                                               (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_);
+                        else
+                            hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(kPackThreads), lds, stream_,
+                                               (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_, chunk);
                     }))
                     return -1;
             }

@@ -39,3 +39,6 @@ python -c "import json;d=json.load(open('$O/config5.json'));print(d['value'], d[
 timeout 300 python bench.py --fp32 --steps 5 --warmup 1 --no-cpu-baseline --selfplay-seconds 0 > $O/bench_fp32.json 2> $O/bench_fp32.err; echo "fp32 rc=$?"
 python -c "import json;d=json.load(open('$O/bench_fp32.json'));print(d['value'], d['roofline'])"
 rm -rf $O/prof/*/p_kernel_trace.csv $O/prof/*/p_agent_info.csv
+# the default line, as the driver runs it (cpu_baseline and the self-play window included)
+timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$?"
+tail -1 $O/bench_default.json | cut -c1-600
