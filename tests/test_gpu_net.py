@@ -297,6 +297,31 @@ def test_computed_table_entries_match_the_tables(tmp_weights_dir, monkeypatch):
         assert np.abs(outs["0"][0]).max() > 0
 
 
+def test_persistent_tower_and_its_weight_hand_over_change_nothing(tmp_weights_dir, monkeypatch):
+    """One launch per convolution (SAYURI_TOWER=0), the persistent tower launch without the weight hand-over between its layers
+    (SAYURI_TOWER_CHAIN=0) and with it (the default) run the same compiled main loop, SE stage and epilogue: bit-identical
+    outputs -- on the 20b x 256 network (SE units included) at 256 boards (256-channel tile) and 40 boards (two 128-channel
+    tiles: no run), and on 13x13 as the NN board."""
+    g = Golden("net_20b256", tmp_weights_dir)
+    for board, n in ((19, 256), (19, 40), (13, 200)):
+        planes = W.synthetic_planes(n, board, seed=7 + n)
+        outs = {}
+        for mode, env in (("layers", {"SAYURI_TOWER": "0"}), ("run", {"SAYURI_TOWER_CHAIN": "0"}), ("run+handover", {})):
+            for k in ("SAYURI_TOWER", "SAYURI_TOWER_CHAIN"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            pipe = HipForwardPipe(g.weights_path, board_size=board, batch_size=n, fp16=True)
+            try:
+                outs[mode] = pipe.BatchForward(planes, [board] * n)
+            finally:
+                pipe.Destroy()
+        for other in ("run", "run+handover"):
+            for a, b in zip(outs["layers"], outs[other]):
+                assert np.array_equal(a, b), (board, n, other)
+        assert np.abs(outs["layers"][0]).max() > 0
+
+
 @pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
 def test_40b384_golden_parity(fp16, tmp_weights_dir):
     """BASELINE.json configs[4] network (40 blocks x 384 filters) on 19 / 13 / 9 boards against the reference's own
