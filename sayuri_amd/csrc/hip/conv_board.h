@@ -628,6 +628,12 @@ __device__ __forceinline__ void board_epilogue(const BoardParams& bp, unsigned c
     });
 }
 
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---- the squeeze-and-excitation unit inside the convolution (reference SEUnit::Forward, se_unit.cc:70-128) -----------
 // A block's last 3x3 convolution is followed by  pool -> FC(3C -> se, act) -> FC(se -> 2C) -> act(sigmoid(g) x + b + res).
 // When the workgroup holds one whole sample and every channel (KO_T == padded C), x is sitting in its accumulators:
@@ -719,30 +725,38 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, m4 = {-5000.f, -5000.f, -5000.f, -5000.f};
+        // max_raw: v_max_f32 as is -- fmaxf() makes hipcc quiet both operands first (three v_max per maximum: 1 264 of them in this
+        // stage); no NaN can come out of the MFMAs of finite weights and activations, and a NaN in would be one out either way.
+        // The guards are wave-uniform and must stay branches: if-converted, every tile carried both forms and 8 selects.
         static_for<NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if (j < nj) {
+            if (j + 1 < nj) {  // a full tile
+                asm volatile("");
                 const f32x4 v = acc[i][j];
-                if (j + 1 < nj) {  // wave-uniform
-                    s4 += v;
+                s4 += v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], v[r]);
-                } else {
+                for (int r = 0; r < 4; ++r) m4[r] = max_raw(m4[r], v[r]);
+            }
+        });
+        static_for<NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j + 1 == nj) {  // the wave's last tile: its unused pixel slots are masked
+                asm volatile("");
+                const f32x4 v = acc[i][j];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        s4[r] += last_valid ? v[r] : 0.f;
-                        m4[r] = last_valid ? fmaxf(m4[r], v[r]) : m4[r];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    s4[r] += last_valid ? v[r] : 0.f;
+                    m4[r] = max_raw(m4[r], last_valid ? v[r] : -5000.f);
                 }
             }
         });
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a = s4[r], b = m4[r];
-            a += row_ror<8>(a); b = fmaxf(b, row_ror<8>(b));
-            a += row_ror<4>(a); b = fmaxf(b, row_ror<4>(b));
-            a += row_ror<2>(a); b = fmaxf(b, row_ror<2>(b));
-            a += row_ror<1>(a); b = fmaxf(b, row_ror<1>(b));
+            a += row_ror<8>(a); b = max_raw(b, row_ror<8>(b));
+            a += row_ror<4>(a); b = max_raw(b, row_ror<4>(b));
+            a += row_ror<2>(a); b = max_raw(b, row_ror<2>(b));
+            a += row_ror<1>(a); b = max_raw(b, row_ror<1>(b));
             s4[r] = a; m4[r] = b;
         }
         if (px == 0) {
