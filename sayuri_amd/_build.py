@@ -65,7 +65,10 @@ def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
         [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-w",
          os.path.join(HIP_SRC, "tower.hip"), "-o", asm],
         [sys.executable, seam, asm, seamed] + (["--inv"] if os.environ.get("SAYURI_TOWER_INV") else []) +
-        (["--sleep=" + os.environ["SAYURI_TOWER_SLEEP"]] if os.environ.get("SAYURI_TOWER_SLEEP") else []),
+        (["--sleep=" + os.environ["SAYURI_TOWER_SLEEP"]] if os.environ.get("SAYURI_TOWER_SLEEP") else []) +
+        # where the plain body starts: 256-byte boundary + 32 bytes, the best of seven placements measured on two boxes
+        # (Kernel 1c); SAYURI_TOWER_ALIGN / SAYURI_TOWER_PAD build the others
+        ["--align=" + os.environ.get("SAYURI_TOWER_ALIGN", "8"), "--pad=" + os.environ.get("SAYURI_TOWER_PAD", "32")],
         [os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", seamed, "-o", elf],
         [os.path.join(LLVM_BIN, "ld.lld"), "-shared", elf, "-o", hsaco],
     ]

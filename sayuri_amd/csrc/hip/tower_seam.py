@@ -50,6 +50,11 @@ def main():
     # measuring builds only: --sleep=N parks every wave for N x 64 cycles in the seam (what does a stall cost a chip that
     # runs at its power limit?)
     sleep = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--sleep=")), 0)
+    # placement of the compiled bodies: each starts on a 2^align-byte boundary plus pad bytes (control never falls into a body,
+    # so the padding is never executed); the K loop sits at a fixed distance from the body's first instruction
+    align = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--align=")), 0)
+    pad = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--pad=")), 0)
+    place = ([f"\t.p2align {align}"] if align else []) + (["\ts_nop 0"] * (pad // 4))
     if len(args) != 2:
         die("usage: tower_seam.py in.s out.s [--inv]")
     lines = open(args[0]).read().split("\n")
@@ -134,7 +139,7 @@ def main():
                  f"\tv_lshl_or_b32 v0, {wv}, 6, v0",
                  "\ts_waitcnt lgkmcnt(0)",
                  "\ts_cmp_eq_u32 s5, 0",
-                 f"\ts_cbranch_scc1 {body_plain}"] + far_jump(body_se) + [
+                 f"\ts_cbranch_scc1 {body_plain}"] + far_jump(body_se) + place + [
                  f"{body_plain}:",
                  "\t; ---- compiled body (plain convolution)"]
         edits[plain["begin"]] = [lines[plain["begin"]]] + entry
