@@ -95,7 +95,7 @@ def test_persistent_tower_code_object():
     """The persistent tower launch (conv_tower.h) is hipcc's single-layer kernels with the layer loop closed in assembly
     (tower_seam.py).  The code object that ships inside libsayuri_hip.so must (i) be the one the build produced,
     (ii) carry the entry stub, the dispatch and one seam per body, (iii) keep every compiled body free of scratch traffic
-    inside its MFMA stream, and (iv) declare the resources of both bodies in the launch kernel's descriptor."""
+    inside its MFMA stream, start the plain body where the build places it, and (iv) declare the resources of both bodies in the launch kernel's descriptor."""
     so = _build.HIP_SO
     if not os.path.exists(so):
         _build.build_hip()
@@ -104,13 +104,14 @@ def test_persistent_tower_code_object():
     blob = open(hsaco, "rb").read()
     assert blob in open(so, "rb").read(), "libsayuri_hip.so does not embed lib/obj/tower.hsaco"
     asm = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", hsaco], capture_output=True, text=True, check=True).stdout
-    sections = {}
+    sections, address = {}, {}
     name = None
     for line in asm.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        m = re.match(r"^([0-9a-f]+) <(.+)>:$", line)
         if m:
-            name = m.group(1)
+            name = m.group(2)
             sections[name] = []
+            address[name] = int(m.group(1), 16)
         elif name and line.strip():
             sections[name].append(line.strip())
     for w in (4, 2):
@@ -121,6 +122,8 @@ def test_persistent_tower_code_object():
         disp = sections[f"tower{w}_dispatch"]
         assert any(i.startswith("s_mov_b64 exec, -1") for i in disp) and any(i.startswith("v_mbcnt_hi") for i in disp)
         assert any(i.startswith("s_setpc_b64") for i in disp), "far jump to the SE body"
+        # placement (tower_seam.py --align=8 --pad=N, N = 32 unless the build was told otherwise): measured, DESIGN.md Kernel 1c
+        assert address[f"tower{w}_body_plain"] % 256 == int(os.environ.get("SAYURI_TOWER_PAD", "32")), hex(address[f"tower{w}_body_plain"])
         for body in (f"tower{w}_body_plain", f"tower{w}_body_se"):
             ins = sections[body]
             mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
