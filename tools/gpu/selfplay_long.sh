@@ -1,6 +1,6 @@
 #!/bin/bash
 # the reference-definition games/hour run: configs[2] for 27 minutes from the empty board (finished games / wall over more than
-# one generation), then 90 s at 2048 and 8192 games
+# one generation); SHORT=1 adds 90 s at 2048 and 8192 games
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/sp
 SAYURI_MEMSTAT=1 timeout 1800 python tools/selfplay_bench.py --seconds 1620 --games 512 --num-games 100000 2> gpurun_out/sp/long.err | tail -1 > gpurun_out/sp/r03_selfplay_27min_512games.json
@@ -8,6 +8,7 @@ python -c "
 import json
 d=json.load(open('gpurun_out/sp/r03_selfplay_27min_512games.json'))
 print({k:d[k] for k in ('nn_evals_per_sec','games_done','games_per_hour','moves_per_sec','mean_batch','host_cpu_cores_busy','max_rss_gb','second_half')})"
+if [ -n "$SHORT" ]; then
 for g in 2048 8192; do
   SAYURI_MEMSTAT=1 timeout 300 python tools/selfplay_bench.py --seconds 90 --games $g 2>gpurun_out/sp/g$g.err | tail -1 > gpurun_out/sp/r03_selfplay_g$g.json
   python -c "
@@ -15,4 +16,5 @@ import json
 d=json.load(open('gpurun_out/sp/r03_selfplay_g$g.json'))
 print($g, {k:d[k] for k in ('nn_evals_per_sec','mean_batch','host_cpu_cores_busy','max_rss_gb','second_half')})"
 done
+fi
 grep -h memstat gpurun_out/sp/*.err
