@@ -68,7 +68,8 @@ def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
         (["--sleep=" + os.environ["SAYURI_TOWER_SLEEP"]] if os.environ.get("SAYURI_TOWER_SLEEP") else []) +
         # where the plain body starts: 256-byte boundary + 32 bytes, the best of seven placements measured on two boxes
         # (Kernel 1c); SAYURI_TOWER_ALIGN / SAYURI_TOWER_PAD build the others
-        ["--align=" + os.environ.get("SAYURI_TOWER_ALIGN", "8"), "--pad=" + os.environ.get("SAYURI_TOWER_PAD", "32")],
+        ["--align=" + os.environ.get("SAYURI_TOWER_ALIGN", "8"), "--pad=" + os.environ.get("SAYURI_TOWER_PAD", "32"),
+         "--pad-se=" + os.environ.get("SAYURI_TOWER_PAD_SE", "32")],
         [os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", seamed, "-o", elf],
         [os.path.join(LLVM_BIN, "ld.lld"), "-shared", elf, "-o", hsaco],
     ]

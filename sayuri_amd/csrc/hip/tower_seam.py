@@ -55,6 +55,8 @@ def main():
     align = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--align=")), 0)
     pad = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--pad=")), 0)
     place = ([f"\t.p2align {align}"] if align else []) + (["\ts_nop 0"] * (pad // 4))
+    pad_se = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--pad-se=")), 0)  # the SE body: its symbol is 256-aligned
+    place_se = ["\ts_nop 0"] * (pad_se // 4)
     if len(args) != 2:
         die("usage: tower_seam.py in.s out.s [--inv]")
     lines = open(args[0]).read().split("\n")
@@ -143,7 +145,7 @@ def main():
                  f"{body_plain}:",
                  "\t; ---- compiled body (plain convolution)"]
         edits[plain["begin"]] = [lines[plain["begin"]]] + entry
-        edits[se["begin"]] = [lines[se["begin"]], f"{body_se}:", "\t; ---- compiled body (convolution + SE unit)"]
+        edits[se["begin"]] = [lines[se["begin"]]] + place_se + [f"{body_se}:", "\t; ---- compiled body (convolution + SE unit)"]
 
         for tag, f in (("p", plain), ("s", se)):
             seam, done = f".Ltower{w}{tag}_seam", f".Ltower{w}{tag}_done"

@@ -124,6 +124,7 @@ def test_persistent_tower_code_object():
         assert any(i.startswith("s_setpc_b64") for i in disp), "far jump to the SE body"
         # placement (tower_seam.py --align=8 --pad=N, N = 32 unless the build was told otherwise): measured, DESIGN.md Kernel 1c
         assert address[f"tower{w}_body_plain"] % 256 == int(os.environ.get("SAYURI_TOWER_PAD", "32")), hex(address[f"tower{w}_body_plain"])
+        assert address[f"tower{w}_body_se"] % 256 == int(os.environ.get("SAYURI_TOWER_PAD_SE", "32")), hex(address[f"tower{w}_body_se"])
         for body in (f"tower{w}_body_plain", f"tower{w}_body_se"):
             ins = sections[body]
             mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
