@@ -144,7 +144,10 @@ private:
     int move_number_ = 0;
     std::uint64_t komi_hash_ = 0, scoring_hash_ = 0;
     int winner_ = kUndecided;
-    // cache of the pass-alive analysis (bit sets: 361 cells; owner as two planes black / white)
+    // cache of the pass-alive analysis (bit sets: 361 cells; owner as two planes black / white).  Written from const methods
+    // (SafeAreaCached / ScoreAndSafeAreaCached, hence Encoder::Planes / Packed on a const GameState&): a GameState belongs to ONE
+    // thread at a time -- every game / search owns its states; two threads encoding the same object would race on these fields.
+    // The key mixes the board size with the ko hash (AreaKey), so a Reset() to another size cannot hit a stale entry.
     mutable std::uint64_t area_key_ = 0;
     mutable std::uint8_t area_have_ = 0;  // bit 0: safe, bit 1: owner
     mutable std::uint64_t area_safe_[6] = {}, area_black_[6] = {}, area_white_[6] = {};

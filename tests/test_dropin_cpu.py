@@ -132,3 +132,17 @@ def test_eight_ranks_on_the_fake_device_halt_together(tmp_path):
     assert d["stopped_early_by_halt"] == list(range(8)), d
     assert len(set(d["exchange_rounds"])) == 1 and d["exchange_rounds"][0] >= 2, d["exchange_rounds"]
     assert all(x["nn_evals"] > 0 and x["mean_batch"] > 1 for x in d["per_rank"])
+
+
+def test_a_run_does_not_halt_over_its_own_network_spelled_differently(tmp_path):
+    """weights_dir with a trailing slash, weights_file without one (tools/fake8.py passes them so): ShouldHalt compares the
+    newest file of the directory with the loaded one by identity (st_dev, st_ino), so the run plays until its clock ends
+    (the reference returns the explicit weights_file from SelectWeights and never halts, engine.cc:63-90)."""
+    out = tmp_path / "fake1.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fake8.py"), "--ranks", "1", "--games", "8", "--playouts", "8",
+                        "--board", "7", "--seconds", "6", "--serial-us", "300", "--out", str(out)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(out.read_text())
+    assert d["ranks_reporting"] == 1 and d["stopped_early_by_halt"] == [] and d["halt_seen_by"] == [], d
+    assert d["per_rank"][0]["games_done"] > 8, d["per_rank"][0]  # more than one game per worker: worker 0 checked at least once

@@ -48,7 +48,8 @@ def child(args):
                 dirichlet_epsilon=0.25, dirichlet_init=0.03, dirichlet_factor=361, first_pass_bonus=1, random_moves_factor=0.1,
                 komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0, resign_playouts=80,
                 resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
-                selfplay_query=[f"bkp:{args.board}:7:1"], weights_dir=wdir, weights_file=wpath,
+                selfplay_query=[f"bkp:{args.board}:7:1"], weights_dir=wdir + "/", weights_file=wpath,  # another spelling of the directory:
+                # the halt check compares file identity (st_dev, st_ino), not strings -- a run must not halt over its own network
                 target_directory=os.path.join(args.work, f"out-r{rank}"))
     os.makedirs(opts["target_directory"], exist_ok=True)
     pg = PeriodicGather()
