@@ -271,6 +271,9 @@ def main():
                     help="also time configs[4]: 40-block x 384 net, batch 256 of mixed 9/13/19 boards (adds ~1 min of weight generation)")
     ap.add_argument("--selfplay-games", type=int, default=512, help="concurrent self-play games per GPU")
     ap.add_argument("--selfplay-visits", type=int, default=400)
+    ap.add_argument("--dist-backend", default=os.environ.get("SAYURI_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend of the multi-rank run: nccl (= RCCL, the default) or gloo (CPU tests on the "
+                         "fake device; also SAYURI_DIST_BACKEND)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -282,8 +285,11 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     from sayuri_amd import _lib
     from sayuri_amd import weights as W
@@ -395,6 +401,9 @@ def main():
                     # the steady-state rate: searched moves per second / moves a finished game had (independent of where the
                     # pre-rolled openings put the games of the first generation)
                     "games_per_hour": round(moves_per_sec * 3600 / mean_len, 1) if mean_len else None,
+                    "games_per_hour_definition": "moves_per_sec * 3600 / mean_moves_per_finished_game (steady-state move rate); the "
+                                                 "reference's finished-games / wall (pipe.cc:272-280) over this window is "
+                                                 "games_per_hour_prerolled_window",
                     "mean_moves_per_finished_game": round(mean_len, 1) if mean_len else None,
                     # games that FINISHED inside the window / wall (reference definition, src/selfplay/pipe.cc:272-280, but the
                     # window's games started at pre-rolled positions: an upper bound, kept for continuity with round 2)

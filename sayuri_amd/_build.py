@@ -27,11 +27,37 @@ HIP_SO = os.path.join(LIB, "libsayuri_hip.so")
 HOST_SO = os.path.join(LIB, "libsayuri_host.so")
 
 
-def _newer(target: str, sources) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+def _digest(sources, extra=()) -> str:
+    """sha256 over the CONTENTS of the sources and whatever else decides the output (command lines, options)."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(sources):
+        h.update(os.path.basename(s).encode() + b"\0")
+        with open(s, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def _stale(target: str, sources, extra=()) -> str:
+    """"" when `target` exists and its stamp names this digest, else the digest to stamp after the rebuild.  Contents, not
+    mtimes: a checkout, a copy to another box or a touched file neither forces nor hides a rebuild; a changed option
+    (SAYURI_TOWER_PAD, SAYURI_EXPERIMENTS ...) does force one."""
+    d = _digest(sources, extra)
+    try:
+        with open(target + ".stamp") as f:
+            if os.path.exists(target) and f.read().strip() == d:
+                return ""
+    except OSError:
+        pass
+    return d
+
+
+def _stamp(target: str, digest: str) -> None:
+    with open(target + ".stamp", "w") as f:
+        f.write(digest + "\n")
 
 
 def _files(d: str, exts):
@@ -45,7 +71,25 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+def _llvm_bin() -> str:
+    """The LLVM tools that belong to the hipcc in use (clang as assembler, ld.lld): next to it, or under ROCM_PATH."""
+    hip = os.path.realpath(_hipcc())
+    roots = [os.path.dirname(os.path.dirname(hip)), os.environ.get("ROCM_PATH", ""), "/opt/rocm"]
+    for r in roots:
+        for sub in ("lib/llvm/bin", "llvm/bin"):
+            d = os.path.join(r, sub) if r else ""
+            if d and os.path.exists(os.path.join(d, "clang")) and os.path.exists(os.path.join(d, "ld.lld")):
+                return d
+    raise RuntimeError("clang / ld.lld of the ROCm LLVM not found (looked next to %s and under ROCM_PATH)" % hip)
+
+
+def _seam_options():
+    # where the plain body starts: 256-byte boundary + 32 bytes, the best of seven placements measured on two boxes
+    # (NOTES.md, Kernel 1c); SAYURI_TOWER_ALIGN / SAYURI_TOWER_PAD build the others
+    return ((["--inv"] if os.environ.get("SAYURI_TOWER_INV") else []) +
+            (["--sleep=" + os.environ["SAYURI_TOWER_SLEEP"]] if os.environ.get("SAYURI_TOWER_SLEEP") else []) +
+            ["--align=" + os.environ.get("SAYURI_TOWER_ALIGN", "8"), "--pad=" + os.environ.get("SAYURI_TOWER_PAD", "32"),
+             "--pad-se=" + os.environ.get("SAYURI_TOWER_PAD_SE", "32")])
 
 
 def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
@@ -57,21 +101,20 @@ def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
     seam = os.path.join(HIP_SRC, "tower_seam.py")
     srcs = [os.path.join(HIP_SRC, f) for f in ("tower.hip", "conv_tower.h", "conv_board.h", "conv_glds.h", "conv_mfma.h",
                                                "small_ops.h", "common.h")] + [seam]
-    if not (force or _newer(blob, srcs)):
+    hip_flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-w"]
+    if os.environ.get("SAYURI_EXPERIMENTS"):
+        hip_flags.insert(0, "-DSAYURI_EXPERIMENTS")
+    digest = _stale(blob, srcs, hip_flags + _seam_options())
+    if not (force or digest):
         return blob
+    digest = digest or _digest(srcs, hip_flags + _seam_options())
     asm, seamed = os.path.join(objdir, "tower.s"), os.path.join(objdir, "tower_seamed.s")
     elf, hsaco, stub = os.path.join(objdir, "tower_dev.o"), os.path.join(objdir, "tower.hsaco"), os.path.join(objdir, "tower_blob.S")
     cmds = [
-        [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-w",
-         os.path.join(HIP_SRC, "tower.hip"), "-o", asm],
-        [sys.executable, seam, asm, seamed] + (["--inv"] if os.environ.get("SAYURI_TOWER_INV") else []) +
-        (["--sleep=" + os.environ["SAYURI_TOWER_SLEEP"]] if os.environ.get("SAYURI_TOWER_SLEEP") else []) +
-        # where the plain body starts: 256-byte boundary + 32 bytes, the best of seven placements measured on two boxes
-        # (Kernel 1c); SAYURI_TOWER_ALIGN / SAYURI_TOWER_PAD build the others
-        ["--align=" + os.environ.get("SAYURI_TOWER_ALIGN", "8"), "--pad=" + os.environ.get("SAYURI_TOWER_PAD", "32"),
-         "--pad-se=" + os.environ.get("SAYURI_TOWER_PAD_SE", "32")],
-        [os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", seamed, "-o", elf],
-        [os.path.join(LLVM_BIN, "ld.lld"), "-shared", elf, "-o", hsaco],
+        [_hipcc()] + hip_flags + [os.path.join(HIP_SRC, "tower.hip"), "-o", asm],
+        [sys.executable, seam, asm, seamed] + _seam_options(),
+        [os.path.join(_llvm_bin(), "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", seamed, "-o", elf],
+        [os.path.join(_llvm_bin(), "ld.lld"), "-shared", elf, "-o", hsaco],
     ]
     for cmd in cmds:
         if verbose:
@@ -80,29 +123,33 @@ def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
     with open(stub, "w") as f:
         f.write('\t.section .rodata\n\t.globl sayuri_tower_hsaco\n\t.type sayuri_tower_hsaco,@object\n\t.balign 4096\n'
                 'sayuri_tower_hsaco:\n\t.incbin "%s"\n\t.size sayuri_tower_hsaco, .-sayuri_tower_hsaco\n'
-                '\t.section .note.GNU-stack,"",@progbits\n' % hsaco)
-    cmd = ["gcc", "-c", stub, "-o", blob]
+                '\t.section .note.GNU-stack,"",@progbits\n' % os.path.basename(hsaco))
+    cmd = ["gcc", "-c", os.path.basename(stub), "-o", os.path.basename(blob)]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    subprocess.check_call(cmd, cwd=objdir)  # .incbin is looked up relative to the working directory: no absolute path in the stub
+    _stamp(blob, digest)
     return blob
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB, exist_ok=True)
     srcs = _files(HIP_SRC, (".hip", ".h", ".py")) + [os.path.join(ROOT, "include", "sayuri_hip.h")]
-    if force or _newer(HIP_SO, srcs):
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w"]
+    if os.environ.get("SAYURI_EXPERIMENTS"):  # in-kernel timelines and forced variants (measuring builds only)
+        flags.insert(0, "-DSAYURI_EXPERIMENTS")
+    digest = _stale(HIP_SO, srcs, flags + _seam_options())
+    if force or digest:
+        digest = digest or _digest(srcs, flags + _seam_options())
         blob = build_tower_blob(force, verbose)
         obj = os.path.join(LIB, "obj", "engine_hip.o")
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-c",
-               os.path.join(HIP_SRC, "engine.hip"), "-o", obj]
-        if os.environ.get("SAYURI_EXPERIMENTS"):  # in-kernel timelines and forced variants (measuring builds only)
-            cmd.insert(1, "-DSAYURI_EXPERIMENTS")
+        cmd = [_hipcc()] + flags + ["-c", os.path.join(HIP_SRC, "engine.hip"), "-o", obj]
         link = [_hipcc(), "--offload-arch=gfx950", "-shared", obj, blob, "-o", HIP_SO]
         for c in (cmd, link):
             if verbose:
                 print(" ".join(c), file=sys.stderr)
             subprocess.check_call(c)
+        _stamp(HIP_SO, digest)
     return HIP_SO
 
 
@@ -115,42 +162,52 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     headers = _files(HOST_SRC, (".h",)) + _files(ENGINE_SRC, (".h",)) + [os.path.join(ROOT, "include", f)
                                                                           for f in os.listdir(os.path.join(ROOT, "include"))]
-    jobs, objs = [], []
+    jobs, objs, stamps = [], [], []
+    hdr_digest = _digest(headers)
     for src in _files(HOST_SRC, (".cc",)) + _files(ENGINE_SRC, (".cc",)):
         obj = os.path.join(objdir, os.path.basename(os.path.dirname(src)) + "_" + os.path.basename(src)[:-3] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + headers):
-            opt = ["-O2"]
-            if os.path.basename(src) in FASTMATH_UNITS:
-                opt = ["-O3", "-ffast-math", "-march=x86-64-v3"]
-            jobs.append(["g++", "-std=c++17"] + opt + ["-fPIC", "-Wall", "-Wextra", "-I" + HOST_SRC, "-I" + ENGINE_SRC,
-                         "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+        opt = ["-O2"]
+        if os.path.basename(src) in FASTMATH_UNITS:
+            opt = ["-O3", "-ffast-math", "-march=x86-64-v3"]
+        flags = ["-std=c++17"] + opt + ["-fPIC", "-Wall", "-Wextra"]
+        digest = _stale(obj, [src], flags + [hdr_digest])
+        if force or digest:
+            stamps.append((obj, digest or _digest([src], flags + [hdr_digest])))
+            jobs.append(["g++"] + flags + ["-I" + HOST_SRC, "-I" + ENGINE_SRC, "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
     if jobs:
         if verbose:
             for j in jobs:
                 print(" ".join(j), file=sys.stderr)
         with ThreadPoolExecutor(max_workers=min(16, len(jobs))) as ex:
             list(ex.map(subprocess.check_call, jobs))
-    if jobs or force or _newer(HOST_SO, objs + [HIP_SO]):
+        for obj, digest in stamps:
+            _stamp(obj, digest)
+    link_digest = _stale(HOST_SO, objs)
+    if jobs or force or link_digest:
         cmd = ["g++", "-shared", "-o", HOST_SO] + objs + ["-L" + LIB, "-lsayuri_hip", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lz"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        _stamp(HOST_SO, _digest(objs))
     return HOST_SO
 
 
-def build_oracle(verbose: bool = False) -> None:
+def build_oracle(force: bool = False, verbose: bool = False) -> None:
     odir = os.path.join(ROOT, "oracle")
     out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-C", odir, "port"], stdout=out)
+    always = ["-B"] if force else []
+    subprocess.check_call(["make", "-C", odir] + always + ["port"], stdout=out)
     if os.path.isdir("/root/reference/src"):
-        subprocess.check_call(["make", "-C", odir, "-j8", "ref"], stdout=out, stderr=out)
+        subprocess.check_call(["make", "-C", odir, "-j8"] + always + ["ref"], stdout=out, stderr=out)
 
 
 def build_all(force: bool = False, verbose: bool = False) -> None:
+    """force=True (or SAYURI_BUILD_FORCE=1) recompiles everything from source whatever is in the tree."""
+    force = force or bool(os.environ.get("SAYURI_BUILD_FORCE"))
     build_hip(force, verbose)
     build_host(force, verbose)
-    build_oracle(verbose)
+    build_oracle(force, verbose)
 
 
 if __name__ == "__main__":

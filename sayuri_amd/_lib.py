@@ -40,7 +40,16 @@ def _require(path: str) -> str:
 def hip() -> ctypes.CDLL:
     global _hip
     if _hip is None:
-        lib = ctypes.CDLL(_require(_build.HIP_SO), mode=ctypes.RTLD_GLOBAL)
+        path = _build.HIP_SO
+        fake = os.environ.get("SAYURI_FAKE_HIP_LIB")
+        if fake:
+            # TEST HOOK (tests/fake_hip): a CPU stand-in for the DEVICE side of include/sayuri_hip.h, loaded ahead of the real
+            # library so that the host side can be run without a GPU.  Never set in production; said out loud when it is.
+            import sys
+            print(f"[sayuri_amd] SAYURI_FAKE_HIP_LIB is set: the device side is the test stand-in {fake}, NOT the MI355X engine",
+                  file=sys.stderr)
+            path = fake
+        lib = ctypes.CDLL(_require(path), mode=ctypes.RTLD_GLOBAL)
         lib.sayuri_hip_last_error.restype = ctypes.c_char_p
         lib.sayuri_hip_device_count.restype = ctypes.c_int
         lib.sayuri_hip_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, c_float_p, c_int_p]
@@ -55,9 +64,10 @@ def hip() -> ctypes.CDLL:
         lib.sayuri_hip_timed_stat.argtypes = [ctypes.c_void_p, ctypes.POINTER(KernelStat)]
         lib.sayuri_hip_device_bytes.restype = ctypes.c_size_t
         lib.sayuri_hip_device_bytes.argtypes = [ctypes.c_void_p]
-        lib.sayuri_hip_test_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int,
-                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                             ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
+        if not fake:  # the stand-in has no kernels to tap
+            lib.sayuri_hip_test_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
         _hip = lib
     return _hip
 

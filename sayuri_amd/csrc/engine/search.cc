@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <random>
 #include <stack>
@@ -181,7 +182,11 @@ void Search::PrepareRootNode(ComputationResult& result, int tag) {
         // a fresh root (the first move of a game, or a position the old tree does not contain): the old tree goes first, and
         // with the arena empty its slabs above the cap go back to the system (tree_arena.h)
         root_.reset();
-        arena_.Reset(kArenaKeepBytes);
+        static const std::size_t keep = [] {
+            const char* e = std::getenv("SAYURI_AB_ARENA_KEEP_MB");  // measuring aid
+            return e ? static_cast<std::size_t>(std::atol(e)) << 20 : kArenaKeepBytes;
+        }();
+        arena_.Reset(keep);
         root_.reset(new (&shared_) Node(active_, &shared_, kPassMove, 1.0f));
     }
     playouts_ = 0;

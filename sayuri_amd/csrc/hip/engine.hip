@@ -468,7 +468,15 @@ public:
         HIP_OK(hipEventCreate(&ev1_));
         enable_big_lds<T>();
         if (sizeof(T) == 2) enable_big_lds_glds();
-        if (sizeof(T) == 2 && flags_.tower && tower_load()) return -1;
+        if (sizeof(T) == 2 && flags_.tower && tower_load()) {
+            // the persistent launch is an optimisation: without its code object the per-layer launches (SAYURI_TOWER=0) run
+            // the same kernels.  Say so once, loudly, and go on.
+            std::fprintf(stderr, "[sayuri_hip] persistent tower kernel not loaded (%s): falling back to one launch per layer\n",
+                         sayuri_hip_last_error());
+            if (tower_mod_) (void)hipModuleUnload(tower_mod_);
+            tower_mod_ = nullptr;
+            tower_fn_[0] = tower_fn_[1] = nullptr;
+        }
         return describe_layers();
     }
 
@@ -514,7 +522,19 @@ public:
         HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
         if (tick_ev_[t]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t], 0));  // the download that last read this slot's outputs
         have_batch_ = true;
+        if (fwdstat_) {  // SAYURI_HIP_FWDSTAT (measuring aid): device time of every submitted forward
+            for (int k = 0; k < 2; ++k)
+                if (!fs_ev_[t][k]) HIP_OK(hipEventCreate(&fs_ev_[t][k]));
+            HIP_OK(hipEventRecord(fs_ev_[t][0], stream_));
+        }
+        const int uploads_before = table_uploads_;
         if (forward()) return -1;
+        if (fwdstat_) {
+            HIP_OK(hipEventRecord(fs_ev_[t][1], stream_));
+            fs_pending_[t] = true;
+            fs_n_[t] = n;
+            fs_uploads_ += table_uploads_ - uploads_before;
+        }
         HIP_OK(hipEventRecord(fwd_done_[t], stream_));
         HIP_OK(hipStreamWaitEvent(d2h_stream_, fwd_done_[t], 0));
         const size_t B2 = (size_t)board_ * board_;
@@ -531,6 +551,15 @@ public:
         if (ticket < 0 || ticket > 1 || !tick_ev_[ticket]) return fail("wait: bad ticket");
         HIP_OK(hipSetDevice(device_));
         HIP_OK(hipEventSynchronize(tick_ev_[ticket]));
+        if (fwdstat_ && fs_pending_[ticket]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, fs_ev_[ticket][0], fs_ev_[ticket][1]) == hipSuccess) {
+                const int b = fs_n_[ticket] >= max_batch_ ? 2 : (fs_n_[ticket] * 2 > max_batch_ ? 1 : 0);
+                fs_ms_[b] += ms;
+                fs_cnt_[b] += 1;
+            }
+            fs_pending_[ticket] = false;
+        }
         return 0;
     }
     int query(int ticket) override {
@@ -920,6 +949,11 @@ private:
         // workspaces
         slot_pix_ = board_ * board_;
         const size_t act_elems = (size_t)max_batch_ * slot_pix_ * cs_max_;
+        // the board kernels address an activation buffer with 24-bit row indices (__umul24) and 32-bit byte offsets from a
+        // uniform base (conv_board.h epilogue): both must cover the largest batch this ctx can be handed
+        if ((size_t)max_batch_ * slot_pix_ >= (size_t(1) << 24) || act_elems * sizeof(T) >= (size_t(1) << 32))
+            return fail("max_batch " + std::to_string(max_batch_) + " is too large for this network on one ctx: max_batch * board^2 must stay below 2^24 rows and an activation buffer (" +
+                        std::to_string(act_elems * sizeof(T) >> 20) + " MiB) below 4 GiB");
         for (IoSlot& io : io_)
             for (int i = 0; i < kNumBufs; ++i)
                 // every activation buffer starts kZeroPrefix bytes into its (zero-filled) allocation: conv_board.h reads
@@ -990,6 +1024,13 @@ private:
             }
         if (tower_mod_) (void)hipModuleUnload(tower_mod_);
         tower_mod_ = nullptr;
+        if (fwdstat_ && fs_cnt_[0] + fs_cnt_[1] + fs_cnt_[2] > 0) {
+            std::fprintf(stderr, "[hip fwdstat] forwards by batch size (<= half | partial | full): %ld / %ld / %ld, mean device ms %.4f / %.4f / %.4f, tower table uploads %ld\n",
+                         fs_cnt_[0], fs_cnt_[1], fs_cnt_[2], fs_cnt_[0] ? fs_ms_[0] / fs_cnt_[0] : 0.0, fs_cnt_[1] ? fs_ms_[1] / fs_cnt_[1] : 0.0,
+                         fs_cnt_[2] ? fs_ms_[2] / fs_cnt_[2] : 0.0, fs_uploads_);
+            fs_cnt_[0] = fs_cnt_[1] = fs_cnt_[2] = 0;
+        }
+        for (auto& pr : fs_ev_) for (hipEvent_t& e : pr) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         for (hipEvent_t& e : tick_ev_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
         pool_.clear();
@@ -1536,6 +1577,7 @@ private:
             HIP_OK(hipEventSynchronize(ts.staged[st]));  // the copy that last read this staging area (never recorded: returns at once)
             std::memcpy(ts.stage[st], run.data(), sizeof(TowerLayer) * n);
             HIP_OK(hipMemcpyAsync(ts.dev + first, ts.stage[st], sizeof(TowerLayer) * n, hipMemcpyHostToDevice, stream_));
+            ++table_uploads_;
             HIP_OK(hipEventRecord(ts.staged[st], stream_));
             std::memcpy(ts.cache.data() + first, run.data(), sizeof(TowerLayer) * n);
         }
@@ -1557,6 +1599,14 @@ private:
     TowerSlot tower_[2];
     std::vector<TowerLayer> run_;
     int run_kot_ = 0, table_used_ = 0;
+    int table_uploads_ = 0;
+    // SAYURI_HIP_FWDSTAT: device time of the forwards sent through submit(), by batch-size class
+    bool fwdstat_ = std::getenv("SAYURI_HIP_FWDSTAT") != nullptr;
+    hipEvent_t fs_ev_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    bool fs_pending_[2] = {false, false};
+    int fs_n_[2] = {0, 0};
+    double fs_ms_[3] = {0, 0, 0};
+    long fs_cnt_[3] = {0, 0, 0}, fs_uploads_ = 0;
     double run_flops_ = 0, run_bytes_ = 0;
 
     int device_;

@@ -213,6 +213,7 @@ void HipForwardPipe::BuildGraphs() {
     }
     trace_ = std::getenv("SAYURI_PIPE_TRACE") != nullptr;
     if (const char* e = std::getenv("SAYURI_PIPE_TAIL")) tail_frac_ = std::atof(e);
+    if (const char* e = std::getenv("SAYURI_AB_ROTATE_NOTIFY")) rotate_notify_ = std::atoi(e) != 0;
     running_.store(true);
     for (auto& g : graphs_) g->pump = std::thread([this, gp = g.get()] { PumpLoop(gp); });
 }
@@ -462,7 +463,7 @@ void HipForwardPipe::PumpLoop(Graph* g) {
         g->epoch.fetch_add(1, std::memory_order_release);
         FutexWakeAll(&g->epoch);
         // fibers parked in Reserve() on the epoch word are woken by their scheduler threads, which may be asleep themselves
-        if (fibers_seen_.load(std::memory_order_relaxed)) sayuri_fiber::NotifyAll();
+        if (rotate_notify_ && fibers_seen_.load(std::memory_order_relaxed)) sayuri_fiber::NotifyAll();
         pump_ns_[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0).count();
     };
     // close the fill set and point callers at the next one of the ring

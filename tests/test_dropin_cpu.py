@@ -146,3 +146,32 @@ def test_a_run_does_not_halt_over_its_own_network_spelled_differently(tmp_path):
     d = json.loads(out.read_text())
     assert d["ranks_reporting"] == 1 and d["stopped_early_by_halt"] == [] and d["halt_seen_by"] == [], d
     assert d["per_rank"][0]["games_done"] > 8, d["per_rank"][0]  # more than one game per worker: worker 0 checked at least once
+
+
+def _bench_on_the_fake_device(tmp_path, world, port, extra=()):
+    fake = str(tmp_path / "libfake_hip.so")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", os.path.join(ROOT, "tests", "fake_hip", "fake_hip.c"), "-o", fake, "-lpthread"])
+    env = dict(os.environ, SAYURI_FAKE_HIP_LIB=fake, FAKE_HIP_DEVICES=str(world), FAKE_HIP_SERIAL_US="3800", FAKE_HIP_CHEAP="1",
+               MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2",
+           "--dist-backend", "gloo", "--selfplay-seconds", "10", "--selfplay-games", "64", "--selfplay-visits", "16"] + list(extra)
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_the_fake_device(tmp_path):
+    """bench.py's own multi-rank path (the command line the driver uses for N > 1: torch.distributed.run, one rank per
+    device, barrier + max-over-ranks timing, the stats all-gather, the periodic exchange of the self-play segment), executed
+    on two gloo ranks over the serial fake device -- so that the first run on an 8-GPU node is not this code's first run."""
+    d = _bench_on_the_fake_device(tmp_path, 2, 29541)
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"] and d["config"]["parallelism"] == "dp2"
+    # value = the units ALL ranks processed / the max-over-ranks time: two serial devices at 3.8 ms per 256-batch
+    assert 0.5 * 2 * 256 / 3.8e-3 < d["value"] < 1.05 * 2 * 256 / 3.8e-3, d["value"]
+    sp = d["selfplay"]
+    assert sp["exchange_rounds"] > 0 and sp["nn_evals_per_sec"] > 0 and sp["moves_per_sec"] > 0 and not sp["halt_seen"]
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
