@@ -420,6 +420,18 @@ void so_tap_head_tail(int bs, int PC, int VC, int prob_ch, int pass_outs, int mi
  * swap dance: `x` is the block input (the skip), `y` the block output. */
 static int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
+/* Probe for the fixture generator (tests/golden/make_golden.py): max |x| of the residual stream after every block of the
+ * NEXT so_forward_raw calls on this thread (entry 0 = after the input convolution); NULL switches it off. */
+static __thread float* g_trunk_probe = NULL;
+static __thread int g_trunk_probe_cap = 0;
+void so_set_trunk_probe(float* absmax, int cap) { g_trunk_probe = absmax; g_trunk_probe_cap = cap; }
+static void trunk_probe(int slot, const float* y, int count) {
+    if (!g_trunk_probe || slot >= g_trunk_probe_cap) return;
+    float m = 0.f;
+    for (int i = 0; i < count; ++i) { const float a = fabsf(y[i]); if (a > m) m = a; }
+    if (m > g_trunk_probe[slot]) g_trunk_probe[slot] = m;
+}
+
 int so_forward_raw(const so_net* n, int bs, const float* planes, float* prob, float* pass,
                    float* misc, float* own) {
     if (!n || bs < 2 || bs > 25) return -1;
@@ -433,6 +445,7 @@ int so_forward_raw(const so_net* n, int bs, const float* planes, float* prob, fl
 
     conv3(n, bs, &n->input, planes, y); /* :391-401 */
     add_spatial(bs, C, y, n->input.b, NULL, act);
+    trunk_probe(0, y, C * S);
 
     for (int i = 0; i < n->nblocks; ++i) {
         const so_block* b = &n->tower[i];
@@ -481,6 +494,7 @@ int so_forward_raw(const so_net* n, int bs, const float* planes, float* prob, fl
             add_spatial(bs, C, y, b->conv[CV_2].b, last_skip, last_act);
         }
         if (b->se) se_unit(bs, C, b, y, x, act); /* :432-446 */
+        trunk_probe(i + 1, y, C * S);
     }
 
     /* policy head :449-536 */

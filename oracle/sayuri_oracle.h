@@ -38,6 +38,9 @@ int so_forward(const so_net* net, int board_size, float komi, int offset, const 
                float* out);
 /* the same evaluation before FillOutputs selects a policy plane:
  * prob [prob_ch][bs*bs], pass [pass_outs], misc [misc_outs], own [own_ch][bs*bs] */
+/* generator aid: max |x| of the residual stream after every block (slot 0 = after the input convolution) of the next
+ * so_forward / so_forward_raw calls on this thread; NULL switches it off */
+void so_set_trunk_probe(float* absmax, int cap);
 int so_forward_raw(const so_net* net, int board_size, const float* planes, float* prob,
                    float* pass, float* misc, float* own);
 

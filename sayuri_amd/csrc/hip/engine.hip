@@ -143,6 +143,7 @@ struct ConvOverride { bool v0 = false, no_board = false; int wnt = 0; };
 struct EngineFlags {
     ConvOverride conv;
     bool tower = true, se_fused = true, heads_fused = true, arith = true;
+    bool io_v2 = true;                 // SAYURI_IO_V2=0: geometry / small outputs by copies again (A/B; see submit())
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     int compute_streams = 1;
     int board_kot = 0;                 // experiments: only this channel tile
@@ -157,6 +158,7 @@ struct EngineFlags {
         }
         f.tower = !off("SAYURI_TOWER");
         f.tower_chain = !off("SAYURI_TOWER_CHAIN");
+        f.io_v2 = !off("SAYURI_IO_V2");
         f.se_fused = !off("SAYURI_SE_FUSED");
         f.heads_fused = !off("SAYURI_HEADS_FUSED");
         f.arith = !getenv("SAYURI_NO_ARITH");
@@ -525,10 +527,24 @@ public:
         if (fwdstat_) {  // SAYURI_HIP_FWDSTAT (measuring aid): device time of every submitted forward
             for (int k = 0; k < 2; ++k)
                 if (!fs_ev_[t][k]) HIP_OK(hipEventCreate(&fs_ev_[t][k]));
+
             HIP_OK(hipEventRecord(fs_ev_[t][0], stream_));
         }
         const int uploads_before = table_uploads_;
-        if (forward()) return -1;
+        // The persistent tower launch holds every CU (all registers, all LDS) for the whole forward.  A copy the runtime
+        // does with a blit KERNEL (everything below 16 KB: pass, misc, the three geometry arrays, the tower table) can
+        // therefore not run beside the OTHER ticket's tower launch: with two batches in flight a finished batch's small
+        // downloads -- and with them its completion event -- waited for the next batch's 3.5 ms launch to end, the next
+        // batch's geometry uploads likewise (driver line of round 3: 64.4 k evals/s in self-play against 70.5 k resident).
+        // So nothing small is copied any more: the heads kernel stores pass / misc straight into the caller's pinned
+        // buffers (20 KB of posted PCIe writes), a uniform batch uses geometry arrays that are resident (enqueue_inputs),
+        // and the tower table does not depend on the batch size (tower_append).  The two large outputs keep their DMA copies.
+        zc_pass_ = flags_.io_v2 ? pass : nullptr;
+        zc_misc_ = flags_.io_v2 ? misc : nullptr;
+        const int frc = forward();
+        const bool small_direct = zc_pass_ != nullptr;
+        zc_pass_ = zc_misc_ = nullptr;
+        if (frc) return -1;
         if (fwdstat_) {
             HIP_OK(hipEventRecord(fs_ev_[t][1], stream_));
             fs_pending_[t] = true;
@@ -539,11 +555,17 @@ public:
         HIP_OK(hipStreamWaitEvent(d2h_stream_, fwd_done_[t], 0));
         const size_t B2 = (size_t)board_ * board_;
         HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, d2h_stream_));
-        HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, d2h_stream_));
-        HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, d2h_stream_));
+        if (!small_direct) {
+            HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, d2h_stream_));
+            HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, d2h_stream_));
+        }
         HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, d2h_stream_));
         if (!tick_ev_[t]) HIP_OK(hipEventCreateWithFlags(&tick_ev_[t], hipEventDisableTiming));
         HIP_OK(hipEventRecord(tick_ev_[t], d2h_stream_));
+        if (fwdstat_) {
+            if (!fs_ev_[t][2]) HIP_OK(hipEventCreate(&fs_ev_[t][2]));
+            HIP_OK(hipEventRecord(fs_ev_[t][2], d2h_stream_));
+        }
         *ticket = t;
         return 0;
     }
@@ -558,6 +580,12 @@ public:
                 fs_ms_[b] += ms;
                 fs_cnt_[b] += 1;
             }
+            if (fs_ev_[ticket][2] && hipEventElapsedTime(&ms, fs_ev_[ticket][1], fs_ev_[ticket][2]) == hipSuccess) {
+                fs_d2h_ms_ += ms;
+                fs_d2h_max_ = std::max(fs_d2h_max_, (double)ms);
+                fs_d2h_slow_ += ms > 1.0f;
+            }
+
             fs_pending_[ticket] = false;
         }
         return 0;
@@ -583,6 +611,20 @@ public:
         have_batch_ = true;
         return 0;
     }
+
+    // resident geometry arrays of a uniform batch of `bs` x `bs` boards (valid for every n <= max_batch)
+    struct IdentGeom { int *off = nullptr, *bsz = nullptr, *perm = nullptr; };
+    const IdentGeom* ident_geom(int bs) {
+        auto it = ident_.find(bs);
+        if (it != ident_.end()) return &it->second;
+        IdentGeom g;
+        std::vector<int> off(max_batch_ + 1), bz(max_batch_, bs), pm(max_batch_);
+        for (int i = 0; i <= max_batch_; ++i) off[i] = i * bs * bs;
+        for (int i = 0; i < max_batch_; ++i) pm[i] = i;
+        if (dev_upload(&g.off, off) || dev_upload(&g.bsz, bz) || dev_upload(&g.perm, pm)) return nullptr;
+        return &ident_.emplace(bs, g).first->second;
+    }
+    std::map<int, IdentGeom> ident_;
 
     // geometry + planes H2D on the stream (no sync).  The geometry arrays are staged in a
     // 2-deep pinned ring so a second batch can be enqueued while the first is still copying.
@@ -622,19 +664,50 @@ public:
             board_plan_valid_ = false;
         }
         IoSlot& slot = io_[cur_slot_];
-        if (slot.tabs_bsz != geom_.bsz) {  // this slot's tables were built for another geometry
+        const bool uniform = !mixed;
+        // One sample per tile and one board size: the tables of a LONGER batch of the same size serve a shorter one (tile i
+        // depends on sample i alone), so a queue that alternates between 256 and 250 positions keeps its tables.
+        const bool one_per_tile = uniform && 2 * geom_.bsz[0] * geom_.bsz[0] > kBoardPT;
+        const bool prefix = flags_.io_v2 && one_per_tile && slot.tabs_single && slot.tabs_bsz.size() >= (size_t)n &&
+                            slot.tabs_bsz[0] == geom_.bsz[0];
+        if (!prefix && slot.tabs_bsz != geom_.bsz) {  // this slot's tables were built for another geometry
             for (auto& kv : slot.tabs) kv.second.fresh = false;
             slot.board.fresh = false;
             slot.tabs_bsz = geom_.bsz;
+            slot.tabs_single = one_per_tile;
+        } else if (prefix && slot.tabs_bsz.size() != (size_t)n) {
+            for (auto& kv : slot.tabs) kv.second.fresh = false;  // the tables of the across-sample tiles (conv_glds.h) know the pixel total
         }
-        int* hg = h_geom_ + (size_t)geom_slot_ * (3 * max_batch_ + 1);
-        geom_slot_ ^= 1;
-        std::memcpy(hg, geom_.off.data(), sizeof(int) * (n + 1));
-        std::memcpy(hg + max_batch_ + 1, geom_.bsz.data(), sizeof(int) * n);
-        std::memcpy(hg + 2 * max_batch_ + 1, perm_.data(), sizeof(int) * n);
-        HIP_OK(hipMemcpyAsync(d_off_, hg, sizeof(int) * (n + 1), hipMemcpyHostToDevice, copy_stream));
-        HIP_OK(hipMemcpyAsync(d_bsz_, hg + max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
-        HIP_OK(hipMemcpyAsync(d_perm_, hg + 2 * max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
+        // Geometry arrays on the device.  A uniform batch (the self-play queue: every position on the NN board) uses arrays
+        // that are resident -- off[i] = i * bs^2, bsz[i] = bs, perm[i] = i hold for every n -- so nothing is copied.  A mixed
+        // batch stages its arrays in a pinned ring and a one-workgroup kernel ON THE FORWARD'S OWN STREAM moves them: a
+        // copy of a few KB is a blit kernel to the runtime, and on the copy stream it would wait for the other ticket's
+        // persistent tower launch to give up a CU (see submit()).
+        if (flags_.io_v2) {
+            if (uniform) {
+                const IdentGeom* id = ident_geom(geom_.bsz[0]);
+                if (!id) return -1;
+                d_off_ = id->off; d_bsz_ = id->bsz; d_perm_ = id->perm;
+            } else {
+                d_off_ = slot.off; d_bsz_ = slot.bsz; d_perm_ = slot.perm;
+                int* hg = h_geom_ + (size_t)geom_slot_ * (3 * max_batch_ + 1);
+                geom_slot_ ^= 1;
+                std::memcpy(hg, geom_.off.data(), sizeof(int) * (n + 1));
+                std::memcpy(hg + max_batch_ + 1, geom_.bsz.data(), sizeof(int) * n);
+                std::memcpy(hg + 2 * max_batch_ + 1, perm_.data(), sizeof(int) * n);
+                hipLaunchKernelGGL(geom_stage_kernel, dim3(1), dim3(256), 0, stream_, (const int*)hg, max_batch_, n, d_off_, d_bsz_, d_perm_);
+                HIP_OK(hipGetLastError());
+            }
+        } else {
+            int* hg = h_geom_ + (size_t)geom_slot_ * (3 * max_batch_ + 1);
+            geom_slot_ ^= 1;
+            std::memcpy(hg, geom_.off.data(), sizeof(int) * (n + 1));
+            std::memcpy(hg + max_batch_ + 1, geom_.bsz.data(), sizeof(int) * n);
+            std::memcpy(hg + 2 * max_batch_ + 1, perm_.data(), sizeof(int) * n);
+            HIP_OK(hipMemcpyAsync(d_off_, hg, sizeof(int) * (n + 1), hipMemcpyHostToDevice, copy_stream));
+            HIP_OK(hipMemcpyAsync(d_bsz_, hg + max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
+            HIP_OK(hipMemcpyAsync(d_perm_, hg + 2 * max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
+        }
         IoSlot& io = io_[cur_slot_];
         io.packed_binary = packed ? binary : 0;
         if (packed) {
@@ -1014,6 +1087,7 @@ private:
         (void)hipSetDevice(device_);
         for (void* p : allocs_) (void)hipFree(p);
         allocs_.clear();
+        ident_.clear();
         if (h_geom_) (void)hipHostFree(h_geom_);
         h_geom_ = nullptr;
         for (TowerSlot& ts : tower_)
@@ -1025,9 +1099,11 @@ private:
         if (tower_mod_) (void)hipModuleUnload(tower_mod_);
         tower_mod_ = nullptr;
         if (fwdstat_ && fs_cnt_[0] + fs_cnt_[1] + fs_cnt_[2] > 0) {
-            std::fprintf(stderr, "[hip fwdstat] forwards by batch size (<= half | partial | full): %ld / %ld / %ld, mean device ms %.4f / %.4f / %.4f, tower table uploads %ld\n",
+            const long all = fs_cnt_[0] + fs_cnt_[1] + fs_cnt_[2];
+            std::fprintf(stderr, "[hip fwdstat] forwards by batch size (<= half | partial | full): %ld / %ld / %ld, mean device ms %.4f / %.4f / %.4f, tower table uploads %ld; "
+                         "forward end -> downloads done: mean %.3f ms, max %.3f, > 1 ms: %ld\n",
                          fs_cnt_[0], fs_cnt_[1], fs_cnt_[2], fs_cnt_[0] ? fs_ms_[0] / fs_cnt_[0] : 0.0, fs_cnt_[1] ? fs_ms_[1] / fs_cnt_[1] : 0.0,
-                         fs_cnt_[2] ? fs_ms_[2] / fs_cnt_[2] : 0.0, fs_uploads_);
+                         fs_cnt_[2] ? fs_ms_[2] / fs_cnt_[2] : 0.0, fs_uploads_, fs_d2h_ms_ / all, fs_d2h_max_, fs_d2h_slow_);
             fs_cnt_[0] = fs_cnt_[1] = fs_cnt_[2] = 0;
         }
         for (auto& pr : fs_ev_) for (hipEvent_t& e : pr) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -1476,7 +1552,7 @@ private:
         h.own_b = cv(SAYURI_L_V_OWNERSHIP).bias;
         h.Cp = Cp; h.cs_p = round_up(Cp, 32); h.Cv = Cv; h.cs_v = round_up(Cv, 32);
         h.prob_ch = d.probabilities_channels; h.act = act; h.board = board_;
-        h.prob = d_prob_; h.pass = d_pass_; h.misc = d_misc_; h.own = d_own_; h.perm = d_perm_;
+        h.prob = d_prob_; h.pass = zc_pass_ ? zc_pass_ : d_pass_; h.misc = zc_misc_ ? zc_misc_ : d_misc_; h.own = d_own_; h.perm = d_perm_;
         if (head_img_ && heads_fused_enabled()) {
             // both heads of a sample in one workgroup: trunk -> LDS -> stacked 1x1 convolution on the matrix cores -> pooling,
             // FCs and the per-pixel planes (head_board.h)
@@ -1538,6 +1614,14 @@ private:
         std::memset(&t, 0, sizeof(t));
         t.sp = sp;
         t.has_se = has_se ? 1 : 0;
+        if (flags_.io_v2) {
+            // what the bodies never read (tile = workgroup id, the launch's grid is the batch): left out of the table, so that
+            // a batch of 250 positions finds the table of a batch of 256 in place and nothing is uploaded
+            ConvParams& c = t.sp.b.c;
+            c.num_pix_tiles = 0;
+            c.g.n_samples = 0;
+            c.g.total_pix = 0;
+        }
         run_.push_back(t);
         run_flops_ += flops;
         run_bytes_ += bytes;
@@ -1586,10 +1670,13 @@ private:
         const TowerLayer* arg = ts.dev + first;
         const int grid = board_plan_.ntiles;
         hipError_t lrc = hipSuccess;
+        static const bool sync_dbg = std::getenv("SAYURI_TOWER_SYNC") != nullptr;  // debugging aid: nothing overlaps the tower launch
+        if (sync_dbg) HIP_OK(hipStreamSynchronize(stream_));
         const int rc = timed("tower_run", run_flops_, run_bytes_, [&] {
             void* params[] = {(void*)&arg};
             lrc = hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, 0, stream_, params, nullptr);
         });
+        if (sync_dbg && lrc == hipSuccess) HIP_OK(hipStreamSynchronize(stream_));
         if (lrc != hipSuccess) return fail(std::string("hipModuleLaunchKernel(conv_tower_kernel): ") + hipGetErrorString(lrc));
         return rc;
     }
@@ -1602,7 +1689,10 @@ private:
     int table_uploads_ = 0;
     // SAYURI_HIP_FWDSTAT: device time of the forwards sent through submit(), by batch-size class
     bool fwdstat_ = std::getenv("SAYURI_HIP_FWDSTAT") != nullptr;
-    hipEvent_t fs_ev_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t fs_ev_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    double fs_d2h_ms_ = 0, fs_d2h_max_ = 0;
+    long fs_d2h_slow_ = 0;
+    float *zc_pass_ = nullptr, *zc_misc_ = nullptr;  // this submit's pass / misc go straight to these (pinned host) buffers
     bool fs_pending_[2] = {false, false};
     int fs_n_[2] = {0, 0};
     double fs_ms_[3] = {0, 0, 0};
@@ -1631,6 +1721,7 @@ private:
         std::map<int, TileTabs> tabs;   // index tables of the geometry this slot last ran (keyed by tile variant)
         BoardTabs board;
         std::vector<int> tabs_bsz;
+        bool tabs_single = false;  // tabs_bsz is one board size with one sample per tile
     };
     IoSlot io_[2];
     hipStream_t compute_[2] = {nullptr, nullptr};

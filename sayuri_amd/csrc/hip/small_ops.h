@@ -127,6 +127,18 @@ static inline int pack_input_chunk(int slot_pix, int cs, int elem) {
 // floats (the value of each broadcast plane).  1.8 KB per sample instead of 62 KB over PCIe and out of HBM.
 // kPackSplit workgroups per sample (pixel ranges): the record goes to LDS with one coalesced load, then thread = (pixel,
 // 16-byte piece) in output order -- every store of a wave is 1 KiB contiguous.
+// The geometry arrays of a MIXED batch, moved from the engine's pinned staging ring to device memory by the forward's own
+// stream (one workgroup; `stage` is host memory the device reads over PCIe: off[n+1] | bsz[n] | perm[n] at strides of
+// max_batch + 1 / max_batch).  Not a hipMemcpyAsync: see Engine::enqueue_inputs.
+__global__ __launch_bounds__(256) void geom_stage_kernel(const int* __restrict__ stage, int max_batch, int n, int* __restrict__ off,
+                                                         int* __restrict__ bsz, int* __restrict__ perm) {
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) off[i] = stage[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        bsz[i] = stage[max_batch + 1 + i];
+        perm[i] = stage[2 * max_batch + 1 + i];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_bits_kernel(const unsigned* __restrict__ records, int rec_words, int nbin,
                                                         T* __restrict__ out, BatchGeom g, int cin, int cs,

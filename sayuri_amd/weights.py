@@ -76,6 +76,10 @@ class NetSpec:
     replk_kernel: int = 7
     version: int = 5
     nntype: str = "Residual"
+    # generator-only knob (not part of the file format): multiplies the scale of every branch that is added back to the
+    # skip.  1.0 keeps the residual stream O(1) through deep towers; larger values make the stream GROW from block to
+    # block (the fp16 stress fixture, tests/golden_specs.py: |x| ~ 1e3 at the end of a 20-block tower)
+    branch_scale: float = 1.0
 
     @staticmethod
     def residual(nblocks: int, channels: int, head_channels: int, se_every: int = 3,
@@ -97,6 +101,13 @@ def spec_20b256() -> NetSpec:
 
 def spec_40b384() -> NetSpec:
     return NetSpec.residual(40, 384, 48)
+
+
+def spec_20b256_hot(branch_scale: float = 3.0) -> NetSpec:
+    """configs[1]'s architecture with BN statistics that let the residual stream grow: the fp16 stress network."""
+    s = NetSpec.residual(20, 256, 32)
+    s.branch_scale = branch_scale
+    return s
 
 
 Layer = Tuple[str, Tuple[int, ...], List[np.ndarray]]  # (struct line, shape ints, tensors)
@@ -156,7 +167,7 @@ class _Gen:
         nb = max(len(s.blocks), 1)
         # keep the residual stream O(1) through deep towers: the branch that is
         # added back to the skip is scaled like a trained final-BN gamma
-        res_scale = 1.0 / math.sqrt(nb)
+        res_scale = s.branch_scale / math.sqrt(nb)
         self.conv_block("input_conv", INPUT_CHANNELS, c, 3, act)
         for i, blk in enumerate(s.blocks):
             p = f"tower.{i}"

@@ -58,6 +58,11 @@ FIXTURES = [
     # regenerated from their seeds, only the reference's outputs are stored)
     dict(name="net_20b256_x64", spec=W.spec_20b256, seed=22, commit_weights=False, winograd=(1,), store_planes=False,
          cases=tuple((19, i % 5, 700 + i) for i in range(64))),
+    # fp16 stress: the 20b x 256 architecture with BN statistics that let the residual stream grow to |x| ~ 1.4e3 by block 20
+    # (sayuri_amd.weights.spec_20b256_hot; the ordinary random-init nets keep it at O(1), so the fp16 gate was calibrated on
+    # small activations only).  fp16 storage of 40 accumulated residual additions at that magnitude is what is checked.
+    dict(name="net_20b256_hot", spec=lambda: W.spec_20b256_hot(5.5), seed=24, commit_weights=False, winograd=(1,), store_planes=False,
+         cases=tuple((19, i % 5, 800 + i) for i in range(8))),
     # BASELINE.json configs[4] network: 40-block x 384-filter, boards 19 / 13 / 9
     dict(name="net_40b384", spec=W.spec_40b384, seed=23, commit_weights=False, winograd=(1,), store_planes=False,
          cases=((19, 0, 601), (13, 1, 602), (9, 2, 603), (19, 3, 604))),

@@ -93,6 +93,40 @@ def test_20b256_golden_and_oracle(fp16, tmp_weights_dir):
         pipe.Destroy()
 
 
+def test_fp16_storage_range_on_the_hot_network(tmp_weights_dir):
+    """fp16 stress fixture: the 20b x 256 architecture with BN statistics that let the residual stream
+    grow to |x| ~ 1.4e3 by block 20 and the raw outputs to ~1e3 (tests/golden_specs.py net_20b256_hot; goldens from the
+    reference's BlasForwardPipe).  The fp16 engine stores 41 layers of such activations as fp16 (max 65 504, 11 bits):
+    outputs must stay finite, within the gate RELATIVE to the output scale, and inside the reference's own GPU-vs-CPU
+    criterion (Network::SelfCheck, network.cc:333-359: L2 <= 0.2).  The measured error goes to gpurun_out/ for profiles/."""
+    import json
+    import os
+    g = Golden("net_20b256_hot", tmp_weights_dir)
+    cases = [(g.planes(c), c["board_size"], c["offset"], g.expected(c)) for c in g.cases]
+    rows = []
+    for fp16 in (True, False):
+        pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=fp16)
+        try:
+            outs = pipe.BatchForward([c[0] for c in cases], [c[1] for c in cases], offsets=[c[2] for c in cases])
+        finally:
+            pipe.Destroy()
+        for (p, bs, off, exp), got in zip(cases, outs):
+            scale = float(np.abs(exp).max())
+            err = float(np.abs(got - exp).max())
+            l2 = self_check_l2(got, exp, bs)
+            rows.append({"fp16": fp16, "output_scale": scale, "max_abs_err": err, "rel_to_scale": err / scale, "selfcheck_l2": l2})
+            assert np.isfinite(got).all(), fp16
+            assert scale > 100.0
+            assert err <= (FP16_ATOL if fp16 else FP32_ATOL) * scale, (fp16, err, scale)
+            assert l2 <= 0.2, (fp16, l2)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "fp16_error_hot_network.json"), "w") as f:
+        json.dump({"fixture": "net_20b256_hot (branch_scale 5.5, seed 24): residual stream max |x| ~ 1.4e3 at block 20",
+                   "worst_fp16_rel_to_scale": max(r["rel_to_scale"] for r in rows if r["fp16"]),
+                   "worst_fp16_selfcheck_l2": max(r["selfcheck_l2"] for r in rows if r["fp16"]), "cases": rows}, f, indent=1)
+
+
 def test_mixed_board_batch_matches_native_evaluation(tmp_weights_dir):
     """configs[4] mechanism: 9/13/19 samples in one batch on a 19x19 graph equal the oracle's
     native small-board evaluation of each sample (no mask error, fp32 engine)."""

@@ -49,6 +49,19 @@ def test_port_matches_reference_golden_20b256(tmp_weights_dir):
         assert np.abs(got - exp).max() <= 5e-5, float(np.abs(got - exp).max())
 
 
+def test_port_matches_reference_golden_hot_network(tmp_weights_dir):
+    """The fp16 stress network (residual stream growing to |x| ~ 1.4e3, outputs of scale ~1e3): the restatement follows the
+    reference to fp32 rounding at that magnitude (relative gate: 2e-5 of the output scale)."""
+    g = Golden("net_20b256_hot", tmp_weights_dir)
+    net = PortNet(g.weights_path, True)
+    for case in g.cases[:2]:
+        got = net.forward(g.planes(case), case["board_size"], offset=case["offset"])
+        exp = g.expected(case)
+        scale = float(np.abs(exp).max())
+        assert scale > 100.0, scale  # the fixture really is hot
+        assert np.isfinite(got).all() and np.abs(got - exp).max() <= 2e-5 * scale, (float(np.abs(got - exp).max()), scale)
+
+
 def test_winograd_and_im2col_agree(tmp_weights_dir):
     g = Golden("tiny_res", tmp_weights_dir)
     a, b = PortNet(g.weights_path, True), PortNet(g.weights_path, False)
