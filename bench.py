@@ -267,8 +267,10 @@ def main():
     ap.add_argument("--selfplay-stagger", type=int, default=360,
                     help="the first game of worker g starts after g*N/games policy-sampled moves (0 = every game from move 0): "
                          "a window of minutes then sees games in every phase, as hours of self-play do, and games/hour can be counted")
-    ap.add_argument("--config5", action="store_true",
-                    help="also time configs[4]: 40-block x 384 net, batch 256 of mixed 9/13/19 boards (adds ~1 min of weight generation)")
+    ap.add_argument("--config5", dest="config5", action="store_true", default=True, help="(the default)")
+    ap.add_argument("--no-config5", dest="config5", action="store_false",
+                    help="skip configs[4] (40-block x 384 net, batch 256 of mixed 9/13/19 boards; single-GPU runs only; ~20 s: the "
+                         "generated weights are cached under /tmp)")
     ap.add_argument("--selfplay-games", type=int, default=512, help="concurrent self-play games per GPU")
     ap.add_argument("--selfplay-visits", type=int, default=400)
     ap.add_argument("--dist-backend", default=os.environ.get("SAYURI_DIST_BACKEND", "nccl"),
@@ -452,8 +454,8 @@ def main():
             result["selfplay"] = selfplay
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wpath, planes, args.cpu_seconds)
-        if args.config5:
-            result["config5"] = config5_segment(lib, local_rank, rank, args.steps, args.warmup)
+        if args.config5 and world == 1:
+            result["config5"] = config5_segment(lib, local_rank, rank, min(args.steps, 30), min(args.warmup, 5))
         if args.profile:
             rows = (_lib.KernelStat * 32)()
             k = lib.sayuri_hip_profile_run(ctx, rows, 32)

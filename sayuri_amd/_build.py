@@ -88,8 +88,7 @@ def _seam_options():
     # (NOTES.md, Kernel 1c); SAYURI_TOWER_ALIGN / SAYURI_TOWER_PAD build the others
     return ((["--inv"] if os.environ.get("SAYURI_TOWER_INV") else []) +
             (["--sleep=" + os.environ["SAYURI_TOWER_SLEEP"]] if os.environ.get("SAYURI_TOWER_SLEEP") else []) +
-            ["--align=" + os.environ.get("SAYURI_TOWER_ALIGN", "8"), "--pad=" + os.environ.get("SAYURI_TOWER_PAD", "32"),
-             "--pad-se=" + os.environ.get("SAYURI_TOWER_PAD_SE", "32")])
+            ["--align=" + os.environ.get("SAYURI_TOWER_ALIGN", "8"), "--pad=" + os.environ.get("SAYURI_TOWER_PAD", "32")])
 
 
 def build_tower_blob(force: bool = False, verbose: bool = False) -> str:

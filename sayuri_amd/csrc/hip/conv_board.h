@@ -666,6 +666,7 @@ template <int N> __device__ __forceinline__ float row_ror(float v) {
 // thread's 16-byte weight loads are independent and go out eight at a time (these FCs are latency-bound: every
 // workgroup of the launch reads the same few hundred KB from L2); red[slice][out] is folded by the caller.
 // Needs out % 4 == 0 and out / 4 <= 512.
+template <int U = 8>  // weight loads in flight per thread
 __device__ __forceinline__ void se_fc4(const FcDev fc, const float* x, float* red, int tid) {
     const int quads = fc.out / 4, parts = 512 / quads;
     const int oq = tid % quads, part = tid / quads;
@@ -674,34 +675,39 @@ __device__ __forceinline__ void se_fc4(const FcDev fc, const float* x, float* re
     const int i0 = part * per, i1 = min(fc.in, i0 + per);
     const float* w = fc.wt + oq * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int i = i0; i < i1; i += 8) {
-        f32x4 wv[8];
+    for (int i = i0; i < i1; i += U) {
+        f32x4 wv[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = i + u < i1 ? *(const f32x4*)(w + (size_t)(i + u) * fc.out) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < U; ++u) wv[u] = i + u < i1 ? *(const f32x4*)(w + (size_t)(i + u) * fc.out) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a += (i + u < i1 ? x[i + u] : 0.f) * wv[u];
+        for (int u = 0; u < U; ++u) a += (i + u < i1 ? x[i + u] : 0.f) * wv[u];
     }
     *(f32x4*)(red + part * fc.out + oq * 4) = a;
 }
 
+// LDS of the SE stage (byte offsets BEHIND the two weight images of the staged form; the K loop's rings are dead by then):
+// [2][KO_T] sums, [2][KO_T] maxima (one row per wave column), pool[3 KO_T], red[2048], mid[512], gate[2 KO_T].  The stage is
+// three steps -- pooling, the two FCs, the gate -- that meet in this layout; the persistent tower launch runs the first and the
+// last as generated assembly on the K loop's own register assignment and the FCs as a compiled body of their own
+// (conv_tower.h, tower_seam.py), the per-layer kernel below runs all three as compiled code.
+template <int WMT> struct SeLds {
+    static constexpr int KO_T = BoardCfg<WMT>::KO_T;
+    static constexpr int psum = 0, pmax = psum + 2 * KO_T * 4, pool = pmax + 2 * KO_T * 4, red = pool + 3 * KO_T * 4,
+                         mid = red + 2048 * 4, gate = mid + 512 * 4, end = gate + 2 * KO_T * 4;
+};
+
+// Step 1: pooling.  Leaves the per-wave-column partial sums and maxima of every channel in LDS and the two FC images on
+// their way (staged form); returns behind the barrier that publishes both.
 template <int WMT>
-__device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
-                                               int wave, int lane, int col0, int nj, int bs, unsigned long long* dbg = nullptr) {
+__device__ __forceinline__ void board_se_pool(const BoardSeParams& sp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
+                                              int wave, int lane, int col0, int nj, int bs) {
     using Cfg = BoardCfg<WMT>;
     constexpr int NJ = Cfg::NJ, KO_T = Cfg::KO_T;
-    const ConvParams& p = sp.b.c;
-    const int tid = wave * 64 + lane, q = lane >> 4, px = lane & 15, wave_m = wave & 3, wave_n = wave >> 2;
-    const int C = sp.C, so = sp.squeeze.out;
+    const int q = lane >> 4, px = lane & 15, wave_m = wave & 3, wave_n = wave >> 2;
     const bool staged = sp.w1h != nullptr;
-    // LDS (the K loop's rings are dead): the two weight images first (staged form), then
-    // [2][KO_T] sums, [2][KO_T] maxima, pool[3 KO_T], red[2048], mid[512], gate[2 KO_T]
     const int w_bytes = staged ? sp.w1_bytes + sp.w2_bytes : 0;
-    float* psum = (float*)(smem + w_bytes);
-    float* pmax = psum + 2 * KO_T;
-    float* pool = pmax + 2 * KO_T;
-    float* red = pool + 3 * KO_T;  // [slices][outputs] of an FC: 512 threads x 4 floats
-    float* mid = red + 2048;
-    float* gate = mid + 512;
+    float* psum = (float*)(smem + w_bytes + SeLds<WMT>::psum);
+    float* pmax = (float*)(smem + w_bytes + SeLds<WMT>::pmax);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with the rings
     if (staged) {
@@ -715,13 +721,12 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
         for (int k = wave; k < n2; k += 8) glds16_s(lane * 16, g2 + k * 1024, l0 + sp.w1_bytes + k * 1024);
     }
 
-    // ---- pooling: per lane over its column tiles (valid pixels only), then over the 16 pixel lanes of a row
-    const int2* pix = sp.b.tab_pix + (size_t)tile * kBoardPT + col0 * 16 + px;
-    // a one-sample tile has its unused pixel slots at the end: only the wave's LAST column tile can hold any, so only
+    // ---- per lane over its column tiles (valid pixels only), then over the 16 pixel lanes of a row.
+    // A one-sample tile has its unused pixel slots at the end: only the wave's LAST column tile can hold any, so only
     // that one is masked (the others are summed with packed adds).  One row tile at a time: eight live temporaries
     // beside the 192 accumulators instead of thirty-two (hipcc parked accumulators in scratch for the wider form --
     // 17 MB of spill stores per launch in the PMC pass)
-    const bool last_valid = nj <= 0 ? false : sp.b.arith ? (col0 + nj - 1) * 16 + px < bs * bs : pix[(nj - 1) * 16].y >= 0;
+    const bool last_valid = nj <= 0 ? false : (col0 + nj - 1) * 16 + px < bs * bs;
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, m4 = {-5000.f, -5000.f, -5000.f, -5000.f};
@@ -767,8 +772,28 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
     }
     if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the images have landed
     __syncthreads();
+}
+
+// Step 2: the two FCs, from the pooled partials to gate[c] = sigmoid(gamma_c), gate[KO_T + c] = beta_c in LDS (pad channels
+// [C, KO_T): both 0 -- their weights and bias are 0, x stays 0).  Needs only LDS and the thread id: the tower launch runs it as a
+// body of its own (tower_se_fc_kernel) between the assembly pooling and the assembly gate.
+template <int WMT, int U = 8>  // U: se_fc4's loads in flight (the tower's FC body has 62 VGPRs: 4)
+__device__ __forceinline__ void board_se_fc(const BoardSeParams& sp, unsigned char* smem, int tid, int bs, unsigned long long* dbg = nullptr) {
+    using Cfg = BoardCfg<WMT>;
+    constexpr int KO_T = Cfg::KO_T;
+    const ConvParams& p = sp.b.c;
+    const int C = sp.C, so = sp.squeeze.out;
+    const bool staged = sp.w1h != nullptr;
+    const int w_bytes = staged ? sp.w1_bytes + sp.w2_bytes : 0;
+    float* psum = (float*)(smem + w_bytes + SeLds<WMT>::psum);
+    float* pmax = (float*)(smem + w_bytes + SeLds<WMT>::pmax);
+    float* pool = (float*)(smem + w_bytes + SeLds<WMT>::pool);
+    float* red = (float*)(smem + w_bytes + SeLds<WMT>::red);  // [slices][outputs] of an FC: 512 threads x 4 floats
+    float* mid = (float*)(smem + w_bytes + SeLds<WMT>::mid);
+    float* gate = (float*)(smem + w_bytes + SeLds<WMT>::gate);
     if (dbg) dbg[2] = __builtin_amdgcn_s_memtime();  // pooled partials exchanged
     const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
+    for (int c = C + tid; c < KO_T; c += 512) { gate[c] = 0.f; gate[KO_T + c] = 0.f; }
     if (staged) {
         // ---- squeeze FC out of LDS: thread = (4 consecutive outputs, every parts-th row); a row's pooled value is folded
         // from the two wave columns' partials on the fly (mean rows: (s0 + s1) / npix, max rows: max(m0, m1))
@@ -817,7 +842,7 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
         }
         __syncthreads();
         // ---- the two FCs (se_fc4 above): squeeze with the unit's activation, excite into the gate
-        se_fc4(sp.squeeze, pool, red, tid);
+        se_fc4<U>(sp.squeeze, pool, red, tid);
         __syncthreads();
         for (int o = tid; o < so; o += 512) {
             float a = sp.squeeze.b[o];
@@ -827,7 +852,7 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
         }
         __syncthreads();
         if (dbg) dbg[3] = __builtin_amdgcn_s_memtime();  // squeeze FC done
-        se_fc4(sp.excite, mid, red, tid);
+        se_fc4<U>(sp.excite, mid, red, tid);
         __syncthreads();
         {
             const int eo = sp.excite.out, parts = 512 / (eo / 4);
@@ -841,21 +866,35 @@ __device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned
         __syncthreads();
         if (dbg) dbg[4] = __builtin_amdgcn_s_memtime();  // excite FC done, gate in LDS
     }
-    // ---- x <- sigmoid(gamma) x + beta on the accumulators (pad channels: weights and bias are 0, x stays 0 * g + b:
-    // their gate entries are never written, so they are masked here)
+}
+
+// Step 3: x <- sigmoid(gamma) x + beta on the accumulators (one fused multiply-add per value).
+template <int WMT>
+__device__ __forceinline__ void board_se_gate(const BoardSeParams& sp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int wave, int lane) {
+    using Cfg = BoardCfg<WMT>;
+    constexpr int NJ = Cfg::NJ, KO_T = Cfg::KO_T;
+    const int q = lane >> 4, wave_m = wave & 3;
+    const int w_bytes = sp.w1h != nullptr ? sp.w1_bytes + sp.w2_bytes : 0;
+    const float* gate = (const float*)(smem + w_bytes + SeLds<WMT>::gate);
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         const int c0 = wave_m * WMT * 16 + i * 16 + 4 * q;
-        f32x4 g = *(const f32x4*)(gate + c0), be = *(const f32x4*)(gate + KO_T + c0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (c0 + r >= C) { g[r] = 0.f; be[r] = 0.f; }
+        const f32x4 g = *(const f32x4*)(gate + c0), be = *(const f32x4*)(gate + KO_T + c0);
         static_for<NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            acc[i][j] = g * acc[i][j] + be;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(g[r], acc[i][j][r], be[r]);
         });
     }
     // the epilogue starts with a barrier before it reuses the LDS
+}
+
+template <int WMT>
+__device__ __forceinline__ void board_se_stage(const BoardSeParams& sp, unsigned char* smem, f32x4 (&acc)[WMT][kBoardNJ], int tile,
+                                               int wave, int lane, int col0, int nj, int bs, unsigned long long* dbg = nullptr) {
+    board_se_pool<WMT>(sp, smem, acc, tile, wave, lane, col0, nj, bs);
+    board_se_fc<WMT>(sp, smem, wave * 64 + lane, bs, dbg);
+    board_se_gate<WMT>(sp, smem, acc, wave, lane);
 }
 
 template <int WMT>

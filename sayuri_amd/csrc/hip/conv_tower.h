@@ -52,11 +52,46 @@ __device__ __forceinline__ TowerLayerCP tower_launder(TowerLayerCP p) {
     return p;
 }
 
-// The compiled bodies (tile = workgroup, one channel tile): SE = false is conv_board_kernel, SE = true
-// conv_board_se_kernel.  Two bodies, not one with a flag: behind a run-time `if` the SE stage makes hipcc park 22
-// accumulator tiles in scratch (748 bytes per lane); the seam picks the body by the element's has_se.  The launch
-// enters through the SE = false kernel (its descriptor carries the resources of both).
-template <int WMT, bool SE>
+// ---- the SE unit inside the run ----------------------------------------------------------------------------------
+// Compiled in one piece with the convolution (rounds 2-3: a second body, conv_tower_kernel<WMT, true>) hipcc re-assigned the
+// 192 accumulator registers after the K loop -- ~60 of the AGPR values copied to VGPRs, six tiles parked in scratch, the
+// pooling reduction three times the instructions it needs -- and the unit cost +17 us per layer.  Now there is ONE convolution
+// body.  Right behind its K loop sits a HOOK: an asm statement that names the table element and the thread id as its only
+// operands and clobbers the registers the K loop's transients lived in (kTowerFreeVgpr.., kTowerFreeSgprs).  tower_seam.py
+// replaces the hook by
+//     has_se ?  pooling (generated assembly, on the accumulators where the K loop left them: the script reads the register of
+//               every output tile off the MFMA stream)  ->  the two FCs (tower_se_fc_kernel below: a compiled body of its own
+//               that only sees LDS, entered like a subroutine with its VGPRs renamed into the clobbered range)  ->  the gate
+//               (generated assembly, in place)  :  nothing
+// and the compiled epilogue follows, for which the accumulators simply have other values.  No scratch, no accumulator moves.
+constexpr int kTowerFreeVgpr = 66;   // v[66:127] are the hook's: the K loop keeps its accumulator tiles below (the build checks)
+constexpr int kTowerFreeSgprs = 64;  // s[0:63] are the hook's
+#define SAYURI_TOWER_CLOBBER_V                                                                                                            \
+    "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",   \
+        "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102",  \
+        "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118",   \
+        "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define SAYURI_TOWER_CLOBBER_S                                                                                                            \
+    "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",     \
+        "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",     \
+        "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",     \
+        "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63"
+
+// One asm statement per accumulator tile: "; TOWER_ACC <side> <row tile> <column tile> <register>".
+template <int WMT, int SIDE, int K> __device__ __forceinline__ void tower_anchor_tile(f32x4& t) {
+    constexpr int i = K % WMT, j = K / WMT;
+    if constexpr (K < 32) asm volatile("; TOWER_ACC %1 %2 %3 %0" : "+a"(t) : "n"(SIDE), "n"(i), "n"(j));
+    else asm volatile("; TOWER_ACC %1 %2 %3 %0" : "+v"(t) : "n"(SIDE), "n"(i), "n"(j));
+}
+template <int WMT, int SIDE> __device__ __forceinline__ void tower_anchor(f32x4 (&acc)[WMT][kBoardNJ]) {
+    static_for<WMT * kBoardNJ>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        tower_anchor_tile<WMT, SIDE, k>(acc[k % WMT][k / WMT]);
+    });
+}
+
+// The compiled convolution body (tile = workgroup, one channel tile): K loop, hook, epilogue.
+template <int WMT>
 __global__ __launch_bounds__(512, 2) void conv_tower_kernel(const TowerLayer* layer) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const TowerLayerCP L = (TowerLayerCP)layer;
@@ -74,26 +109,31 @@ __global__ __launch_bounds__(512, 2) void conv_tower_kernel(const TowerLayer* la
     f32x4 acc[WMT][kBoardNJ];
     {
         const BoardParams& bp = *(const BoardParams*)&L->sp.b;
-        board_mainloop<WMT, false, SE ? 1 : 2>(bp, smem, acc, tile, 0, wave, lane, col0, nj == kBoardNJ, bs, nullptr,
-                                         (const __attribute__((address_space(4))) BoardParams*)&L->sp.b);
+        board_mainloop<WMT, false, 2>(bp, smem, acc, tile, 0, wave, lane, col0, nj == kBoardNJ, bs, nullptr,
+                                      (const __attribute__((address_space(4))) BoardParams*)&L->sp.b);
     }
-    // everything the SE stage and the epilogue need is derived again from (table element, thread id, workgroup id)
-    // behind an opaque point: nothing but those three stays alive across the K loop
-    const TowerLayerCP L2 = tower_launder(L);
+    // The hook (see above; the operand list is what tower_seam.py parses).  Everything the epilogue needs is derived again from
+    // (table element, thread id, workgroup id) behind it: nothing but those three stays alive across the K loop.
+    // The anchors in front of it name every accumulator tile as a read-write operand of its K-loop register class and print its
+    // register: the tiles are in THOSE registers at the hook and whatever copy the compiler made earlier is dead.  tower_seam.py
+    // fails the build if any instruction sits between the first anchor and the hook.
+    TowerLayerCP L2 = L;
     int tid2 = tid;
-    asm volatile("" : "+v"(tid2));
+    tower_anchor<WMT, 0>(acc);
+    asm volatile("; TOWER_SE_HOOK elem=%0 tid=%1 wmt=%2 ui=%3 cols=%4 w1h=%5 w2h=%6 w1b=%7 w2b=%8 psum=%9 pmax=%10 gate=%11 kot=%12"
+                 : "+s"(L2), "+v"(tid2)
+                 : "n"(WMT), "n"(offsetof(TowerLayer, sp.b.uniform_info)), "n"(offsetof(TowerLayer, sp.b.tab_cols)),
+                   "n"(offsetof(TowerLayer, sp.w1h)), "n"(offsetof(TowerLayer, sp.w2h)), "n"(offsetof(TowerLayer, sp.w1_bytes)),
+                   "n"(offsetof(TowerLayer, sp.w2_bytes)), "n"(SeLds<WMT>::psum), "n"(SeLds<WMT>::pmax), "n"(SeLds<WMT>::gate),
+                   "n"(BoardCfg<WMT>::KO_T)
+                 : "memory", "vcc", "scc", SAYURI_TOWER_CLOBBER_V, SAYURI_TOWER_CLOBBER_S);
     const BoardSeParams& sp = *(const BoardSeParams*)&L2->sp;
     const BoardParams& bp = sp.b;
     const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
     const int ui2 = bp.uniform_info;
     const int info2 = ui2 >= 0 ? ui2 : __builtin_amdgcn_readfirstlane(bp.tab_cols[tile]);
-    const int ncols2 = info2 & 0xff, bs2 = info2 >> 8, nj02 = (ncols2 + 1) >> 1;
+    const int ncols2 = info2 & 0xff, nj02 = (ncols2 + 1) >> 1;
     const int col02 = (wave2 >> 2) ? nj02 : 0, nj2 = (wave2 >> 2) ? ncols2 - nj02 : nj02;
-    if constexpr (SE) {
-        board_se_stage<WMT>(sp, smem, acc, tile, wave2, lane2, col02, nj2, bs2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // gate fully read before the epilogue's residual pieces land in the same LDS
-    }
     switch (bp.c.act) {
     case kMish: board_epilogue<WMT, kMish>(bp, smem, acc, tile, 0, wave2, lane2, col02, nj2); break;
     case kIdentity: board_epilogue<WMT, kIdentity>(bp, smem, acc, tile, 0, wave2, lane2, col02, nj2); break;
@@ -104,6 +144,19 @@ __global__ __launch_bounds__(512, 2) void conv_tower_kernel(const TowerLayer* la
     case kGELU: board_epilogue<WMT, kGELU>(bp, smem, acc, tile, 0, wave2, lane2, col02, nj2); break;
     default: board_epilogue<WMT, kHardSwish>(bp, smem, acc, tile, 0, wave2, lane2, col02, nj2); break;
     }
+}
+
+// The FCs of the SE unit as a body of their own: pooled partials in LDS -> gate in LDS (board_se_fc, conv_board.h).  Entered
+// from the hook like a subroutine (s[0:1] = the element, s2 = workgroup id, v0 = thread id), every s_endpgm returns there.
+// It may use neither AGPRs nor scratch nor more than 128 - kTowerFreeVgpr VGPRs / kTowerFreeSgprs SGPRs: tower_seam.py checks.
+template <int WMT>
+__global__ __launch_bounds__(512) void tower_se_fc_kernel(const TowerLayer* layer) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const BoardSeParams& sp = layer->sp;
+    const int ui = sp.b.uniform_info;
+    const int info = ui >= 0 ? ui : __builtin_amdgcn_readfirstlane(sp.b.tab_cols[tile]);
+    board_se_fc<WMT, 4>(sp, smem, tid, info >> 8);
 }
 
 }  // namespace sayuri

@@ -144,6 +144,7 @@ struct EngineFlags {
     ConvOverride conv;
     bool tower = true, se_fused = true, heads_fused = true, arith = true;
     bool io_v2 = true;                 // SAYURI_IO_V2=0: geometry / small outputs by copies again (A/B; see submit())
+    bool io_zc = true, io_geom = true, io_prefix = true;  // its three parts, one at a time (SAYURI_IO_ZC / _GEOM / _PREFIX = 0)
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     int compute_streams = 1;
     int board_kot = 0;                 // experiments: only this channel tile
@@ -159,6 +160,9 @@ struct EngineFlags {
         f.tower = !off("SAYURI_TOWER");
         f.tower_chain = !off("SAYURI_TOWER_CHAIN");
         f.io_v2 = !off("SAYURI_IO_V2");
+        f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");
+        f.io_geom = f.io_v2 && !off("SAYURI_IO_GEOM");
+        f.io_prefix = f.io_v2 && !off("SAYURI_IO_PREFIX");
         f.se_fused = !off("SAYURI_SE_FUSED");
         f.heads_fused = !off("SAYURI_HEADS_FUSED");
         f.arith = !getenv("SAYURI_NO_ARITH");
@@ -414,8 +418,8 @@ extern "C" const unsigned char sayuri_tower_hsaco[];
 namespace sayuri {
 static int load_tower_module(hipModule_t* mod, hipFunction_t fn[2]) {
     HIP_OK(hipModuleLoadData(mod, sayuri_tower_hsaco));
-    HIP_OK(hipModuleGetFunction(&fn[0], *mod, "_ZN6sayuri17conv_tower_kernelILi4ELb0EEEvPKNS_10TowerLayerE"));
-    HIP_OK(hipModuleGetFunction(&fn[1], *mod, "_ZN6sayuri17conv_tower_kernelILi2ELb0EEEvPKNS_10TowerLayerE"));
+    HIP_OK(hipModuleGetFunction(&fn[0], *mod, "_ZN6sayuri17conv_tower_kernelILi4EEEvPKNS_10TowerLayerE"));
+    HIP_OK(hipModuleGetFunction(&fn[1], *mod, "_ZN6sayuri17conv_tower_kernelILi2EEEvPKNS_10TowerLayerE"));
     return 0;
 }
 
@@ -539,8 +543,8 @@ public:
         // So nothing small is copied any more: the heads kernel stores pass / misc straight into the caller's pinned
         // buffers (20 KB of posted PCIe writes), a uniform batch uses geometry arrays that are resident (enqueue_inputs),
         // and the tower table does not depend on the batch size (tower_append).  The two large outputs keep their DMA copies.
-        zc_pass_ = flags_.io_v2 ? pass : nullptr;
-        zc_misc_ = flags_.io_v2 ? misc : nullptr;
+        zc_pass_ = flags_.io_zc ? pass : nullptr;
+        zc_misc_ = flags_.io_zc ? misc : nullptr;
         const int frc = forward();
         const bool small_direct = zc_pass_ != nullptr;
         zc_pass_ = zc_misc_ = nullptr;
@@ -668,22 +672,26 @@ public:
         // One sample per tile and one board size: the tables of a LONGER batch of the same size serve a shorter one (tile i
         // depends on sample i alone), so a queue that alternates between 256 and 250 positions keeps its tables.
         const bool one_per_tile = uniform && 2 * geom_.bsz[0] * geom_.bsz[0] > kBoardPT;
-        const bool prefix = flags_.io_v2 && one_per_tile && slot.tabs_single && slot.tabs_bsz.size() >= (size_t)n &&
+        const bool prefix = flags_.io_prefix && one_per_tile && slot.tabs_single && slot.tabs_bsz.size() >= (size_t)n &&
                             slot.tabs_bsz[0] == geom_.bsz[0];
         if (!prefix && slot.tabs_bsz != geom_.bsz) {  // this slot's tables were built for another geometry
             for (auto& kv : slot.tabs) kv.second.fresh = false;
             slot.board.fresh = false;
             slot.tabs_bsz = geom_.bsz;
             slot.tabs_single = one_per_tile;
-        } else if (prefix && slot.tabs_bsz.size() != (size_t)n) {
-            for (auto& kv : slot.tabs) kv.second.fresh = false;  // the tables of the across-sample tiles (conv_glds.h) know the pixel total
+        }
+        // the tables of the across-sample tiles (conv_glds.h) know the pixel total: they serve exactly the batch size they were
+        // built for (the board tables above serve every prefix)
+        if (slot.tabs_n != n) {
+            for (auto& kv : slot.tabs) kv.second.fresh = false;
+            slot.tabs_n = n;
         }
         // Geometry arrays on the device.  A uniform batch (the self-play queue: every position on the NN board) uses arrays
         // that are resident -- off[i] = i * bs^2, bsz[i] = bs, perm[i] = i hold for every n -- so nothing is copied.  A mixed
         // batch stages its arrays in a pinned ring and a one-workgroup kernel ON THE FORWARD'S OWN STREAM moves them: a
         // copy of a few KB is a blit kernel to the runtime, and on the copy stream it would wait for the other ticket's
         // persistent tower launch to give up a CU (see submit()).
-        if (flags_.io_v2) {
+        if (flags_.io_geom) {
             if (uniform) {
                 const IdentGeom* id = ident_geom(geom_.bsz[0]);
                 if (!id) return -1;
@@ -926,7 +934,11 @@ private:
         void* q = nullptr;
         const size_t bytes = std::max<size_t>(count * sizeof(U), 256);
         HIP_OK(hipMalloc(&q, bytes));
+        // The zero fill runs on the NULL stream and hipMemset returns before it has: this engine's streams are non-blocking, so
+        // a copy or kernel they write into the new buffer right away could be overtaken by it (round 4: the first packed batch of
+        // a staging slot lost the tail of its records to the fill of the buffer allocated for them one call earlier).
         HIP_OK(hipMemset(q, 0, bytes));
+        HIP_OK(hipStreamSynchronize(nullptr));
         allocs_.push_back(q);
         dev_bytes_ += bytes;
         *p = (U*)q;
@@ -1036,6 +1048,7 @@ private:
         const size_t B2 = (size_t)board_ * board_;
         for (IoSlot& io : io_) {
             if (dev_alloc(&io.planes, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
+            if (dev_alloc(&io.packed, (size_t)max_batch_ * (40 * 12 + 8))) return -1;  // the packed form of the same planes (packed_planes.h)
             if (dev_alloc(&io.off, max_batch_ + 1) || dev_alloc(&io.bsz, max_batch_) || dev_alloc(&io.perm, max_batch_)) return -1;
             if (dev_alloc(&io.prob, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
             if (dev_alloc(&io.pass, (size_t)max_batch_ * desc_.pass_probability_outputs)) return -1;
@@ -1722,6 +1735,7 @@ private:
         BoardTabs board;
         std::vector<int> tabs_bsz;
         bool tabs_single = false;  // tabs_bsz is one board size with one sample per tile
+        int tabs_n = -1;           // batch size the across-sample tables (tabs) were last built for
     };
     IoSlot io_[2];
     hipStream_t compute_[2] = {nullptr, nullptr};

@@ -4,8 +4,8 @@
 #include "conv_tower.h"
 
 namespace sayuri {
-template __global__ void conv_tower_kernel<4, false>(const TowerLayer*);
-template __global__ void conv_tower_kernel<4, true>(const TowerLayer*);
-template __global__ void conv_tower_kernel<2, false>(const TowerLayer*);
-template __global__ void conv_tower_kernel<2, true>(const TowerLayer*);
+template __global__ void conv_tower_kernel<4>(const TowerLayer*);
+template __global__ void tower_se_fc_kernel<4>(const TowerLayer*);
+template __global__ void conv_tower_kernel<2>(const TowerLayer*);
+template __global__ void tower_se_fc_kernel<2>(const TowerLayer*);
 }  // namespace sayuri

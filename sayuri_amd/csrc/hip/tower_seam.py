@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
-"""Close the layer loop of the persistent tower launch in the assembly hipcc emits for tower.hip.
+"""Close the layer loop of the persistent tower launch in the assembly hipcc emits for tower.hip, and put the SE unit
+into it as generated assembly.
 
-    python tower_seam.py tower.s tower_seamed.s [--inv]
+    python tower_seam.py tower.s tower_seamed.s [--inv] [--sleep=N] [--align=A --pad=P]
 
-conv_tower.h explains why the loop is not written in C++.  hipcc compiles, per channel-tile width W, two single-layer
-kernels  conv_tower_kernel<W, false>  (plain convolution)  and  conv_tower_kernel<W, true>  (convolution + SE unit);
-each takes ONE argument, a pointer to a TowerLayer, loaded from s[0:1] + 0.  This script turns the pair into one
-persistent kernel (entered through the <W, false> symbol):
+conv_tower.h explains why neither is written in C++.  hipcc compiles, per channel-tile width W, two single-layer kernels
+    conv_tower_kernel<W>    K loop | hook | epilogue        (the convolution body)
+    tower_se_fc_kernel<W>   pooled partials in LDS -> gate in LDS   (the FCs of the SE unit)
+each with ONE argument, a pointer to a TowerLayer, loaded from s[0:1] + 0.  This script turns the pair into one persistent
+kernel (entered through the conv_tower_kernel<W> symbol):
 
   entry stub     s[B:B+1] <- the table pointer (the launch's only argument), s[B+2] <- workgroup id, s[B+3] <- wave id,
-                 where B is the first SGPR neither compiled body allocates
+                 where B is the first SGPR no compiled body allocates
   dispatch       rebuilds the ABI entry state for the element at s[B:B+1] -- s[0:1] = its address (the element starts
                  with its own address, so it reads as a kernarg segment), s2 = workgroup id, v0 = thread id, exec = -1 --
-                 and enters the body the element's has_se asks for
-  seam           every s_endpgm of both bodies becomes a branch to:  s_waitcnt vmcnt(0) lgkmcnt(0) (this wave's stores
-                 are acknowledged), s_barrier (all eight waves'), then end if the element was the last of the run, else
+                 parks the element's has_se in s[B+4] and enters the convolution body
+  hook           the `; TOWER_SE_HOOK` asm statement behind the K loop becomes: has_se == 0 ? nothing :
+                     pooling over the accumulators IN THE REGISTERS THE K LOOP LEFT THEM IN (read off the `; TOWER_ACC`
+                     anchors that precede the hook) -> partial sums / maxima in LDS, the FC images on their way by LDS-DMA
+                     far jump into the FC body (its VGPRs renamed into the range the hook statement clobbers), which
+                     returns through every one of its s_endpgm
+                     the gate, x <- sigmoid(gamma) x + beta, in place
+  seam           every s_endpgm of the convolution body becomes a branch to:  s_waitcnt vmcnt(0) lgkmcnt(0) (this wave's
+                 stores are acknowledged), s_barrier (all eight waves'), then end if the element was the last of the run, else
                  s[B:B+1] += STRIDE and back to dispatch.
 
-The launch kernel's descriptor and metadata get the union of both bodies' resources (SGPRs incl. the four parked ones,
-scratch) and the whole 160 KiB of LDS as its static group segment (the bodies address it from 0).
-Fails loudly when the assembly does not look like what it was written against.
+The launch kernel's descriptor and metadata get the union of the bodies' resources (SGPRs incl. the five parked ones) and the
+whole 160 KiB of LDS as its static group segment (the bodies address it from 0).  Scratch: none -- the build fails if any body
+wants it.  Fails loudly when the assembly does not look like what it was written against.
+
+What the generated pooling / gate must reproduce bit for bit is board_se_pool / board_se_gate (conv_board.h): the per-layer
+kernel conv_board_se_kernel runs those, and SAYURI_TOWER=0/1 give identical outputs (tests/test_gpu_smallops.py).
 """
 import re
 import sys
@@ -27,8 +38,13 @@ import sys
 STRIDE = 320       # sizeof(TowerLayer), conv_tower.h kTowerStride
 LAST_OFFSET = 8    # offsetof(TowerLayer, last); has_se follows it
 LDS_BYTES = 160 * 1024
+FREE_VGPR = 66     # conv_tower.h kTowerFreeVgpr: v[66:127] belong to the hook
+FREE_SGPRS = 64    # conv_tower.h kTowerFreeSgprs: s[0:63] belong to the hook
+FC_SGPR_CAP = 40   # the FC body may use s[0:39]; the hook keeps what must survive the call in s[40:63]
+NJ = 12            # conv_board.h kBoardNJ
 
-KERNEL_RE = re.compile(r"^(_ZN6sayuri17conv_tower_kernelILi(\d+)ELb([01])EEEvPKNS_10TowerLayerE):")
+CONV_RE = re.compile(r"^(_ZN6sayuri17conv_tower_kernelILi(\d+)EEEvPKNS_10TowerLayerE):")
+FC_RE = re.compile(r"^(_ZN6sayuri18tower_se_fc_kernelILi(\d+)EEEvPKNS_10TowerLayerE):")
 
 
 def die(msg):
@@ -44,19 +60,293 @@ def far_jump(sym, t=4):
             f"\ts_setpc_b64 s[{t}:{t + 1}]"]
 
 
+def is_instruction(ln):
+    s = ln.strip()
+    return bool(s) and ln.startswith("\t") and not s.startswith(".") and not s.startswith(";")
+
+
+def rename_vgprs(ln, shift):
+    """v<N> -> v<N+shift> in the operands of one line of compiled assembly (mnemonics never match: `v_`)."""
+    code, sep, comment = ln.partition(";")
+    code = re.sub(r"\bv\[(\d+):(\d+)\]", lambda m: f"v[{int(m.group(1)) + shift}:{int(m.group(2)) + shift}]", code)
+    code = re.sub(r"\bv(\d+)\b", lambda m: f"v{int(m.group(1)) + shift}", code)
+    return code + sep + comment
+
+
+def max_reg(body, cls):
+    hi = -1
+    for ln in body:
+        code = ln.split(";")[0]
+        for m in re.finditer(r"\b%s\[(\d+):(\d+)\]" % cls, code):
+            hi = max(hi, int(m.group(2)))
+        for m in re.finditer(r"\b%s(\d+)\b" % cls, code):
+            hi = max(hi, int(m.group(1)))
+    return hi
+
+
+class Regs:
+    """Names for the hook's registers: v[FREE_VGPR:127] and s[0:FREE_SGPRS-1]; `keep` SGPRs survive the FC call."""
+
+    def __init__(self):
+        self.v_next, self.s_low, self.s_keep = FREE_VGPR, 4, FC_SGPR_CAP  # s[0:3] are set up for the call itself
+
+    def v(self, n=1, align=1):
+        self.v_next = (self.v_next + align - 1) // align * align
+        r = self.v_next
+        self.v_next += n
+        if self.v_next > 128:
+            die("the hook ran out of VGPRs")
+        return r
+
+    def s(self, n=1, keep=False):
+        if keep:
+            self.s_keep = (self.s_keep + n - 1) // n * n
+            r = self.s_keep
+            self.s_keep += n
+            if self.s_keep > FREE_SGPRS:
+                die("the hook ran out of SGPRs")
+            return r
+        self.s_low = (self.s_low + n - 1) // n * n
+        r = self.s_low
+        self.s_low += n
+        if self.s_low > FC_SGPR_CAP:
+            die("the hook ran out of scratch SGPRs")
+        return r
+
+
+def vr(lo, n=1):
+    return f"v{lo}" if n == 1 else f"v[{lo}:{lo + n - 1}]"
+
+
+def sr(lo, n=1):
+    return f"s{lo}" if n == 1 else f"s[{lo}:{lo + n - 1}]"
+
+
+def se_hook(w, hook, acc, B, fc_label):
+    """The SE unit between the K loop and the epilogue of width-w's convolution body, as assembly text.
+    hook: the parsed operands of the TOWER_SE_HOOK statement; acc[(i, j)] = ('a' | 'v', first register) of output tile
+    (row tile i, column tile j); B: first parked SGPR (table B:B+1, workgroup B+2, wave B+3, has_se B+4)."""
+    wmt, kot = hook["wmt"], hook["kot"]
+    E, T = hook["elem"], hook["tid"]          # s[lo:lo+1] text, v text
+    WG, WAVE, HAS_SE = f"s{B + 2}", f"s{B + 3}", f"s{B + 4}"
+    L = f".Ltower{w}_se"
+    R = Regs()
+    o = []
+    a = o.append
+
+    # ---- registers
+    s_m0 = R.s(keep=True)
+    s_w1h, s_w2h = R.s(2, keep=True), R.s(2, keep=True)
+    s_wb = R.s(2, keep=True)                  # w1_bytes, w2_bytes
+    s_wbytes = R.s(keep=True)                 # bytes of LDS in front of the stage's vectors
+    s_wave_m = R.s(keep=True)
+    s_info, s_ncols, s_bs, s_nj0, s_wave_n, s_col0, s_nj, s_njm1 = (R.s() for _ in range(8))
+    s_t0, s_t1, s_k, s_n = (R.s() for _ in range(4))
+    s_p = R.s(2)
+    s_valid, s_px0, s_save = R.s(2), R.s(2), R.s(2)
+    v_lane, v_lane16, v_px, v_q, v_t, v_addr = (R.v() for _ in range(6))
+    sets = [(R.v(4, 4), R.v(4, 4)) for _ in range(2)]     # (sums, maxima) of a row tile, alternating
+    xs = [R.v(4, 4) for _ in range(2)]                    # an AGPR tile on its way through the VALU, alternating
+
+    a(f"\t; ---- tower_seam.py: the SE unit (width {w}: {wmt} row tiles x {NJ} column tiles per wave)")
+    a(f"\ts_cmp_eq_u32 {HAS_SE}, 0")
+    a(f"\ts_cbranch_scc1 {L}_skip")
+    a(f"\ts_mov_b32 {sr(s_m0)}, m0")
+    a("\ts_waitcnt lgkmcnt(0)")
+    a("\ts_barrier")                          # every wave is done with the rings
+    a(f"\ts_load_dwordx2 {sr(s_w1h, 2)}, {E}, {hex(hook['w1h'])}")
+    a(f"\ts_load_dwordx2 {sr(s_w2h, 2)}, {E}, {hex(hook['w2h'])}")
+    if hook["w2b"] != hook["w1b"] + 4:
+        die("w1_bytes / w2_bytes are not adjacent in BoardSeParams")
+    a(f"\ts_load_dwordx2 {sr(s_wb, 2)}, {E}, {hex(hook['w1b'])}")
+    a(f"\ts_load_dword {sr(s_info)}, {E}, {hex(hook['ui'])}")
+    a(f"\tv_and_b32_e32 {vr(v_lane)}, 63, {T}")
+    a(f"\tv_lshlrev_b32_e32 {vr(v_lane16)}, 4, {vr(v_lane)}")
+    a(f"\tv_and_b32_e32 {vr(v_px)}, 15, {vr(v_lane)}")
+    a(f"\tv_lshrrev_b32_e32 {vr(v_q)}, 4, {vr(v_lane)}")
+    a("\ts_waitcnt lgkmcnt(0)")
+    a(f"\ts_cmp_gt_i32 {sr(s_info)}, -1")
+    a(f"\ts_cbranch_scc1 {L}_info")
+    a(f"\ts_load_dwordx2 {sr(s_p, 2)}, {E}, {hex(hook['cols'])}")
+    a(f"\ts_lshl_b32 {sr(s_t0)}, {WG}, 2")
+    a("\ts_waitcnt lgkmcnt(0)")
+    a(f"\ts_load_dword {sr(s_info)}, {sr(s_p, 2)}, {sr(s_t0)}")
+    a("\ts_waitcnt lgkmcnt(0)")
+    a(f"{L}_info:")
+    a(f"\ts_and_b32 {sr(s_ncols)}, {sr(s_info)}, 0xff")
+    a(f"\ts_lshr_b32 {sr(s_bs)}, {sr(s_info)}, 8")
+    a(f"\ts_add_u32 {sr(s_nj0)}, {sr(s_ncols)}, 1")
+    a(f"\ts_lshr_b32 {sr(s_nj0)}, {sr(s_nj0)}, 1")
+    a(f"\ts_lshr_b32 {sr(s_wave_n)}, {WAVE}, 2")
+    a(f"\ts_and_b32 {sr(s_wave_m)}, {WAVE}, 3")
+    a(f"\ts_sub_u32 {sr(s_t0)}, {sr(s_ncols)}, {sr(s_nj0)}")
+    a(f"\ts_cmp_eq_u32 {sr(s_wave_n)}, 0")
+    a(f"\ts_cselect_b32 {sr(s_col0)}, 0, {sr(s_nj0)}")
+    a(f"\ts_cselect_b32 {sr(s_nj)}, {sr(s_nj0)}, {sr(s_t0)}")
+    a(f"\ts_sub_u32 {sr(s_njm1)}, {sr(s_nj)}, 1")
+    a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_wb)}, {sr(s_wb + 1)}")
+    a(f"\ts_cmp_lg_u64 {sr(s_w1h, 2)}, 0")
+    a(f"\ts_cselect_b32 {sr(s_wbytes)}, {sr(s_t0)}, 0")
+    a(f"\ts_cbranch_scc0 {L}_nostage")
+    # ---- both FC images on their way into LDS: linear 1 KiB pieces, piece k by wave k % 8; the squeeze image of this
+    # tile's board size first
+    a(f"\ts_sub_u32 {sr(s_t0)}, {sr(s_bs)}, 2")
+    a(f"\ts_mul_hi_u32 {sr(s_t1)}, {sr(s_t0)}, {sr(s_wb)}")
+    a(f"\ts_mul_i32 {sr(s_t0)}, {sr(s_t0)}, {sr(s_wb)}")
+    a(f"\ts_add_u32 {sr(s_w1h)}, {sr(s_w1h)}, {sr(s_t0)}")
+    a(f"\ts_addc_u32 {sr(s_w1h + 1)}, {sr(s_w1h + 1)}, {sr(s_t1)}")
+    for tag, base, nbytes, lds0 in (("1", s_w1h, s_wb, None), ("2", s_w2h, s_wb + 1, s_wb)):
+        a(f"\ts_lshr_b32 {sr(s_n)}, {sr(nbytes)}, 10")
+        a(f"\ts_mov_b32 {sr(s_k)}, {WAVE}")
+        a(f"{L}_dma{tag}:")
+        a(f"\ts_cmp_ge_u32 {sr(s_k)}, {sr(s_n)}")
+        a(f"\ts_cbranch_scc1 {L}_dma{tag}_done")
+        a(f"\ts_lshl_b32 {sr(s_t0)}, {sr(s_k)}, 10")
+        a(f"\ts_add_u32 {sr(s_p)}, {sr(base)}, {sr(s_t0)}")
+        a(f"\ts_addc_u32 {sr(s_p + 1)}, {sr(base + 1)}, 0")
+        if lds0 is not None:
+            a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_t0)}, {sr(lds0)}")
+        a(f"\ts_mov_b32 m0, {sr(s_t0)}")
+        a("\ts_nop 4")
+        a(f"\tglobal_load_lds_dwordx4 {vr(v_lane16)}, {sr(s_p, 2)}")
+        a(f"\ts_add_u32 {sr(s_k)}, {sr(s_k)}, 8")
+        a(f"\ts_branch {L}_dma{tag}")
+        a(f"{L}_dma{tag}_done:")
+    a(f"{L}_nostage:")
+    # ---- pooling.  last_valid (lane): (col0 + nj - 1) * 16 + px < bs * bs -- a one-sample tile has its unused pixel slots at
+    # the end, only the wave's last column tile can hold any
+    a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_col0)}, {sr(s_njm1)}")
+    a(f"\ts_lshl_b32 {sr(s_t0)}, {sr(s_t0)}, 4")
+    a(f"\tv_add_u32_e32 {vr(v_t)}, {sr(s_t0)}, {vr(v_px)}")
+    a(f"\ts_mul_i32 {sr(s_t1)}, {sr(s_bs)}, {sr(s_bs)}")
+    a(f"\tv_cmp_gt_u32_e64 {sr(s_valid, 2)}, {sr(s_t1)}, {vr(v_t)}")
+    a(f"\tv_cmp_eq_u32_e64 {sr(s_px0, 2)}, 0, {vr(v_px)}")
+    # psum[wave_n * KO_T + wave_m * WMT * 16 + i * 16 + 4 q] (floats) behind the images
+    a(f"\ts_mul_i32 {sr(s_t0)}, {sr(s_wave_n)}, {kot * 4}")
+    a(f"\ts_mul_i32 {sr(s_t1)}, {sr(s_wave_m)}, {wmt * 16 * 4}")
+    a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_t0)}, {sr(s_t1)}")
+    a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_t0)}, {sr(s_wbytes)}")
+    a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_t0)}, {hook['psum']}")
+    a(f"\tv_lshl_add_u32 {vr(v_addr)}, {vr(v_q)}, 4, {sr(s_t0)}")
+
+    def tile_ops(i, j, S4, M4, X):
+        """sum += tile, max = max(max, tile) for output tile (i, j); the caller has set exec"""
+        kind, lo = acc[(i, j)]
+        if kind == "a":
+            for r in range(4):
+                a(f"\tv_accvgpr_read_b32 {vr(X + r)}, a{lo + r}")
+            src = X
+        else:
+            src = lo
+        if src % 2 == 0:
+            a(f"\tv_pk_add_f32 {vr(S4, 2)}, {vr(S4, 2)}, {vr(src, 2)}")
+            a(f"\tv_pk_add_f32 {vr(S4 + 2, 2)}, {vr(S4 + 2, 2)}, {vr(src + 2, 2)}")
+        else:
+            for r in range(4):
+                a(f"\tv_add_f32_e32 {vr(S4 + r)}, {vr(S4 + r)}, {vr(src + r)}")
+        for r in range(4):
+            a(f"\tv_max_f32_e32 {vr(M4 + r)}, {vr(M4 + r)}, {vr(src + r)}")
+
+    for i in range(wmt):
+        S4, M4 = sets[i & 1]
+        for r in range(4):
+            a(f"\tv_mov_b32_e32 {vr(S4 + r)}, 0")
+            a(f"\tv_mov_b32_e32 {vr(M4 + r)}, 0xc59c4000")   # -5000.0f
+        a(f"\ts_cmp_lt_i32 {sr(s_nj)}, 1")
+        a(f"\ts_cbranch_scc1 {L}_red{i}")
+        for j in range(NJ):
+            a(f"\ts_cmp_eq_u32 {sr(s_njm1)}, {j}")
+            a(f"\ts_cbranch_scc1 {L}_last{i}_{j}")
+            tile_ops(i, j, S4, M4, xs[j & 1])
+        a(f"\ts_branch {L}_red{i}")
+        for j in range(NJ):
+            a(f"{L}_last{i}_{j}:")
+            a(f"\ts_mov_b64 {sr(s_save, 2)}, exec")
+            a(f"\ts_and_b64 exec, exec, {sr(s_valid, 2)}")
+            tile_ops(i, j, S4, M4, xs[j & 1])
+            a(f"\ts_mov_b64 exec, {sr(s_save, 2)}")
+            if j + 1 < NJ:
+                a(f"\ts_branch {L}_red{i}")
+        a(f"{L}_red{i}:")
+        a("\ts_nop 4")   # a VALU result read by a DPP operand: two wait states; exec written by the SALU: five
+        for step in (8, 4, 2, 1):
+            for r in range(4):
+                a(f"\tv_add_f32_dpp {vr(S4 + r)}, {vr(S4 + r)}, {vr(S4 + r)} row_ror:{step} row_mask:0xf bank_mask:0xf")
+            for r in range(4):
+                a(f"\tv_max_f32_dpp {vr(M4 + r)}, {vr(M4 + r)}, {vr(M4 + r)} row_ror:{step} row_mask:0xf bank_mask:0xf")
+        a(f"\ts_mov_b64 {sr(s_save, 2)}, exec")
+        a(f"\ts_and_b64 exec, exec, {sr(s_px0, 2)}")
+        a(f"\tds_write_b128 {vr(v_addr)}, {vr(S4, 4)} offset:{i * 64}")
+        a(f"\tds_write_b128 {vr(v_addr)}, {vr(M4, 4)} offset:{i * 64 + hook['pmax'] - hook['psum']}")
+        a(f"\ts_mov_b64 exec, {sr(s_save, 2)}")
+    a("\ts_waitcnt vmcnt(0) lgkmcnt(0)")    # this wave's pieces of the images have landed, its partials are written
+    a("\ts_barrier")
+    # ---- the FCs: a compiled body of its own, entered with the ABI's entry state
+    e_lo = int(re.match(r"s\[(\d+):", E).group(1))
+    a(f"\ts_mov_b32 s0, s{e_lo}")
+    a(f"\ts_mov_b32 s1, s{e_lo + 1}")
+    a(f"\ts_mov_b32 s2, {WG}")
+    a(f"\tv_mov_b32_e32 v{FREE_VGPR}, {T}")
+    a("\ts_mov_b64 exec, -1")
+    o.extend(far_jump(fc_label))
+    a(f"tower{w}_se_return:")
+    a("\ts_mov_b64 exec, -1")
+    # ---- the gate: x <- sigmoid(gamma) x + beta, one fused multiply-add per value, in place
+    R2 = Regs()
+    g_lane, g_q, g_addr = R2.v(), R2.v(), R2.v()
+    gs = [(R2.v(4, 4), R2.v(4, 4)) for _ in range(wmt)]
+    gx = [R2.v(4, 4) for _ in range(2)]
+    a(f"\tv_and_b32_e32 {vr(g_lane)}, 63, {T}")
+    a(f"\tv_lshrrev_b32_e32 {vr(g_q)}, 4, {vr(g_lane)}")
+    a(f"\ts_mul_i32 s4, {sr(s_wave_m)}, {wmt * 16 * 4}")
+    a(f"\ts_add_u32 s4, s4, {sr(s_wbytes)}")
+    a(f"\ts_add_u32 s4, s4, {hook['gate']}")
+    a(f"\tv_lshl_add_u32 {vr(g_addr)}, {vr(g_q)}, 4, s4")
+    for i in range(wmt):
+        a(f"\tds_read_b128 {vr(gs[i][0], 4)}, {vr(g_addr)} offset:{i * 64}")
+        a(f"\tds_read_b128 {vr(gs[i][1], 4)}, {vr(g_addr)} offset:{i * 64 + kot * 4}")
+    a("\ts_waitcnt lgkmcnt(0)")
+    a("\ts_barrier")                         # the gate is read: the epilogue's residual rows may land in this LDS
+
+    def fma_tile(G, Bt, t):
+        if t % 2 == 0:
+            a(f"\tv_pk_fma_f32 {vr(t, 2)}, {vr(G, 2)}, {vr(t, 2)}, {vr(Bt, 2)}")
+            a(f"\tv_pk_fma_f32 {vr(t + 2, 2)}, {vr(G + 2, 2)}, {vr(t + 2, 2)}, {vr(Bt + 2, 2)}")
+        else:
+            for r in range(4):
+                a(f"\tv_fma_f32 {vr(t + r)}, {vr(G + r)}, {vr(t + r)}, {vr(Bt + r)}")
+
+    tiles = [(i, j) for i in range(wmt) for j in range(NJ)]
+    agpr = [t for t in tiles if acc[t][0] == "a"]
+    for k in range(0, len(agpr), 2):
+        pair = agpr[k:k + 2]
+        for n, t in enumerate(pair):
+            for r in range(4):
+                a(f"\tv_accvgpr_read_b32 {vr(gx[n] + r)}, a{acc[t][1] + r}")
+        for n, t in enumerate(pair):
+            fma_tile(gs[t[0]][0], gs[t[0]][1], gx[n])
+        for n, t in enumerate(pair):
+            for r in range(4):
+                a(f"\tv_accvgpr_write_b32 a{acc[t][1] + r}, {vr(gx[n] + r)}")
+    for t in tiles:
+        if acc[t][0] == "v":
+            fma_tile(gs[t[0]][0], gs[t[0]][1], acc[t][1])
+    a(f"\ts_mov_b32 m0, {sr(s_m0)}")
+    a(f"{L}_skip:")
+    return o
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     inv = "--inv" in sys.argv
     # measuring builds only: --sleep=N parks every wave for N x 64 cycles in the seam (what does a stall cost a chip that
     # runs at its power limit?)
     sleep = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--sleep=")), 0)
-    # placement of the compiled bodies: each starts on a 2^align-byte boundary plus pad bytes (control never falls into a body,
+    # placement of the convolution body: it starts on a 2^align-byte boundary plus pad bytes (control never falls into a body,
     # so the padding is never executed); the K loop sits at a fixed distance from the body's first instruction
     align = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--align=")), 0)
     pad = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--pad=")), 0)
     place = ([f"\t.p2align {align}"] if align else []) + (["\ts_nop 0"] * (pad // 4))
-    pad_se = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--pad-se=")), 0)  # the SE body: its symbol is 256-aligned
-    place_se = ["\ts_nop 0"] * (pad_se // 4)
     if len(args) != 2:
         die("usage: tower_seam.py in.s out.s [--inv]")
     lines = open(args[0]).read().split("\n")
@@ -65,23 +355,24 @@ def main():
     funcs = {}
     i = 0
     while i < len(lines):
-        m = KERNEL_RE.match(lines[i])
+        m = CONV_RE.match(lines[i]) or FC_RE.match(lines[i])
         if m:
-            name, w, se = m.group(1), int(m.group(2)), int(m.group(3))
+            kind = "conv" if CONV_RE.match(lines[i]) else "fc"
+            name, w = m.group(1), int(m.group(2))
             j = i + 1
             while j < len(lines) and not lines[j].startswith("\t.section\t.rodata"):
                 j += 1
             if j == len(lines):
                 die("no .rodata section after " + name)
-            funcs[(w, se)] = dict(name=name, begin=i, end=j)
+            funcs[(w, kind)] = dict(name=name, begin=i, end=j)
             i = j
         i += 1
     widths = sorted({w for (w, _) in funcs})
     if not widths:
         die("no conv_tower_kernel in the input")
     for w in widths:
-        if (w, 0) not in funcs or (w, 1) not in funcs:
-            die(f"conv_tower_kernel<{w}, false/true> must both be present")
+        if (w, "conv") not in funcs or (w, "fc") not in funcs:
+            die(f"conv_tower_kernel<{w}> and tower_se_fc_kernel<{w}> must both be present")
 
     def directive(name, key):
         """value of `.amdhsa_<key>` inside the descriptor of kernel `name` (and its line index)"""
@@ -97,33 +388,105 @@ def main():
 
     edits = {}      # line index -> replacement list
     for w in widths:
-        plain, se = funcs[(w, 0)], funcs[(w, 1)]
-        for f in (plain, se):
+        conv, fc = funcs[(w, "conv")], funcs[(w, "fc")]
+        for f in (conv, fc):
             for key, want in (("user_sgpr_count", 2), ("user_sgpr_kernarg_segment_ptr", 1), ("system_sgpr_workgroup_id_x", 1),
                               ("system_sgpr_workgroup_id_y", 0), ("system_sgpr_workgroup_id_z", 0), ("system_vgpr_workitem_id", 0),
                               ("kernarg_size", 8), ("group_segment_fixed_size", 0), ("user_sgpr_kernarg_preload_length", 0),
-                              ("uses_dynamic_stack", 0)):
+                              ("uses_dynamic_stack", 0), ("private_segment_fixed_size", 0)):
                 got, _ = directive(f["name"], key)
                 if got != want:
                     die(f"{f['name']}: .amdhsa_{key} = {got}, the seam was written for {want}")
             body = lines[f["begin"] + 1:f["end"]]
-            first = next((ln for ln in body if ln.startswith("\t") and not ln.startswith("\t.")), "")
+            first = next((ln for ln in body if is_instruction(ln)), "")
             if not re.match(r"\ts_load_dwordx2 s\[\d+:\d+\], s\[0:1\], 0x0", first):
                 die(f"{f['name']}: the body does not start by loading its argument from s[0:1] ({first.strip()!r})")
+            if any(re.match(r"\s*scratch_", ln) for ln in body):
+                die(f"{f['name']}: scratch access in a tower body")
             f["sgprs"], _ = directive(f["name"], "next_free_sgpr")
-            f["scratch"], _ = directive(f["name"], "private_segment_fixed_size")
             f["vgprs"], _ = directive(f["name"], "next_free_vgpr")
             f["accum"], _ = directive(f["name"], "accum_offset")
-        if plain["accum"] != se["accum"]:
-            die(f"width {w}: the two bodies put their AGPRs at different offsets of the register file")
-        vgprs = max(plain["vgprs"], se["vgprs"])  # same accum_offset: the launch needs the larger of the two totals
-        B = (max(plain["sgprs"], se["sgprs"]) + 1) & ~1
-        if B + 4 > 102:
-            die(f"width {w}: no four SGPRs left above the compiler's {B}")
-        tab, wg, wv = f"s[{B}:{B + 1}]", f"s{B + 2}", f"s{B + 3}"
-        disp, body_plain, body_se = f"tower{w}_dispatch", f"tower{w}_body_plain", f"tower{w}_body_se"
 
-        entry = [f"\t; ---- tower_seam.py: entry stub (table {tab}, workgroup {wg}, wave {wv})",
+        # ---- the FC body: a subroutine of the hook.  No AGPRs, its VGPRs fit behind FREE_VGPR, its SGPRs below FC_SGPR_CAP
+        fbody = lines[fc["begin"] + 1:fc["end"]]
+        if any(re.search(r"\ba\d+\b|\ba\[\d+:\d+\]|v_accvgpr|v_mfma", ln.split(";")[0]) for ln in fbody):
+            die(f"{fc['name']}: touches AGPRs (they hold the accumulators)")
+        fv, fs = max_reg(fbody, "v"), max_reg(fbody, "s")
+        if fv + FREE_VGPR > 127:
+            die(f"{fc['name']}: v{fv} does not fit behind v{FREE_VGPR} (128 - {FREE_VGPR} VGPRs belong to the hook)")
+        if fs >= FC_SGPR_CAP:
+            die(f"{fc['name']}: s{fs} -- the hook keeps its own values from s{FC_SGPR_CAP} on")
+        if any(re.search(r"\bm0\b|ttmp|flat_scratch|s_getpc|s_setpc|s_swappc|s_call", ln.split(";")[0]) for ln in fbody):
+            die(f"{fc['name']}: uses m0 / calls (not expected in the FC body)")
+        fc_label, fc_ret = f"tower{w}_body_fc", f"tower{w}_se_return"
+        for k in range(fc["begin"] + 1, fc["end"]):
+            if lines[k].strip() == "s_endpgm":
+                edits[k] = far_jump(fc_ret)
+            elif is_instruction(lines[k]):
+                edits[k] = [rename_vgprs(lines[k], FREE_VGPR)]
+        edits[fc["begin"]] = [lines[fc["begin"]], f"{fc_label}:", "\t; ---- compiled body (FCs of the SE unit), VGPRs renamed by tower_seam.py"]
+
+        # ---- the convolution body: anchors and hook
+        cb = range(conv["begin"] + 1, conv["end"])
+        hooks = [k for k in cb if "; TOWER_SE_HOOK " in lines[k]]
+        if len(hooks) != 1:
+            die(f"{conv['name']}: {len(hooks)} TOWER_SE_HOOK statements")
+        hk = hooks[0]
+        hook = {}
+        for tok in lines[hk].split("TOWER_SE_HOOK", 1)[1].split():
+            key, _, val = tok.partition("=")
+            hook[key] = val if key in ("elem", "tid") else int(val, 0)
+        for key in ("elem", "tid", "wmt", "ui", "cols", "w1h", "w2h", "w1b", "w2b", "psum", "pmax", "gate", "kot"):
+            if key not in hook:
+                die(f"{conv['name']}: the hook statement names no `{key}`")
+        if hook["wmt"] != w:
+            die(f"{conv['name']}: the hook says wmt={hook['wmt']}")
+        m = re.match(r"^s\[(\d+):(\d+)\]$", hook["elem"])
+        if not m or int(m.group(1)) < FREE_SGPRS or not re.match(r"^v\d+$", hook["tid"]) or int(hook["tid"][1:]) >= FREE_VGPR:
+            die(f"{conv['name']}: hook operands {hook['elem']} / {hook['tid']} sit inside the clobbered ranges")
+        acc, first_anchor = {}, None
+        for k in cb:
+            m = re.search(r"; TOWER_ACC (\d+) (\d+) (\d+) ([av])\[(\d+):(\d+)\]", lines[k])
+            if not m:
+                continue
+            side, ti, tj, kind, lo, hi = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4), int(m.group(5)), int(m.group(6))
+            if side != 0 or hi != lo + 3 or (ti, tj) in acc or k > hk:
+                die(f"{conv['name']}: unexpected anchor {lines[k].strip()!r}")
+            if kind == "v" and lo + 3 >= FREE_VGPR:
+                die(f"{conv['name']}: accumulator tile ({ti}, {tj}) lives in v[{lo}:{hi}], inside the hook's range")
+            acc[(ti, tj)] = (kind, lo)
+            first_anchor = k if first_anchor is None else first_anchor
+        if len(acc) != w * NJ:
+            die(f"{conv['name']}: {len(acc)} anchors for {w * NJ} output tiles")
+        regs = sorted((kind, lo) for kind, lo in acc.values())
+        if any(regs[n][0] == regs[n + 1][0] and regs[n][1] + 4 > regs[n + 1][1] for n in range(len(regs) - 1)):
+            die(f"{conv['name']}: overlapping accumulator tiles")
+        stray = [lines[k].strip() for k in range(first_anchor, hk) if is_instruction(lines[k])]
+        if stray:
+            die(f"{conv['name']}: instructions between the anchors and the hook ({stray[:3]}): the tiles may have moved")
+        # the MFMAs' results are read by the pooling: the K loop's s_nop 15 pair must be what precedes the anchors
+        before = [lines[k].strip() for k in range(conv["begin"] + 1, first_anchor) if is_instruction(lines[k])][-2:]
+        if before != ["s_nop 15", "s_nop 15"]:
+            die(f"{conv['name']}: {before} in front of the anchors, expected the K loop's two s_nop 15")
+        # every accumulator the MFMA stream writes is an anchored tile
+        written = set()
+        for k in range(conv["begin"] + 1, first_anchor):
+            m = re.match(r"\tv_mfma_\w+ ([av])\[(\d+):(\d+)\]", lines[k])
+            if m:
+                written.add((m.group(1), int(m.group(2))))
+        if written != set(acc.values()):
+            die(f"{conv['name']}: the MFMA stream writes {len(written)} tiles, the anchors name {len(set(acc.values()))} (or others)")
+
+        B = (max(conv["sgprs"], fc["sgprs"]) + 1) & ~1
+        if B + 5 > 102:
+            die(f"width {w}: no five SGPRs left above the compiler's {B}")
+        if B < FREE_SGPRS + 2:
+            B = FREE_SGPRS + 2
+        tab, wg, wv, hs = f"s[{B}:{B + 1}]", f"s{B + 2}", f"s{B + 3}", f"s{B + 4}"
+        disp, body_conv = f"tower{w}_dispatch", f"tower{w}_body_conv"
+        edits[hk] = se_hook(w, hook, acc, B, fc_label)
+
+        entry = [f"\t; ---- tower_seam.py: entry stub (table {tab}, workgroup {wg}, wave {wv}, has_se {hs})",
                  f"\ts_load_dwordx2 {tab}, s[0:1], 0x0",
                  f"\ts_mov_b32 {wg}, s2",
                  f"\tv_readfirstlane_b32 {wv}, v0",
@@ -131,7 +494,7 @@ def main():
                  f"\ts_lshr_b32 {wv}, {wv}, 6",
                  "\ts_waitcnt lgkmcnt(0)",
                  f"{disp}:",
-                 f"\ts_load_dwordx2 s[4:5], {tab}, {hex(LAST_OFFSET)}",
+                 f"\ts_load_dword {hs}, {tab}, {hex(LAST_OFFSET + 4)}",
                  "\ts_mov_b64 exec, -1",
                  f"\ts_mov_b32 s0, s{B}",
                  f"\ts_mov_b32 s1, s{B + 1}",
@@ -140,51 +503,47 @@ def main():
                  "\tv_mbcnt_hi_u32_b32 v0, -1, v0",
                  f"\tv_lshl_or_b32 v0, {wv}, 6, v0",
                  "\ts_waitcnt lgkmcnt(0)",
-                 "\ts_cmp_eq_u32 s5, 0",
-                 f"\ts_cbranch_scc1 {body_plain}"] + far_jump(body_se) + place + [
-                 f"{body_plain}:",
-                 "\t; ---- compiled body (plain convolution)"]
-        edits[plain["begin"]] = [lines[plain["begin"]]] + entry
-        edits[se["begin"]] = [lines[se["begin"]]] + place_se + [f"{body_se}:", "\t; ---- compiled body (convolution + SE unit)"]
+                 f"\ts_branch {body_conv}"] + place + [
+                 f"{body_conv}:",
+                 "\t; ---- compiled body (convolution: K loop, hook, epilogue)"]
+        edits[conv["begin"]] = [lines[conv["begin"]]] + entry
 
-        for tag, f in (("p", plain), ("s", se)):
-            seam, done = f".Ltower{w}{tag}_seam", f".Ltower{w}{tag}_done"
-            ends = [k for k in range(f["begin"], f["end"]) if lines[k].strip() == "s_endpgm"]
-            if not ends:
-                die(f"{f['name']}: no s_endpgm")
-            for k in ends:
-                edits[k] = [f"\ts_branch {seam}"]
-            tail = [f"{seam}:",
-                    "\ts_waitcnt vmcnt(0) lgkmcnt(0)",
-                    f"\ts_load_dword s4, {tab}, {hex(LAST_OFFSET)}",
-                    "\ts_waitcnt lgkmcnt(0)",
-                    "\ts_barrier"]
-            if inv:
-                tail.append("\tbuffer_inv sc1")
-            for _ in range(sleep // 127):
-                tail.append("\ts_sleep 127")
-            if sleep % 127:
-                tail.append(f"\ts_sleep {sleep % 127}")
-            tail += ["\ts_cmp_lg_u32 s4, 0",
-                     f"\ts_cbranch_scc1 {done}",
-                     f"\ts_add_u32 s{B}, s{B}, {STRIDE}",
-                     f"\ts_addc_u32 s{B + 1}, s{B + 1}, 0"] + far_jump(disp) + [
-                     f"{done}:",
-                     "\ts_endpgm"]
-            edits[ends[-1]] = edits[ends[-1]] + tail
+        seam, done = f".Ltower{w}_seam", f".Ltower{w}_done"
+        ends = [k for k in cb if lines[k].strip() == "s_endpgm"]
+        if not ends:
+            die(f"{conv['name']}: no s_endpgm")
+        for k in ends:
+            edits[k] = [f"\ts_branch {seam}"]
+        tail = [f"{seam}:",
+                "\ts_waitcnt vmcnt(0) lgkmcnt(0)",
+                f"\ts_load_dword s4, {tab}, {hex(LAST_OFFSET)}",
+                "\ts_waitcnt lgkmcnt(0)",
+                "\ts_barrier"]
+        if inv:
+            tail.append("\tbuffer_inv sc1")
+        for _ in range(sleep // 127):
+            tail.append("\ts_sleep 127")
+        if sleep % 127:
+            tail.append(f"\ts_sleep {sleep % 127}")
+        tail += ["\ts_cmp_lg_u32 s4, 0",
+                 f"\ts_cbranch_scc1 {done}",
+                 f"\ts_add_u32 s{B}, s{B}, {STRIDE}",
+                 f"\ts_addc_u32 s{B + 1}, s{B + 1}, 0"] + far_jump(disp) + [
+                 f"{done}:",
+                 "\ts_endpgm"]
+        edits[ends[-1]] = edits[ends[-1]] + tail
 
         # ---- the launch kernel's descriptor
-        scratch = max(plain["scratch"], se["scratch"])
-        for key, val in (("next_free_vgpr", vgprs), ("next_free_sgpr", B + 4), ("private_segment_fixed_size", scratch), ("enable_private_segment", 1 if scratch else 0),
-                         ("group_segment_fixed_size", LDS_BYTES)):
-            _, idx = directive(plain["name"], key)
+        if conv["accum"] < FREE_VGPR + fv + 1:
+            die(f"width {w}: accum_offset {conv['accum']} below the FC body's renamed VGPRs")
+        for key, val in (("next_free_sgpr", B + 5), ("group_segment_fixed_size", LDS_BYTES)):
+            _, idx = directive(conv["name"], key)
             edits[idx] = [re.sub(r"\d+\s*$", str(val), lines[idx])]
-        # ---- and its metadata entry (the runtime sizes LDS and scratch from there)
+        # ---- and its metadata entry (the runtime sizes LDS from there)
         try:
-            n = next(k for k, ln in enumerate(lines) if ln.strip() == ".name:           " + plain["name"] or
-                     (ln.strip().startswith(".name:") and ln.split()[-1] == plain["name"]))
+            n = next(k for k, ln in enumerate(lines) if ln.strip().startswith(".name:") and ln.split()[-1] == conv["name"])
         except StopIteration:
-            die("no metadata entry for " + plain["name"])
+            die("no metadata entry for " + conv["name"])
         lo = n
         while not lines[lo].startswith("  - "):
             lo -= 1
@@ -193,13 +552,12 @@ def main():
             hi += 1
         seen = set()
         for k in range(lo, hi + 1):
-            for key, val in ((".group_segment_fixed_size:", LDS_BYTES), (".private_segment_fixed_size:", scratch), (".sgpr_count:", B + 4 + 6), (".vgpr_count:", vgprs),
-                             (".agpr_count:", vgprs - plain["accum"])):
+            for key, val in ((".group_segment_fixed_size:", LDS_BYTES), (".sgpr_count:", B + 5 + 6)):
                 if lines[k].strip().lstrip("- ").startswith(key):
                     edits[k] = [re.sub(r"\d+\s*$", str(val), lines[k])]
                     seen.add(key)
-        if len(seen) != 5:
-            die("metadata entry of " + plain["name"] + " lacks " + str(5 - len(seen)) + " expected keys")
+        if len(seen) != 2:
+            die("metadata entry of " + conv["name"] + " lacks " + str(2 - len(seen)) + " expected keys")
 
     out = []
     for k, ln in enumerate(lines):

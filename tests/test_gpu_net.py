@@ -296,8 +296,11 @@ def test_packed_planes_give_identical_outputs(name, fp16, tmp_weights_dir):
         tol = fp16_tol if fp16 else (lambda e: FP32_ATOL)
         for i, bs in enumerate(bsz):
             if bs == B:
-                assert np.array_equal(q_fp32[i], q_pack[i]), i
-                assert np.array_equal(q_fp32[i], q_mix[i]), i
+                exp = oracle.forward(planes[i], bs)
+                what = lambda: (i, [float(np.abs(q[i] - exp).max()) for q in (q_fp32, q_pack, q_mix)], float(np.abs(q_fp32[i] - q_pack[i]).max()),
+                                float(np.abs(q_fp32[i] - q_mix[i]).max()), pipe.pump_times())
+                assert np.array_equal(q_fp32[i], q_pack[i]), what()
+                assert np.array_equal(q_fp32[i], q_mix[i]), what()
             else:
                 exp = oracle.forward(planes[i], bs)
                 for q in (q_fp32, q_pack, q_mix):

@@ -92,10 +92,12 @@ def test_no_spill_inside_the_mfma_streams(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="needs the ROCm llvm tools")
 def test_persistent_tower_code_object():
-    """The persistent tower launch (conv_tower.h) is hipcc's single-layer kernels with the layer loop closed in assembly
-    (tower_seam.py).  The code object that ships inside libsayuri_hip.so must (i) be the one the build produced,
-    (ii) carry the entry stub, the dispatch and one seam per body, (iii) keep every compiled body free of scratch traffic
-    inside its MFMA stream, start the plain body where the build places it, and (iv) declare the resources of both bodies in the launch kernel's descriptor."""
+    """The persistent tower launch (conv_tower.h) is hipcc's single-layer convolution kernel with the layer loop closed in
+    assembly and the SE unit put in as generated assembly around a compiled FC body (tower_seam.py).  The code object that
+    ships inside libsayuri_hip.so must (i) be the one the build produced, (ii) carry the entry stub, the dispatch, the SE hook
+    (pooling -> FC body -> gate, all behind the K loop and in front of the epilogue) and one seam, (iii) use NO scratch at all --
+    the SE unit of rounds 2-3 parked six accumulator tiles there -- and no AGPR inside the FC body, (iv) start the convolution
+    body where the build places it, and (v) declare 160 KiB of static LDS and no private segment in the launch descriptor."""
     so = _build.HIP_SO
     if not os.path.exists(so):
         _build.build_hip()
@@ -104,39 +106,59 @@ def test_persistent_tower_code_object():
     blob = open(hsaco, "rb").read()
     assert blob in open(so, "rb").read(), "libsayuri_hip.so does not embed lib/obj/tower.hsaco"
     asm = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", hsaco], capture_output=True, text=True, check=True).stdout
-    sections, address = {}, {}
+    order, sections, address = [], {}, {}
     name = None
     for line in asm.splitlines():
         m = re.match(r"^([0-9a-f]+) <(.+)>:$", line)
         if m:
             name = m.group(2)
+            order.append(name)
             sections[name] = []
             address[name] = int(m.group(1), 16)
         elif name and line.strip():
-            sections[name].append(line.strip())
+            sections[name].append(line.split("//")[0].strip())
+    assert not [i for body in sections.values() for i in body if i.startswith("scratch_")], "scratch access in the tower code object"
     for w in (4, 2):
-        entry = f"_ZN6sayuri17conv_tower_kernelILi{w}ELb0EEEvPKNS_10TowerLayerE"
+        entry = f"_ZN6sayuri17conv_tower_kernelILi{w}EEEvPKNS_10TowerLayerE"
         assert entry in sections and f"tower{w}_dispatch" in sections, "entry stub / dispatch missing"
         stub = sections[entry]
         assert stub[0].startswith("s_load_dwordx2") and "s[0:1]" in stub[0], stub[0]
         disp = sections[f"tower{w}_dispatch"]
         assert any(i.startswith("s_mov_b64 exec, -1") for i in disp) and any(i.startswith("v_mbcnt_hi") for i in disp)
-        assert any(i.startswith("s_setpc_b64") for i in disp), "far jump to the SE body"
+        assert disp[0].startswith("s_load_dword ") and disp[0].endswith("0xc"), "the dispatch parks has_se: " + disp[0]
         # placement (tower_seam.py --align=8 --pad=N, N = 32 unless the build was told otherwise): measured, DESIGN.md Kernel 1c
-        assert address[f"tower{w}_body_plain"] % 256 == int(os.environ.get("SAYURI_TOWER_PAD", "32")), hex(address[f"tower{w}_body_plain"])
-        assert address[f"tower{w}_body_se"] % 256 == int(os.environ.get("SAYURI_TOWER_PAD_SE", "32")), hex(address[f"tower{w}_body_se"])
-        for body in (f"tower{w}_body_plain", f"tower{w}_body_se"):
-            ins = sections[body]
-            mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
-            assert len(mf) > 100, f"{body}: no MFMA stream"
-            inside = [x for x in ins[mf[0]:mf[-1] + 1] if x.startswith("scratch_")]
-            assert not inside, f"{body}: {len(inside)} scratch accesses inside the MFMA stream, e.g. {inside[:3]}"
-            # the seam: every exit of the body goes through  vmcnt(0) -> s_barrier -> (end | next element)
-            ends = [i for i, x in enumerate(ins) if x.startswith("s_endpgm")]
-            assert len(ends) == 1, f"{body}: {len(ends)} s_endpgm (the seam owns the only one)"
-            tail = ins[ends[0] - 16:ends[0]]
-            assert any(x.startswith("s_waitcnt vmcnt(0)") for x in tail) and any(x.startswith("s_barrier") for x in tail), tail
-            assert any(x.startswith("s_setpc_b64") for x in tail), "far jump back to the dispatch"
+        assert address[f"tower{w}_body_conv"] % 256 == int(os.environ.get("SAYURI_TOWER_PAD", "32")), hex(address[f"tower{w}_body_conv"])
+        # the convolution body up to the FC's return label: K loop, then the hook's pooling (accumulators read in place:
+        # v_accvgpr_read, DPP row reductions, the partials written to LDS), then the far jump into the FC body
+        head = sections[f"tower{w}_body_conv"]
+        mf = [i for i, x in enumerate(head) if x.startswith("v_mfma")]
+        assert len(mf) > 100, "no MFMA stream in the convolution body"
+        nop = next(i for i in range(mf[-1], len(head)) if head[i].startswith("s_nop 15"))
+        after = head[nop:]  # the K loop's exit: two s_nop 15 (the last MFMAs retire), then the hook
+        assert after[1].startswith("s_nop 15") and after[2].startswith("s_cmp_eq_u32") and after[3].startswith("s_cbranch_scc1"), after[:4]
+        assert any("row_ror:8" in x for x in after) and any(x.startswith("ds_write_b128") for x in after), "pooling missing behind the K loop"
+        assert after[-1].startswith("s_setpc_b64"), "far jump into the FC body: " + after[-1]
+        assert not [x for x in after if x.startswith("v_mfma")]
+        # behind the return label: the gate in place (fused multiply-adds between accvgpr reads and writes), then the compiled
+        # epilogue and the seam: every exit goes through  vmcnt(0) -> s_barrier -> (end | next element)
+        tail = sections[f"tower{w}_se_return"]
+        first_store = next(i for i, x in enumerate(tail) if x.startswith("global_store"))
+        gate = tail[:first_store]
+        assert sum(x.startswith("v_pk_fma_f32") for x in gate) >= 2 * w * 12, "the gate's fused multiply-adds"
+        assert sum(x.startswith("v_accvgpr_write") for x in gate) >= 4 * min(32, w * 12), "gated tiles go back to their AGPRs"
+        ends = [i for i, x in enumerate(tail) if x.startswith("s_endpgm")]
+        assert len(ends) == 1, f"{len(ends)} s_endpgm in the convolution body (the seam owns the only one)"
+        last = tail[ends[0] - 16:ends[0]]
+        assert any(x.startswith("s_waitcnt vmcnt(0)") for x in last) and any(x.startswith("s_barrier") for x in last), last
+        assert any(x.startswith("s_setpc_b64") for x in last), "far jump back to the dispatch"
+        # the FC body: no AGPR, no MFMA, VGPRs only from the hook's range, leaves through far jumps (no s_endpgm)
+        fc = sections[f"tower{w}_body_fc"]
+        assert len(fc) > 200 and not [x for x in fc if x.startswith("s_endpgm") or "v_accvgpr" in x or x.startswith("v_mfma")]
+        regs = [int(n) for x in fc for n in re.findall(r"\bv(\d+)\b", x)] + [int(n) for x in fc for pair in re.findall(r"\bv\[(\d+):(\d+)\]", x) for n in pair]
+        assert regs and min(regs) >= 66 and max(regs) <= 127, (min(regs), max(regs))
+        assert sum(x.startswith("s_setpc_b64") for x in fc) >= 1
     notes = subprocess.run([READELF, "--notes", hsaco], capture_output=True, text=True, check=True).stdout
-    blocks = [b for b in notes.split(".agpr_count") if "conv_tower_kernelILi4ELb0" in b]
+    blocks = [b for b in notes.split(".agpr_count") if "conv_tower_kernelILi4EEE" in b]
     assert blocks and re.search(r"\.group_segment_fixed_size:\s+163840", blocks[0]), "launch kernel: static 160 KiB of LDS"
+    assert re.search(r"\.private_segment_fixed_size:\s+0\b", blocks[0]), "launch kernel: no scratch"
+    assert re.search(r"\.vgpr_spill_count:\s+0\b", blocks[0]) and re.search(r"\.sgpr_spill_count:\s+0\b", blocks[0])

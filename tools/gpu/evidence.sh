@@ -26,7 +26,7 @@ U=gpurun_out/r03_mfma_rate_ubench.txt
 cat $U
 
 echo "=== SE timeline"
-SAYURI_BOARD_DBG=-3 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --selfplay-seconds 0 --profile > gpurun_out/se_tl.json 2> gpurun_out/se_tl.err
+SAYURI_BOARD_DBG=-3 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config5 --selfplay-seconds 0 --profile > gpurun_out/se_tl.json 2> gpurun_out/se_tl.err
 grep "timeline wg[12]" gpurun_out/se_tl.err | head -20
 grep -A12 "kernel class" gpurun_out/se_tl.err | head -30
 python -c "import json;d=json.load(open('gpurun_out/se_tl.json'));print('evals/s', d['value'], d['roofline'])"
@@ -35,7 +35,7 @@ echo "=== traffic"
 i=0
 for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_WRITE_sum TCC_WRITE_SECTORS_sum" "TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum" "TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_WRITE_DRAM_sum" "TCC_WRITEBACK_sum TCC_NORMAL_WRITEBACK_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_WRITE_sum"; do
   i=$((i+1))
-  (cd /tmp && timeout 150 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/traffic/p$i -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --selfplay-seconds 0 --no-pump > $GRAFT_REPO_ROOT/gpurun_out/traffic/p$i.out 2> $GRAFT_REPO_ROOT/gpurun_out/traffic/p$i.err)
+  (cd /tmp && timeout 150 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/traffic/p$i -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config5 --selfplay-seconds 0 --no-pump > $GRAFT_REPO_ROOT/gpurun_out/traffic/p$i.out 2> $GRAFT_REPO_ROOT/gpurun_out/traffic/p$i.err)
   echo "## set $i [$set] rc=$?"
   grep -E "Memory access fault|Segmentation|rror" gpurun_out/traffic/p$i.err | head -2
   python tools/pmc_summary.py gpurun_out/traffic/p$i "conv_board_kernel<4" 2>&1 | tail -n +2

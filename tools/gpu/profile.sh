@@ -6,12 +6,12 @@ TAG=${TAG:-r03}
 O=gpurun_out/$TAG
 mkdir -p $O/prof
 export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --selfplay-seconds 0 --no-pump"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-config5 --selfplay-seconds 0 --no-pump"
 if [ -z "$SKIP_TESTS" ]; then
   timeout 2400 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
 fi
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof/kt -o p --output-format csv -- $B --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$O/prof/kt.out 2> $GRAFT_REPO_ROOT/$O/prof/kt.err); echo "kernel-trace rc=$?"
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --selfplay-seconds 0 --no-pump --steps 20 --warmup 5   ($(date -u +%FT%TZ))"
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-config5 --selfplay-seconds 0 --no-pump --steps 20 --warmup 5   ($(date -u +%FT%TZ))"
   echo "# bench line of the same command:"; tail -1 $O/prof/kt.out | sed 's/^/# /' | cut -c1-1500
   find $O/prof/kt -name "*kernel_stats.csv" | head -1 | xargs cat; } > $O/rocprofv3_kernel_stats.txt
 head -8 $O/rocprofv3_kernel_stats.txt | cut -c1-220
@@ -36,7 +36,7 @@ done > $O/pmc_raw.txt 2>&1
 cat $O/pmc_raw.txt
 timeout 900 python bench.py --no-cpu-baseline --selfplay-seconds 0 --config5 > $O/config5.json 2> $O/config5.err; echo "config5 rc=$?"
 python -c "import json;d=json.load(open('$O/config5.json'));print(d['value'], d['roofline']['frac'], d['config5'])"
-timeout 300 python bench.py --fp32 --steps 5 --warmup 1 --no-cpu-baseline --selfplay-seconds 0 > $O/bench_fp32.json 2> $O/bench_fp32.err; echo "fp32 rc=$?"
+timeout 300 python bench.py --fp32 --steps 5 --warmup 1 --no-cpu-baseline --no-config5 --selfplay-seconds 0 > $O/bench_fp32.json 2> $O/bench_fp32.err; echo "fp32 rc=$?"
 python -c "import json;d=json.load(open('$O/bench_fp32.json'));print(d['value'], d['roofline'])"
 rm -rf $O/prof/*/p_kernel_trace.csv $O/prof/*/p_agent_info.csv
 # the default line, as the driver runs it (cpu_baseline and the self-play window included)

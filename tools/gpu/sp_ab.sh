@@ -20,7 +20,7 @@ PY
   grep -h "fwdstat\|closed:" gpurun_out/spab/$name.err
 }
 # the microbench of this box first (resident inputs)
-python bench.py --steps 20 --warmup 5 --selfplay-seconds 0 --no-cpu-baseline 2>/dev/null | python -c "
+python bench.py --steps 20 --warmup 5 --selfplay-seconds 0 --no-cpu-baseline --no-config5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('microbench', d['value'], d['ms_per_step'], d['config'].get('pump_packed',{}).get('nn_evals_per_sec'))" 
 for round in 1 2; do

@@ -19,10 +19,10 @@ except Exception as e:
 PY
   grep -h "fwdstat\|closed:" gpurun_out/spab2/$name.err
 }
-python bench.py --steps 20 --warmup 5 --selfplay-seconds 0 --no-cpu-baseline 2>/dev/null | python -c "
+python bench.py --steps 20 --warmup 5 --selfplay-seconds 0 --no-cpu-baseline --no-config5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('microbench', d['value'], d['ms_per_step'], 'pump', d['config'].get('pump',{}).get('nn_evals_per_sec'), 'pump_packed', d['config'].get('pump_packed',{}).get('nn_evals_per_sec'))"
-SAYURI_IO_V2=0 python bench.py --steps 20 --warmup 5 --selfplay-seconds 0 --no-cpu-baseline 2>/dev/null | python -c "
+SAYURI_IO_V2=0 python bench.py --steps 20 --warmup 5 --selfplay-seconds 0 --no-cpu-baseline --no-config5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('microbench io_v2=0', d['value'], d['ms_per_step'], 'pump', d['config'].get('pump',{}).get('nn_evals_per_sec'), 'pump_packed', d['config'].get('pump_packed',{}).get('nn_evals_per_sec'))"
 run v2_1 A=1
