@@ -336,6 +336,227 @@ def se_hook(w, hook, acc, B, fc_label):
     return o
 
 
+def epi_hook(w, hook, acc, B):
+    """The epilogue of width-w's convolution body as assembly text, for the layers it covers (Mish, one sample per tile with
+    computed table entries, the layer's channels = the channel tile): optional residual, activation, fp16 NHWC store, straight
+    from the accumulators where the K loop left them -- the arithmetic of board_epilogue / mish2 (conv_board.h) operation for
+    operation, so the outputs equal the compiled epilogue's bit for bit.  What it saves is what hipcc adds: per 16-byte store
+    ~14 register moves staging the swap operands and a conversion + half a packed add per residual value (here one
+    v_fma_mix_f32), in front of everything ~200 accumulator moves -- the epilogue is bound by VALU issue (tools/ubench/trans_rate.hip:
+    a plain operation 4 cycles of a SIMD, a packed one 5, a transcendental 10.7, v_permlane16_swap 14).  Other layers fall through
+    to the compiled epilogue behind this text."""
+    wmt, kot = hook["wmt"], hook["kot"]
+    if wmt % 2:
+        return []
+    npair = wmt // 2
+    pieces = NJ * npair
+    nd = max(pieces - 20, 0)            # residual pieces that go to registers instead of the wave's 20 KiB of LDS
+    if nd % npair:
+        die("epilogue: register pieces are not whole column tiles")
+    JH, NRT = NJ // 2, nd // npair      # register tiles: [JH, JH + NRT)
+    E, T = hook["elem"], hook["tid"]
+    WG, WAVE = f"s{B + 2}", f"s{B + 3}"
+    L = f".Ltower{w}_ep"
+    R = Regs()
+    o = []
+    a = o.append
+    s_res, s_out, s_l2e, s_valid, s_save = R.s(2), R.s(2), R.s(2), R.s(2), R.s(2)
+    (s_arith, s_act, s_couts, s_slotpix, s_ui, s_ncols, s_bs, s_nj0, s_wave_n, s_wave_m, s_col0, s_nj, s_npix, s_t0, s_t1, s_late,
+     s_step, s_mylds) = (R.s() for _ in range(18))
+    v_lane, v_R, v_px, v_cb, v_off, v_pxl, v_t, v_lds, v_a, v_r, v_so = (R.v() for _ in range(11))
+    rreg = [R.v(4, 4) for _ in range(nd)]
+    X, Y, RR = R.v(4, 4), R.v(4, 4), R.v(4, 4)
+    Tm, U = R.v(8, 2), R.v(8, 4)
+    Hs = [U, U + 4]   # the fp16 result of a pair lives where the pair's temporaries lived (alternating halves: a store's data is
+                      # rewritten two pairs later at the earliest)
+
+    def lds_slot(j, pr):
+        return (j if j < JH else j - NRT) * npair + pr
+
+    a(f"\t; ---- tower_seam.py: the epilogue (width {w}) for Mish layers with computed table entries; others take the compiled one below")
+    a(f"\ts_load_dword {sr(s_arith)}, {E}, {hex(hook['arith'])}")
+    a(f"\ts_load_dword {sr(s_act)}, {E}, {hex(hook['act'])}")
+    a(f"\ts_load_dword {sr(s_couts)}, {E}, {hex(hook['couts'])}")
+    a(f"\ts_load_dword {sr(s_slotpix)}, {E}, {hex(hook['slotpix'])}")
+    a(f"\ts_load_dword {sr(s_ui)}, {E}, {hex(hook['ui'])}")
+    a(f"\ts_load_dwordx2 {sr(s_res, 2)}, {E}, {hex(hook['res'])}")
+    a(f"\ts_load_dwordx2 {sr(s_out, 2)}, {E}, {hex(hook['out'])}")
+    a("\ts_waitcnt lgkmcnt(0)")
+    for cmp_, br in ((f"s_cmp_eq_u32 {sr(s_arith)}, 0", "scc1"), (f"s_cmp_lg_u32 {sr(s_act)}, {hook['mish']}", "scc1"),
+                     (f"s_cmp_lt_i32 {sr(s_ui)}, 0", "scc1"), (f"s_cmp_lg_u32 {sr(s_couts)}, {kot}", "scc1")):
+        a("\t" + cmp_)
+        a(f"\ts_cbranch_{br} {L}_compiled")
+    # ---- geometry of this wave and lane (board_epilogue's first lines)
+    a(f"\tv_and_b32_e32 {vr(v_lane)}, 63, {T}")
+    a(f"\tv_lshrrev_b32_e32 {vr(v_R)}, 4, {vr(v_lane)}")
+    a(f"\tv_and_b32_e32 {vr(v_px)}, 15, {vr(v_lane)}")
+    a(f"\ts_and_b32 {sr(s_ncols)}, {sr(s_ui)}, 0xff")
+    a(f"\ts_lshr_b32 {sr(s_bs)}, {sr(s_ui)}, 8")
+    a(f"\ts_add_u32 {sr(s_nj0)}, {sr(s_ncols)}, 1")
+    a(f"\ts_lshr_b32 {sr(s_nj0)}, {sr(s_nj0)}, 1")
+    a(f"\ts_lshr_b32 {sr(s_wave_n)}, {WAVE}, 2")
+    a(f"\ts_and_b32 {sr(s_wave_m)}, {WAVE}, 3")
+    a(f"\ts_sub_u32 {sr(s_t0)}, {sr(s_ncols)}, {sr(s_nj0)}")
+    a(f"\ts_cmp_eq_u32 {sr(s_wave_n)}, 0")
+    a(f"\ts_cselect_b32 {sr(s_col0)}, 0, {sr(s_nj0)}")
+    a(f"\ts_cselect_b32 {sr(s_nj)}, {sr(s_nj0)}, {sr(s_t0)}")
+    a(f"\ts_mul_i32 {sr(s_npix)}, {sr(s_bs)}, {sr(s_bs)}")
+    # after the swap of pair pr a lane holds row tile 2 pr + (R & 1), channels (R >> 1) * 8 .. + 7 of it:
+    # cb(pr) = wave_m * WMT * 16 + (2 pr + (R & 1)) * 16 + (R >> 1) * 8, i.e. cb(0) + 32 pr
+    a(f"\tv_and_b32_e32 {vr(v_t)}, 1, {vr(v_R)}")
+    a(f"\tv_lshlrev_b32_e32 {vr(v_t)}, 4, {vr(v_t)}")
+    a(f"\tv_lshrrev_b32_e32 {vr(v_cb)}, 1, {vr(v_R)}")
+    a(f"\tv_lshl_add_u32 {vr(v_cb)}, {vr(v_cb)}, 3, {vr(v_t)}")
+    a(f"\ts_mul_i32 {sr(s_t0)}, {sr(s_wave_m)}, {wmt * 16}")
+    a(f"\tv_add_u32_e32 {vr(v_cb)}, {sr(s_t0)}, {vr(v_cb)}")
+    # byte offset of (this lane's pixel of column tile 0, cb(0)) in the output / residual buffers; column tile j adds j * step
+    a(f"\ts_lshl_b32 {sr(s_t1)}, {sr(s_col0)}, 4")
+    a(f"\tv_add_u32_e32 {vr(v_pxl)}, {sr(s_t1)}, {vr(v_px)}")
+    a(f"\ts_mul_i32 {sr(s_t0)}, {WG}, {sr(s_slotpix)}")
+    a(f"\tv_add_u32_e32 {vr(v_off)}, {sr(s_t0)}, {vr(v_pxl)}")
+    a(f"\tv_mul_lo_u32 {vr(v_off)}, {vr(v_off)}, {sr(s_couts)}")
+    a(f"\tv_add_u32_e32 {vr(v_off)}, {vr(v_off)}, {vr(v_cb)}")
+    a(f"\tv_lshlrev_b32_e32 {vr(v_off)}, 1, {vr(v_off)}")
+    a(f"\ts_lshl_b32 {sr(s_step)}, {sr(s_couts)}, 5")
+    a(f"\ts_mul_i32 {sr(s_mylds)}, {WAVE}, {20 * 1024}")
+    a(f"\tv_lshlrev_b32_e32 {vr(v_lds)}, 4, {vr(v_lane)}")
+    a(f"\tv_add_u32_e32 {vr(v_lds)}, {sr(s_mylds)}, {vr(v_lds)}")
+    a(f"\ts_mov_b32 {sr(s_l2e)}, 0x3fb8aa3b")
+    a(f"\ts_mov_b32 {sr(s_l2e + 1)}, 0x3fb8aa3b")
+    a(f"\ts_cmp_eq_u64 {sr(s_res, 2)}, 0")
+    a(f"\ts_cbranch_scc1 {L}_tiles_nores")
+    # ---- residual: ALL rows of the wave requested at once (LDS-DMA into the dead rings, the few that do not fit into
+    # registers); issue order = first half, second half, register pieces: board_epilogue explains the two-step wait
+    a("\ts_waitcnt lgkmcnt(0)")
+    a("\ts_barrier")                     # every wave is done with the rings
+
+    def offsets_of(j, want_pr):
+        """v_a <- byte offset of (column tile j, pair 0), vcc <- lanes whose pixel exists; yields the piece offsets in v_r"""
+        a(f"\tv_add_u32_e32 {vr(v_t)}, {16 * j}, {vr(v_pxl)}")
+        a(f"\tv_cmp_gt_u32_e32 vcc, {sr(s_npix)}, {vr(v_t)}")
+        a(f"\ts_mul_i32 {sr(s_t0)}, {sr(s_step)}, {j}")
+        a(f"\tv_add_u32_e32 {vr(v_a)}, {sr(s_t0)}, {vr(v_off)}")
+
+    lds_tiles = [j for j in range(NJ) if j < JH or j >= JH + NRT]
+    for j in lds_tiles:
+        a(f"\ts_cmp_le_u32 {sr(s_nj)}, {j}")
+        a(f"\ts_cbranch_scc1 {L}_lds_issued")
+        offsets_of(j, None)
+        for pr in range(npair):
+            if pr:
+                a(f"\tv_add_u32_e32 {vr(v_a)}, 64, {vr(v_a)}")
+            a(f"\tv_cndmask_b32_e32 {vr(v_r)}, 0, {vr(v_a)}, vcc")
+            a(f"\ts_add_u32 {sr(s_t1)}, {sr(s_mylds)}, {lds_slot(j, pr) * 1024}")
+            a(f"\ts_mov_b32 m0, {sr(s_t1)}")
+            a("\ts_nop 1")
+            a(f"\tglobal_load_lds_dwordx4 {vr(v_r)}, {sr(s_res, 2)}")
+    a(f"{L}_lds_issued:")
+    for k in range(nd):
+        j, pr = JH + k // npair, k % npair
+        if pr == 0:
+            a(f"\ts_cmp_le_u32 {sr(s_nj)}, {j}")
+            a(f"\ts_cbranch_scc1 {L}_reg_issued")
+            offsets_of(j, None)
+        else:
+            a(f"\tv_add_u32_e32 {vr(v_a)}, 64, {vr(v_a)}")
+        a(f"\tv_cndmask_b32_e32 {vr(v_r)}, 0, {vr(v_a)}, vcc")
+        a(f"\tglobal_load_dwordx4 {vr(rreg[k], 4)}, {vr(v_r)}, {sr(s_res, 2)}")
+    a(f"{L}_reg_issued:")
+    # loads younger than the first half = the pieces of the column tiles [JH, nj)
+    a(f"\ts_sub_i32 {sr(s_late)}, {sr(s_nj)}, {JH}")
+    a(f"\ts_max_i32 {sr(s_late)}, {sr(s_late)}, 0")
+    for t in range(NJ - JH + 1):
+        a(f"\ts_cmp_eq_u32 {sr(s_late)}, {t}")
+        a(f"\ts_cbranch_scc1 {L}_late{t}")
+    a(f"\ts_branch {L}_late0")
+    for t in range(NJ - JH, -1, -1):
+        a(f"{L}_late{t}:")
+        a(f"\ts_waitcnt vmcnt({t * npair})")
+        if t:
+            a(f"\ts_branch {L}_tiles")
+    a(f"{L}_tiles:")
+
+    def mish8(x_pairs, h):
+        """x_pairs: four even-aligned VGPR pairs holding 8 values; h <- their Mish as 8 fp16 (4 VGPRs)"""
+        t = [Tm + 2 * k for k in range(4)]
+        u = [U + 2 * k for k in range(4)]
+        for k in range(4):
+            a(f"\tv_pk_mul_f32 {vr(t[k], 2)}, {vr(x_pairs[k], 2)}, {sr(s_l2e, 2)}")
+        for k in range(8):
+            a(f"\tv_exp_f32_e32 {vr(Tm + k)}, {vr(Tm + k)}")
+        for k in range(4):
+            a(f"\tv_pk_add_f32 {vr(u[k], 2)}, {vr(t[k], 2)}, 2.0 op_sel_hi:[1,0]")
+        for k in range(4):
+            a(f"\tv_pk_fma_f32 {vr(t[k], 2)}, {vr(t[k], 2)}, {vr(u[k], 2)}, 2.0 op_sel_hi:[1,1,0]")
+        for k in range(8):
+            a(f"\tv_rcp_f32_e32 {vr(Tm + k)}, {vr(Tm + k)}")
+        for k in range(4):
+            a(f"\tv_pk_fma_f32 {vr(t[k], 2)}, {vr(t[k], 2)}, -2.0, 1.0 op_sel_hi:[1,0,0]")
+        for k in range(4):
+            a(f"\tv_pk_mul_f32 {vr(x_pairs[k], 2)}, {vr(x_pairs[k], 2)}, {vr(t[k], 2)}")
+        for k in range(4):
+            a(f"\tv_cvt_pk_f16_f32 {vr(h + k)}, {vr(x_pairs[k])}, {vr(x_pairs[k] + 1)}")
+
+    def tiles(with_res):
+        tag = "r" if with_res else "n"
+        nstore = 0
+        for j in range(NJ):
+            a(f"\ts_cmp_le_u32 {sr(s_nj)}, {j}")
+            a(f"\ts_cbranch_scc1 {L}_done")
+            if j == JH and with_res:
+                a("\ts_waitcnt vmcnt(0)")         # the second half's rows (and the first half's stores)
+            a(f"\tv_add_u32_e32 {vr(v_t)}, {16 * j}, {vr(v_pxl)}")
+            a(f"\tv_cmp_gt_u32_e64 {sr(s_valid, 2)}, {sr(s_npix)}, {vr(v_t)}")
+            a(f"\ts_mul_i32 {sr(s_t0)}, {sr(s_step)}, {j}")
+            a(f"\tv_add_u32_e32 {vr(v_so)}, {sr(s_t0)}, {vr(v_off)}")
+            for pr in range(npair):
+                ta, tb = acc[(2 * pr, j)], acc[(2 * pr + 1, j)]
+                in_lds = not (JH <= j < JH + NRT)
+                rr = RR
+                if with_res and in_lds:
+                    # the piece comes back from LDS (lane-linear: the lane that reads it is the lane that fetched it)
+                    a(f"\tds_read_b128 {vr(RR, 4)}, {vr(v_lds)} offset:{lds_slot(j, pr) * 1024}")
+                elif with_res:
+                    rr = rreg[(j - JH) * npair + pr]
+                xs = []
+                for (kind, lo), tmp in ((ta, X), (tb, Y)):
+                    if kind == "a":
+                        for r in range(4):
+                            a(f"\tv_accvgpr_read_b32 {vr(tmp + r)}, a{lo + r}")
+                        xs.append(tmp)
+                    else:
+                        if lo % 2:
+                            die("epilogue: an accumulator tile in VGPRs is not even-aligned")
+                        xs.append(lo)
+                xa, xb = xs
+                a("\ts_nop 1")                    # a VALU result read by v_permlane16_swap: two wait states
+                for r in range(4):
+                    a(f"\tv_permlane16_swap_b32 {vr(xa + r)}, {vr(xb + r)}")
+                if with_res:
+                    # + residual: one fused multiply-add per value reads the fp16 half directly (v + (float)rr * 1.0: the same
+                    # single rounding as conversion + add)
+                    if in_lds:
+                        a("\ts_waitcnt lgkmcnt(0)")
+                    vals = [xa, xa + 1, xa + 2, xa + 3, xb, xb + 1, xb + 2, xb + 3]
+                    for q in range(8):
+                        a(f"\tv_fma_mix_f32 {vr(vals[q])}, {vr(rr + q // 2)}, 1.0, {vr(vals[q])} op_sel:[{q & 1},0,0] op_sel_hi:[1,0,0]")
+                h = Hs[nstore & 1]
+                nstore += 1
+                mish8([xa, xa + 2, xb, xb + 2], h)
+                a(f"\ts_and_saveexec_b64 {sr(s_save, 2)}, {sr(s_valid, 2)}")
+                a(f"\tglobal_store_dwordx4 {vr(v_so)}, {vr(h, 4)}, {sr(s_out, 2)}" + (f" offset:{64 * pr}" if pr else ""))
+                a(f"\ts_mov_b64 exec, {sr(s_save, 2)}")
+        a(f"\ts_branch {L}_done")
+
+    tiles(True)
+    a(f"{L}_tiles_nores:")
+    tiles(False)
+    a(f"{L}_done:")
+    o.extend(far_jump(f"tower{w}_seam"))
+    a(f"{L}_compiled:")
+    return o
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     inv = "--inv" in sys.argv
@@ -436,7 +657,8 @@ def main():
         for tok in lines[hk].split("TOWER_SE_HOOK", 1)[1].split():
             key, _, val = tok.partition("=")
             hook[key] = val if key in ("elem", "tid") else int(val, 0)
-        for key in ("elem", "tid", "wmt", "ui", "cols", "w1h", "w2h", "w1b", "w2b", "psum", "pmax", "gate", "kot"):
+        for key in ("elem", "tid", "wmt", "ui", "cols", "w1h", "w2h", "w1b", "w2b", "psum", "pmax", "gate", "kot", "res", "out", "couts",
+                    "slotpix", "act", "arith", "mish"):
             if key not in hook:
                 die(f"{conv['name']}: the hook statement names no `{key}`")
         if hook["wmt"] != w:
@@ -484,7 +706,7 @@ def main():
             B = FREE_SGPRS + 2
         tab, wg, wv, hs = f"s[{B}:{B + 1}]", f"s{B + 2}", f"s{B + 3}", f"s{B + 4}"
         disp, body_conv = f"tower{w}_dispatch", f"tower{w}_body_conv"
-        edits[hk] = se_hook(w, hook, acc, B, fc_label)
+        edits[hk] = se_hook(w, hook, acc, B, fc_label) + epi_hook(w, hook, acc, B)
 
         entry = [f"\t; ---- tower_seam.py: entry stub (table {tab}, workgroup {wg}, wave {wv}, has_se {hs})",
                  f"\ts_load_dwordx2 {tab}, s[0:1], 0x0",
@@ -515,6 +737,7 @@ def main():
         for k in ends:
             edits[k] = [f"\ts_branch {seam}"]
         tail = [f"{seam}:",
+                f"tower{w}_seam:",
                 "\ts_waitcnt vmcnt(0) lgkmcnt(0)",
                 f"\ts_load_dword s4, {tab}, {hex(LAST_OFFSET)}",
                 "\ts_waitcnt lgkmcnt(0)",

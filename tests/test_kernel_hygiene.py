@@ -146,9 +146,16 @@ def test_persistent_tower_code_object():
         gate = tail[:first_store]
         assert sum(x.startswith("v_pk_fma_f32") for x in gate) >= 2 * w * 12, "the gate's fused multiply-adds"
         assert sum(x.startswith("v_accvgpr_write") for x in gate) >= 4 * min(32, w * 12), "gated tiles go back to their AGPRs"
-        ends = [i for i, x in enumerate(tail) if x.startswith("s_endpgm")]
-        assert len(ends) == 1, f"{len(ends)} s_endpgm in the convolution body (the seam owns the only one)"
-        last = tail[ends[0] - 16:ends[0]]
+        # ... then the generated epilogue for Mish layers with computed table entries (one v_fma_mix_f32 per residual value, the
+        # Mish of mish2 operation for operation, 16-byte stores) which leaves by a far jump to the seam, then the compiled epilogue
+        gen = tail[first_store - 200:]
+        assert any(x.startswith("v_fma_mix_f32") for x in tail) and any(x.startswith("v_permlane16_swap_b32") for x in gen)
+        assert sum(x.startswith("s_setpc_b64") for x in tail) >= 1, "the generated epilogue jumps to the seam"
+        # the seam: every exit goes through  vmcnt(0) -> s_barrier -> (end | next element)
+        seam = sections[f"tower{w}_seam"]
+        ends = [i for i, x in enumerate(seam) if x.startswith("s_endpgm")]
+        assert len(ends) == 1 and not [x for x in tail + head if x.startswith("s_endpgm")], "the seam owns the only s_endpgm"
+        last = seam[:ends[0]]
         assert any(x.startswith("s_waitcnt vmcnt(0)") for x in last) and any(x.startswith("s_barrier") for x in last), last
         assert any(x.startswith("s_setpc_b64") for x in last), "far jump back to the dispatch"
         # the FC body: no AGPR, no MFMA, VGPRs only from the hook's range, leaves through far jumps (no s_endpgm)
