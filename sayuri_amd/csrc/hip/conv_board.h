@@ -34,6 +34,18 @@ constexpr int kBoardMaxPos = 512;           // halo positions per tile (DMA bloc
 constexpr int kBoardMaxSub = 32;            // samples per tile
 constexpr int kBoardNJ = kBoardCols / 2;    // column tiles per wave
 
+// Row order of the weight image for the GENERATED epilogue of the persistent launch (tower_seam.py epi_hook).  A lane of the
+// 16x16 accumulator layout holds rows 4q .. 4q+3 (q = lane >> 4) of each 16-row tile; a 16-byte store wants 8 CONSECUTIVE
+// channels per lane.  The compiled epilogue pairs the quads of two row tiles with four v_permlane16_swap per store -- 14 SIMD
+// cycles each, a seventh of the epilogue's VALU time (tools/ubench/trans_rate.hip).  With the image's rows permuted inside every
+// group of 32 (= a pair of row tiles; a wave's rows start at a multiple of 32 for the even tile counts) -- row (tile t, m)
+// carries channel 8 (m >> 2) + 4 t + (m & 3) -- lane q of the pair holds channels 8q .. 8q+3 (tile 0) and 8q+4 .. 8q+7 (tile 1)
+// without any exchange.  The bias travels in the same order (the main loop indexes it by row).  BoardParams::row_order says
+// which image a layer was given; only the generated code reads it.
+__host__ __device__ constexpr int board_row_channel(int row) {
+    return (row & ~31) + 8 * ((row & 15) >> 2) + 4 * ((row >> 4) & 1) + (row & 3);
+}
+
 struct BoardParams {
     ConvParams c;          // num_pix_tiles = number of board tiles; in must carry the kZeroPrefix zero bytes in front
     const int* tab_src;    // [tile][npos]   activation row feeding each halo position, -1 = zero
@@ -50,6 +62,7 @@ struct BoardParams {
     // for this one, the prologue does not ask for group 0 again
     const void* w_next;
     int w_ready;
+    int row_order;  // persistent tower launch only: 1 = weights and bias are in board_row_channel order (the generated epilogue runs)
 };
 
 // Which samples share a tile: consecutive samples OF ONE BOARD SIZE, greedily, while pixels <= 384, halo positions

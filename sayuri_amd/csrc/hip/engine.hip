@@ -102,6 +102,17 @@ static void register_all_glds() {
     register_glds<8, 3>(); register_glds<8, 2>(); register_glds<8, 1>();
     register_glds<4, 3>(); register_glds<4, 2>(); register_glds<4, 1>();
 }
+// The weight image of the board kernels with an even tile count: the same planes with their rows in board_row_channel order
+// (conv_board.h: a lane then holds 8 consecutive channels of a row-tile pair without any exchange).
+template <typename T> static std::vector<T> board_row_order(const std::vector<T>& img, int ko_pad) {
+    std::vector<T> out(img.size());
+    const size_t planes = img.size() / ((size_t)ko_pad * 8);
+    for (size_t pl = 0; pl < planes; ++pl)
+        for (int r = 0; r < ko_pad; ++r)
+            std::copy_n(img.begin() + (pl * ko_pad + board_row_channel(r)) * 8, 8, out.begin() + (pl * ko_pad + r) * 8);
+    return out;
+}
+static bool board_uses_row_order(int kot) { return (kot / 64) % 2 == 0; }  // 256 / 128: yes; 192 (three row tiles per wave): natural order
 // one-workgroup-per-board kernels (conv_board.h), by output-channel tile
 typedef void (*BoardFn)(const BoardParams);
 typedef void (*BoardSeFn)(const BoardSeParams);
@@ -146,6 +157,7 @@ struct EngineFlags {
     bool io_v2 = true;                 // SAYURI_IO_V2=0: geometry / small outputs by copies again (A/B; see submit())
     bool io_zc = true, io_geom = true, io_prefix = true;  // its three parts, one at a time (SAYURI_IO_ZC / _GEOM / _PREFIX = 0)
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
+    bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
     int compute_streams = 1;
     int board_kot = 0;                 // experiments: only this channel tile
     int act_override = -1;             // experiments: activation of every board convolution
@@ -159,6 +171,7 @@ struct EngineFlags {
         }
         f.tower = !off("SAYURI_TOWER");
         f.tower_chain = !off("SAYURI_TOWER_CHAIN");
+        f.tower_gen_epi = !off("SAYURI_TOWER_GEN_EPI");
         f.io_v2 = !off("SAYURI_IO_V2");
         f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");
         f.io_geom = f.io_v2 && !off("SAYURI_IO_GEOM");
@@ -322,6 +335,8 @@ struct ConvLayerDev {
     std::vector<float> hw, hb;  // host tensors as handed over the ABI
     int cin_s = 0, cout_s = 0, wmt = 0, ko_pad = 0;
     void* w = nullptr;      // MFMA image, or [k*k][cs] fp32 for depthwise
+    void* w_board = nullptr;  // the same image in board_row_channel order (fp16 3x3 layers a board kernel may run) ...
+    float* bias_board = nullptr;  // ... and the bias in the same order: what a layer gets whose epilogue is the generated one
     float* bias = nullptr;  // [ko_pad] / [cs]
     float* w32 = nullptr;   // plain fp32 copy [cout][cin] for the tiny head convs
 };
@@ -1016,6 +1031,13 @@ private:
                 T* w = nullptr;
                 if (dev_upload(&w, img) || dev_upload(&L.bias, b)) return -1;
                 L.w = w;
+                if (sizeof(T) == 2 && L.k == 3 && L.ko_pad % 128 == 0) {
+                    T* wb = nullptr;
+                    std::vector<float> bb(L.ko_pad);
+                    for (int r = 0; r < L.ko_pad; ++r) bb[r] = b[board_row_channel(r)];
+                    if (dev_upload(&wb, board_row_order(img, L.ko_pad)) || dev_upload(&L.bias_board, bb)) return -1;
+                    L.w_board = wb;
+                }
             }
             std::vector<float>().swap(L.hw);
             std::vector<float>().swap(L.hb);
@@ -1271,6 +1293,14 @@ private:
         return pick_board(board_plan_, L.ko_pad, kot_tiles, flags_.board_kot);
     }
 
+    // Does this layer of the persistent launch get the generated epilogue (tower_seam.py epi_hook)?  Then its weights and bias go
+    // in board_row_channel order and BoardParams::row_order says so.  What the generated text covers: Mish, one sample per tile
+    // with computed table entries (arith), the layer's channels = the channel tile, an even number of row tiles per wave.
+    bool board_row_order_ok(const ConvLayerDev& L, const BoardEntry* be, const BoardParams& bp, int act) const {
+        return flags_.tower_gen_epi && tower_ok(be->kot) && !bp.dbg && board_uses_row_order(be->kot) && bp.arith && act == kMish &&
+               L.cout_s == be->kot && L.ko_pad == be->kot && L.w_board && L.bias_board;
+    }
+
     // A block's last 3x3 convolution with the squeeze-and-excitation unit that follows it inside the kernel
     // (conv_board.h).  Returns 1 when the fused kernel does not apply (the caller then runs conv + se_unit), 0 / -1.
     int conv_se(const ConvLayerDev& L, const FcLayerDev& sq, const FcLayerDev& ex, const T* in, T* out, const T* res, int C, int act) {
@@ -1312,6 +1342,7 @@ private:
         const double px = geom_.total;
         const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out);
         const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
+        if (board_row_order_ok(L, be, bp, act)) { p.w = L.w_board; p.bias = L.bias_board; bp.row_order = 1; }
         if (tower_ok(be->kot) && !bp.dbg) return tower_append(be->kot, sp, true, flops, bytes);
         const auto fn = be->fn_se;
         const size_t lds = be->lds(board_plan_.npos);
@@ -1353,6 +1384,7 @@ private:
             const double flops = 2.0 * px * L.cin * L.cout * 9;
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
             if (bkt == 1 && tower_ok(be->kot) && !bp.dbg) {
+                if (board_row_order_ok(L, be, bp, p.act)) { p.w = L.w_board; p.bias = L.bias_board; bp.row_order = 1; }
                 BoardSeParams sp;
                 std::memset(&sp, 0, sizeof(sp));
                 sp.b = bp;
@@ -2314,7 +2346,16 @@ static int test_conv_se_impl(int device, int n, const int* board_sizes, int max_
                 img[((((size_t)t * nch + c / 32) * 4 + (c % 32) / 8) * ko_pad + ko) * 8 + c % 8] = (T)w[((size_t)ko * C + c) * 9 + t];
     std::vector<float> hb(ko_pad, 0.f);
     if (bias) std::copy(bias, bias + C, hb.begin());
-    T* dw = A.upload(img);
+    // through the tower a Mish layer with computed table entries takes the generated epilogue: weights and bias in
+    // board_row_channel order (Engine::board_row_order_ok)
+    const bool row_order = via_tower && board_uses_row_order(be->kot) && act == kMish && plan.single && plan.uniform_info >= 0 && cs == be->kot &&
+                           !EngineFlags::off("SAYURI_TOWER_GEN_EPI");
+    if (row_order) {
+        std::vector<float> hbb(ko_pad);
+        for (int r = 0; r < ko_pad; ++r) hbb[r] = hb[board_row_channel(r)];
+        hb.swap(hbb);
+    }
+    T* dw = A.upload(row_order ? board_row_order(img, ko_pad) : img);
     float* db = A.upload(hb);
     float* dw1 = A.upload(fc_transposed(w1, 3 * C, se));
     float* dw2 = A.upload(fc_transposed(w2, se, 2 * C));
@@ -2334,6 +2375,7 @@ static int test_conv_se_impl(int device, int n, const int* board_sizes, int max_
     bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos;
     bp.uniform_info = plan.uniform_info;
     bp.arith = (plan.single && plan.uniform_info >= 0) ? 1 : 0;
+    bp.row_order = row_order ? 1 : 0;
     ConvParams& p = bp.c;
     p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = tg.g;
     p.cin_s = cs; p.cout_s = cs; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.num_pix_tiles = plan.ntiles;

@@ -114,6 +114,12 @@ class Regs:
         return r
 
 
+def quad_channel(i):
+    """conv_board.h board_quad_channel for even tile counts, lane quad 0: first channel (from the wave's first) of the four a lane
+    holds of row tile i; quad q adds 8 q"""
+    return (i >> 1) * 32 + 4 * (i & 1)
+
+
 def vr(lo, n=1):
     return f"v{lo}" if n == 1 else f"v[{lo}:{lo + n - 1}]"
 
@@ -127,6 +133,8 @@ def se_hook(w, hook, acc, B, fc_label):
     hook: the parsed operands of the TOWER_SE_HOOK statement; acc[(i, j)] = ('a' | 'v', first register) of output tile
     (row tile i, column tile j); B: first parked SGPR (table B:B+1, workgroup B+2, wave B+3, has_se B+4)."""
     wmt, kot = hook["wmt"], hook["kot"]
+    if wmt % 2:
+        die("the SE hook is written for even row-tile counts (board_row_channel order)")
     E, T = hook["elem"], hook["tid"]          # s[lo:lo+1] text, v text
     WG, WAVE, HAS_SE = f"s{B + 2}", f"s{B + 3}", f"s{B + 4}"
     L = f".Ltower{w}_se"
@@ -144,7 +152,8 @@ def se_hook(w, hook, acc, B, fc_label):
     s_t0, s_t1, s_k, s_n = (R.s() for _ in range(4))
     s_p = R.s(2)
     s_valid, s_px0, s_save = R.s(2), R.s(2), R.s(2)
-    v_lane, v_lane16, v_px, v_q, v_t, v_addr = (R.v() for _ in range(6))
+    v_lane, v_lane16, v_px, v_q, v_t, v_addr, v_addr2 = (R.v() for _ in range(7))
+    s_ro = R.s(keep=True)                     # BoardParams::row_order of the layer
     sets = [(R.v(4, 4), R.v(4, 4)) for _ in range(2)]     # (sums, maxima) of a row tile, alternating
     xs = [R.v(4, 4) for _ in range(2)]                    # an AGPR tile on its way through the VALU, alternating
 
@@ -221,13 +230,15 @@ def se_hook(w, hook, acc, B, fc_label):
     a(f"\ts_mul_i32 {sr(s_t1)}, {sr(s_bs)}, {sr(s_bs)}")
     a(f"\tv_cmp_gt_u32_e64 {sr(s_valid, 2)}, {sr(s_t1)}, {vr(v_t)}")
     a(f"\tv_cmp_eq_u32_e64 {sr(s_px0, 2)}, 0, {vr(v_px)}")
-    # psum[wave_n * KO_T + wave_m * WMT * 16 + i * 16 + 4 q] (floats) behind the images
+    # psum[wave_n * KO_T + wave_m * WMT * 16 + first channel of (row tile i, quad q)] (floats) behind the images
     a(f"\ts_mul_i32 {sr(s_t0)}, {sr(s_wave_n)}, {kot * 4}")
     a(f"\ts_mul_i32 {sr(s_t1)}, {sr(s_wave_m)}, {wmt * 16 * 4}")
     a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_t0)}, {sr(s_t1)}")
     a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_t0)}, {sr(s_wbytes)}")
     a(f"\ts_add_u32 {sr(s_t0)}, {sr(s_t0)}, {hook['psum']}")
-    a(f"\tv_lshl_add_u32 {vr(v_addr)}, {vr(v_q)}, 4, {sr(s_t0)}")
+    a(f"\tv_lshl_add_u32 {vr(v_addr)}, {vr(v_q)}, 4, {sr(s_t0)}")       # natural row order: quad q of row tile i at 16 i + 4 q
+    a(f"\tv_lshl_add_u32 {vr(v_addr2)}, {vr(v_q)}, 5, {sr(s_t0)}")      # board_row_channel order: at quad_channel(i) + 8 q
+    a(f"\ts_load_dword {sr(s_ro)}, {E}, {hex(hook['roword'])}")
 
     def tile_ops(i, j, S4, M4, X):
         """sum += tile, max = max(max, tile) for output tile (i, j); the caller has set exec"""
@@ -276,8 +287,17 @@ def se_hook(w, hook, acc, B, fc_label):
                 a(f"\tv_max_f32_dpp {vr(M4 + r)}, {vr(M4 + r)}, {vr(M4 + r)} row_ror:{step} row_mask:0xf bank_mask:0xf")
         a(f"\ts_mov_b64 {sr(s_save, 2)}, exec")
         a(f"\ts_and_b64 exec, exec, {sr(s_px0, 2)}")
+        if i == 0:
+            a("\ts_waitcnt lgkmcnt(0)")      # row_order has arrived
+        a(f"\ts_cmp_eq_u32 {sr(s_ro)}, 0")
+        a(f"\ts_cbranch_scc1 {L}_pst{i}")
+        a(f"\tds_write_b128 {vr(v_addr2)}, {vr(S4, 4)} offset:{quad_channel(i) * 4}")
+        a(f"\tds_write_b128 {vr(v_addr2)}, {vr(M4, 4)} offset:{quad_channel(i) * 4 + hook['pmax'] - hook['psum']}")
+        a(f"\ts_branch {L}_pse{i}")
+        a(f"{L}_pst{i}:")
         a(f"\tds_write_b128 {vr(v_addr)}, {vr(S4, 4)} offset:{i * 64}")
         a(f"\tds_write_b128 {vr(v_addr)}, {vr(M4, 4)} offset:{i * 64 + hook['pmax'] - hook['psum']}")
+        a(f"{L}_pse{i}:")
         a(f"\ts_mov_b64 exec, {sr(s_save, 2)}")
     a("\ts_waitcnt vmcnt(0) lgkmcnt(0)")    # this wave's pieces of the images have landed, its partials are written
     a("\ts_barrier")
@@ -301,10 +321,19 @@ def se_hook(w, hook, acc, B, fc_label):
     a(f"\ts_mul_i32 s4, {sr(s_wave_m)}, {wmt * 16 * 4}")
     a(f"\ts_add_u32 s4, s4, {sr(s_wbytes)}")
     a(f"\ts_add_u32 s4, s4, {hook['gate']}")
+    a(f"\ts_cmp_eq_u32 {sr(s_ro)}, 0")
+    a(f"\ts_cbranch_scc1 {L}_gnat")
+    a(f"\tv_lshl_add_u32 {vr(g_addr)}, {vr(g_q)}, 5, s4")
+    for i in range(wmt):
+        a(f"\tds_read_b128 {vr(gs[i][0], 4)}, {vr(g_addr)} offset:{quad_channel(i) * 4}")
+        a(f"\tds_read_b128 {vr(gs[i][1], 4)}, {vr(g_addr)} offset:{quad_channel(i) * 4 + kot * 4}")
+    a(f"\ts_branch {L}_gread")
+    a(f"{L}_gnat:")
     a(f"\tv_lshl_add_u32 {vr(g_addr)}, {vr(g_q)}, 4, s4")
     for i in range(wmt):
         a(f"\tds_read_b128 {vr(gs[i][0], 4)}, {vr(g_addr)} offset:{i * 64}")
         a(f"\tds_read_b128 {vr(gs[i][1], 4)}, {vr(g_addr)} offset:{i * 64 + kot * 4}")
+    a(f"{L}_gread:")
     a("\ts_waitcnt lgkmcnt(0)")
     a("\ts_barrier")                         # the gate is read: the epilogue's residual rows may land in this LDS
 
@@ -337,11 +366,12 @@ def se_hook(w, hook, acc, B, fc_label):
 
 
 def epi_hook(w, hook, acc, B):
-    """The epilogue of width-w's convolution body as assembly text, for the layers it covers (Mish, one sample per tile with
-    computed table entries, the layer's channels = the channel tile): optional residual, activation, fp16 NHWC store, straight
+    """The epilogue of width-w's convolution body as assembly text, for the layers the host marks with row_order = 1 (Mish, one
+    sample per tile with computed table entries, the layer's channels = the channel tile; their weights and bias are in
+    board_row_channel order, so a lane's two accumulator quads of a row-tile pair ARE 8 consecutive channels): optional residual, activation, fp16 NHWC store, straight
     from the accumulators where the K loop left them -- the arithmetic of board_epilogue / mish2 (conv_board.h) operation for
     operation, so the outputs equal the compiled epilogue's bit for bit.  What it saves is what hipcc adds: per 16-byte store
-    ~14 register moves staging the swap operands and a conversion + half a packed add per residual value (here one
+    ~14 register moves staging its operands and a conversion + half a packed add per residual value (here one
     v_fma_mix_f32), in front of everything ~200 accumulator moves -- the epilogue is bound by VALU issue (tools/ubench/trans_rate.hip:
     a plain operation 4 cycles of a SIMD, a packed one 5, a transcendental 10.7, v_permlane16_swap 14).  Other layers fall through
     to the compiled epilogue behind this text."""
@@ -374,18 +404,17 @@ def epi_hook(w, hook, acc, B):
         return (j if j < JH else j - NRT) * npair + pr
 
     a(f"\t; ---- tower_seam.py: the epilogue (width {w}) for Mish layers with computed table entries; others take the compiled one below")
-    a(f"\ts_load_dword {sr(s_arith)}, {E}, {hex(hook['arith'])}")
-    a(f"\ts_load_dword {sr(s_act)}, {E}, {hex(hook['act'])}")
+    a(f"\ts_load_dword {sr(s_arith)}, {E}, {hex(hook['roword'])}")
     a(f"\ts_load_dword {sr(s_couts)}, {E}, {hex(hook['couts'])}")
     a(f"\ts_load_dword {sr(s_slotpix)}, {E}, {hex(hook['slotpix'])}")
     a(f"\ts_load_dword {sr(s_ui)}, {E}, {hex(hook['ui'])}")
     a(f"\ts_load_dwordx2 {sr(s_res, 2)}, {E}, {hex(hook['res'])}")
     a(f"\ts_load_dwordx2 {sr(s_out, 2)}, {E}, {hex(hook['out'])}")
     a("\ts_waitcnt lgkmcnt(0)")
-    for cmp_, br in ((f"s_cmp_eq_u32 {sr(s_arith)}, 0", "scc1"), (f"s_cmp_lg_u32 {sr(s_act)}, {hook['mish']}", "scc1"),
-                     (f"s_cmp_lt_i32 {sr(s_ui)}, 0", "scc1"), (f"s_cmp_lg_u32 {sr(s_couts)}, {kot}", "scc1")):
-        a("\t" + cmp_)
-        a(f"\ts_cbranch_{br} {L}_compiled")
+    # row_order = 1: the host gave this layer the board_row_channel image BECAUSE this text will run (Mish, one sample per tile with
+    # computed table entries, channels = the channel tile: Engine::board_row_order_ok)
+    a(f"\ts_cmp_eq_u32 {sr(s_arith)}, 0")
+    a(f"\ts_cbranch_scc1 {L}_compiled")
     # ---- geometry of this wave and lane (board_epilogue's first lines)
     a(f"\tv_and_b32_e32 {vr(v_lane)}, 63, {T}")
     a(f"\tv_lshrrev_b32_e32 {vr(v_R)}, 4, {vr(v_lane)}")
@@ -401,14 +430,10 @@ def epi_hook(w, hook, acc, B):
     a(f"\ts_cselect_b32 {sr(s_col0)}, 0, {sr(s_nj0)}")
     a(f"\ts_cselect_b32 {sr(s_nj)}, {sr(s_nj0)}, {sr(s_t0)}")
     a(f"\ts_mul_i32 {sr(s_npix)}, {sr(s_bs)}, {sr(s_bs)}")
-    # after the swap of pair pr a lane holds row tile 2 pr + (R & 1), channels (R >> 1) * 8 .. + 7 of it:
-    # cb(pr) = wave_m * WMT * 16 + (2 pr + (R & 1)) * 16 + (R >> 1) * 8, i.e. cb(0) + 32 pr
-    a(f"\tv_and_b32_e32 {vr(v_t)}, 1, {vr(v_R)}")
-    a(f"\tv_lshlrev_b32_e32 {vr(v_t)}, 4, {vr(v_t)}")
-    a(f"\tv_lshrrev_b32_e32 {vr(v_cb)}, 1, {vr(v_R)}")
-    a(f"\tv_lshl_add_u32 {vr(v_cb)}, {vr(v_cb)}, 3, {vr(v_t)}")
+    # the weight image's rows are in board_row_channel order: a lane holds channels 32 pr + 8 R .. + 7 of pair pr (the quad of
+    # row tile 2 pr, then the quad of 2 pr + 1) -- cb(pr) = wave_m * WMT * 16 + 8 R + 32 pr, no exchange between lanes
     a(f"\ts_mul_i32 {sr(s_t0)}, {sr(s_wave_m)}, {wmt * 16}")
-    a(f"\tv_add_u32_e32 {vr(v_cb)}, {sr(s_t0)}, {vr(v_cb)}")
+    a(f"\tv_lshl_add_u32 {vr(v_cb)}, {vr(v_R)}, 3, {sr(s_t0)}")
     # byte offset of (this lane's pixel of column tile 0, cb(0)) in the output / residual buffers; column tile j adds j * step
     a(f"\ts_lshl_b32 {sr(s_t1)}, {sr(s_col0)}, 4")
     a(f"\tv_add_u32_e32 {vr(v_pxl)}, {sr(s_t1)}, {vr(v_px)}")
@@ -529,9 +554,6 @@ def epi_hook(w, hook, acc, B):
                             die("epilogue: an accumulator tile in VGPRs is not even-aligned")
                         xs.append(lo)
                 xa, xb = xs
-                a("\ts_nop 1")                    # a VALU result read by v_permlane16_swap: two wait states
-                for r in range(4):
-                    a(f"\tv_permlane16_swap_b32 {vr(xa + r)}, {vr(xb + r)}")
                 if with_res:
                     # + residual: one fused multiply-add per value reads the fp16 half directly (v + (float)rr * 1.0: the same
                     # single rounding as conversion + add)
@@ -658,7 +680,7 @@ def main():
             key, _, val = tok.partition("=")
             hook[key] = val if key in ("elem", "tid") else int(val, 0)
         for key in ("elem", "tid", "wmt", "ui", "cols", "w1h", "w2h", "w1b", "w2b", "psum", "pmax", "gate", "kot", "res", "out", "couts",
-                    "slotpix", "act", "arith", "mish"):
+                    "slotpix", "act", "arith", "mish", "roword"):
             if key not in hook:
                 die(f"{conv['name']}: the hook statement names no `{key}`")
         if hook["wmt"] != w:

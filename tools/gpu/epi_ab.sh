@@ -5,6 +5,7 @@ mkdir -p gpurun_out
 cp sayuri_amd/lib/libsayuri_hip_new.so sayuri_amd/lib/libsayuri_hip.so
 timeout 600 python -m pytest tests/test_gpu_net.py -m gpu -x -q --timeout 300 -k "bit_identical or tower or persistent or launch" 2>&1 | tail -5
 timeout 600 python -m pytest tests/test_gpu_smallops.py -m gpu -x -q --timeout 150 -k "se_unit or conv_with_se" 2>&1 | tail -4
+SAYURI_TOWER_GEN_EPI=0 timeout 600 python -m pytest tests/test_gpu_smallops.py tests/test_gpu_net.py -m gpu -x -q --timeout 300 -k "se_unit or conv_with_se or bit_identical or golden" 2>&1 | tail -4
 timeout 900 python -m pytest tests/test_gpu_net.py tests/test_gpu_layers.py -m gpu -x -q --timeout 300 2>&1 | tail -5
 for v in old new old new old new; do
 cp sayuri_amd/lib/libsayuri_hip_$v.so sayuri_amd/lib/libsayuri_hip.so
