@@ -63,21 +63,17 @@ def algorithmic_flops_per_eval(spec, board: int = 19) -> float:
 def hbm_traffic(fp16: bool, dominant: str) -> dict:
     """HBM-side (fabric) bytes per launch of the dominant kernel, from the rocprofv3 PMC passes kept under profiles/
     (counters cannot be read from inside this process; MI355X_MICROARCH.md HBM section: separate --pmc passes, requests x
-    calibrated bytes per request).  The passes run on the per-layer launches (SAYURI_TOWER=0; rocprofv3's counter collection
-    faults the persistent launch): one tower launch = the sum over its layers.  `traffic_source` names the file, its age
-    and the commit it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+    calibrated bytes per request).  Round 4: the passes run on the persistent tower launch itself (conv_tower_kernel<4>;
+    rounds 2-3 had to sum per-layer launches).  `traffic_source` names the file, its age and the commit it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
     layer_algo = 2 * 256 * 361 * 256 * 2 + 256 * 256 * 9 * 2  # in + out + weights of one 256->256 layer, fp16, batch 256
-    if not fp16 or not os.path.exists(path):
+    if not fp16 or dominant != "tower_run" or not os.path.exists(path):
         return {"traffic": None, "algorithmic_bytes": layer_algo}
     t = json.load(open(path))
-    if dominant == "tower_run":
-        rd, wr, algo = t["tower_run"]["read_bytes"], t["tower_run"]["write_bytes"], t["tower_run"]["algorithmic_bytes"]
-    else:
-        rd, wr, algo = t["conv3x3_tower"]["read_bytes"], t["conv3x3_tower"]["write_bytes"], t["conv3x3_tower"]["algorithmic_bytes"]
+    rd, wr, algo = t["tower_run"]["read_bytes"], t["tower_run"]["write_bytes"], t["tower_run"]["algorithmic_bytes"]
     age_h = (time.time() - os.path.getmtime(path)) / 3600.0
     return {"traffic": rd + wr, "traffic_read": rd, "traffic_write": wr, "algorithmic_bytes": algo,
-            "traffic_over_algorithmic": round((rd + wr) / algo, 3),
+            "traffic_over_algorithmic": round((rd + wr) / algo, 3), "traffic_is_per_layer_sum": False,
             "traffic_source": f"{os.path.relpath(path, ROOT)} ({t['source']}; measured on commit {t.get('commit', '?')}, file {age_h:.1f} h old)"}
 
 

@@ -1,5 +1,8 @@
 #include "tree.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <functional>
 #include <cstring>
@@ -368,7 +371,7 @@ Node* Node::PuctSelectChild(int color, bool is_root) {
     Edge* best = nullptr;
     float best_value = std::numeric_limits<float>::lowest();
     bool bare_seen = false;
-    auto consider = [&](Edge& c) {
+    auto consider = [&](Edge& c, Edge*& best, float& best_value) {
         Node* n = c.Get();
         if (n && !n->IsActive()) return;
         float q = fpu;
@@ -398,9 +401,32 @@ Node* Node::PuctSelectChild(int color, bool is_root) {
             if (bare_seen) continue;
             bare_seen = true;
         }
-        consider(c);
+        consider(c, best, best_value);
     }
-    if (!bare_seen && hi < size) consider(children_[static_cast<size_t>(hi)]);  // the best of the bare edges beyond
+    if (!bare_seen && hi < size) consider(children_[static_cast<size_t>(hi)], best, best_value);  // the best of the bare edges beyond
+    // SAYURI_PUCT_CHECK=1 (tests): the reference's loop over ALL children must pick the same edge, and the two conditions the
+    // pruning rests on must hold -- children sorted by policy, nothing but bare edges beyond inflated_hi_
+    static const bool check = std::getenv("SAYURI_PUCT_CHECK") != nullptr;
+    if (check) {
+        Edge* full = nullptr;
+        float full_value = std::numeric_limits<float>::lowest();
+        for (int i = 0; i < size; ++i) {
+            Edge& c = children_[static_cast<size_t>(i)];
+            consider(c, full, full_value);
+            // (the root is exempt: every child is looked at there, and its policies carry noise)
+            const bool sorted = is_root || i == 0 || !(children_[static_cast<size_t>(i - 1)].GetPolicy() < c.GetPolicy());
+            if (!sorted || (i >= hi && c.Get())) {
+                std::fprintf(stderr, "PuctSelectChild: %s at child %d of %d (inflated_hi %d, root %d)\n",
+                             sorted ? "an inflated edge beyond inflated_hi_" : "children not sorted by policy", i, size, static_cast<int>(inflated_hi_), is_root ? 1 : 0);
+                std::abort();
+            }
+        }
+        if (full != best) {
+            std::fprintf(stderr, "PuctSelectChild: the pruned loop picked child %d, the full loop child %d (of %d, root %d)\n",
+                         static_cast<int>(best - children_.data()), static_cast<int>(full - children_.data()), size, is_root ? 1 : 0);
+            std::abort();
+        }
+    }
     return Inflate(*best);
 }
 

@@ -121,14 +121,14 @@ __global__ __launch_bounds__(512, 2) void conv_tower_kernel(const TowerLayer* la
     int tid2 = tid;
     tower_anchor<WMT, 0>(acc);
     asm volatile("; TOWER_SE_HOOK elem=%0 tid=%1 wmt=%2 ui=%3 cols=%4 w1h=%5 w2h=%6 w1b=%7 w2b=%8 psum=%9 pmax=%10 gate=%11 kot=%12 "
-                 "res=%13 out=%14 couts=%15 slotpix=%16 act=%17 arith=%18 mish=%19 roword=%20"
+                 "res=%13 out=%14 couts=%15 slotpix=%16 act=%17 arith=%18 mish=%19 roword=%20 relu=%21 identity=%22"
                  : "+s"(L2), "+v"(tid2)
                  : "n"(WMT), "n"(offsetof(TowerLayer, sp.b.uniform_info)), "n"(offsetof(TowerLayer, sp.b.tab_cols)),
                    "n"(offsetof(TowerLayer, sp.w1h)), "n"(offsetof(TowerLayer, sp.w2h)), "n"(offsetof(TowerLayer, sp.w1_bytes)),
                    "n"(offsetof(TowerLayer, sp.w2_bytes)), "n"(SeLds<WMT>::psum), "n"(SeLds<WMT>::pmax), "n"(SeLds<WMT>::gate),
                    "n"(BoardCfg<WMT>::KO_T), "n"(offsetof(TowerLayer, sp.b.c.res)), "n"(offsetof(TowerLayer, sp.b.c.out)),
                    "n"(offsetof(TowerLayer, sp.b.c.cout_s)), "n"(offsetof(TowerLayer, sp.b.c.g.slot_pix)), "n"(offsetof(TowerLayer, sp.b.c.act)),
-                   "n"(offsetof(TowerLayer, sp.b.arith)), "n"((int)kMish), "n"(offsetof(TowerLayer, sp.b.row_order))
+                   "n"(offsetof(TowerLayer, sp.b.arith)), "n"((int)kMish), "n"(offsetof(TowerLayer, sp.b.row_order)), "n"((int)kReLU), "n"((int)kIdentity)
                  : "memory", "vcc", "scc", SAYURI_TOWER_CLOBBER_V, SAYURI_TOWER_CLOBBER_S);
     const BoardSeParams& sp = *(const BoardSeParams*)&L2->sp;
     const BoardParams& bp = sp.b;

@@ -1294,10 +1294,11 @@ private:
     }
 
     // Does this layer of the persistent launch get the generated epilogue (tower_seam.py epi_hook)?  Then its weights and bias go
-    // in board_row_channel order and BoardParams::row_order says so.  What the generated text covers: Mish, one sample per tile
+    // in board_row_channel order and BoardParams::row_order says so.  What the generated text covers: Mish / ReLU / no activation, one sample per tile
     // with computed table entries (arith), the layer's channels = the channel tile, an even number of row tiles per wave.
     bool board_row_order_ok(const ConvLayerDev& L, const BoardEntry* be, const BoardParams& bp, int act) const {
-        return flags_.tower_gen_epi && tower_ok(be->kot) && !bp.dbg && board_uses_row_order(be->kot) && bp.arith && act == kMish &&
+        return flags_.tower_gen_epi && tower_ok(be->kot) && !bp.dbg && board_uses_row_order(be->kot) && bp.arith &&
+               (act == kMish || act == kReLU || act == kIdentity) &&
                L.cout_s == be->kot && L.ko_pad == be->kot && L.w_board && L.bias_board;
     }
 
@@ -2348,7 +2349,7 @@ static int test_conv_se_impl(int device, int n, const int* board_sizes, int max_
     if (bias) std::copy(bias, bias + C, hb.begin());
     // through the tower a Mish layer with computed table entries takes the generated epilogue: weights and bias in
     // board_row_channel order (Engine::board_row_order_ok)
-    const bool row_order = via_tower && board_uses_row_order(be->kot) && act == kMish && plan.single && plan.uniform_info >= 0 && cs == be->kot &&
+    const bool row_order = via_tower && board_uses_row_order(be->kot) && (act == kMish || act == kReLU || act == kIdentity) && plan.single && plan.uniform_info >= 0 && cs == be->kot &&
                            !EngineFlags::off("SAYURI_TOWER_GEN_EPI");
     if (row_order) {
         std::vector<float> hbb(ko_pad);

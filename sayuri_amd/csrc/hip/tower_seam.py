@@ -366,8 +366,8 @@ def se_hook(w, hook, acc, B, fc_label):
 
 
 def epi_hook(w, hook, acc, B):
-    """The epilogue of width-w's convolution body as assembly text, for the layers the host marks with row_order = 1 (Mish, one
-    sample per tile with computed table entries, the layer's channels = the channel tile; their weights and bias are in
+    """The epilogue of width-w's convolution body as assembly text, for the layers the host marks with row_order = 1 (Mish, ReLU or
+    no activation, one sample per tile with computed table entries, the layer's channels = the channel tile; their weights and bias are in
     board_row_channel order, so a lane's two accumulator quads of a row-tile pair ARE 8 consecutive channels): optional residual, activation, fp16 NHWC store, straight
     from the accumulators where the K loop left them -- the arithmetic of board_epilogue / mish2 (conv_board.h) operation for
     operation, so the outputs equal the compiled epilogue's bit for bit.  What it saves is what hipcc adds: per 16-byte store
@@ -405,6 +405,7 @@ def epi_hook(w, hook, acc, B):
 
     a(f"\t; ---- tower_seam.py: the epilogue (width {w}) for Mish layers with computed table entries; others take the compiled one below")
     a(f"\ts_load_dword {sr(s_arith)}, {E}, {hex(hook['roword'])}")
+    a(f"\ts_load_dword {sr(s_act)}, {E}, {hex(hook['act'])}")
     a(f"\ts_load_dword {sr(s_couts)}, {E}, {hex(hook['couts'])}")
     a(f"\ts_load_dword {sr(s_slotpix)}, {E}, {hex(hook['slotpix'])}")
     a(f"\ts_load_dword {sr(s_ui)}, {E}, {hex(hook['ui'])}")
@@ -497,9 +498,7 @@ def epi_hook(w, hook, acc, B):
     for t in range(NJ - JH, -1, -1):
         a(f"{L}_late{t}:")
         a(f"\ts_waitcnt vmcnt({t * npair})")
-        if t:
-            a(f"\ts_branch {L}_tiles")
-    a(f"{L}_tiles:")
+        a(f"\ts_branch {L}_tiles")
 
     def mish8(x_pairs, h):
         """x_pairs: four even-aligned VGPR pairs holding 8 values; h <- their Mish as 8 fp16 (4 VGPRs)"""
@@ -522,8 +521,20 @@ def epi_hook(w, hook, acc, B):
         for k in range(4):
             a(f"\tv_cvt_pk_f16_f32 {vr(h + k)}, {vr(x_pairs[k])}, {vr(x_pairs[k] + 1)}")
 
-    def tiles(with_res):
-        tag = "r" if with_res else "n"
+    def act8(kind, x_pairs, h):
+        """h <- act(the 8 values of x_pairs) as 8 fp16; kind = the activation's name in common.h"""
+        if kind == "mish":
+            return mish8(x_pairs, h)
+        if kind == "relu":      # x > 0 ? x : 0 as a compare and a select (v_max_f32 might hand back -0)
+            for k in range(4):
+                for e in range(2):
+                    a(f"\tv_cmp_lt_f32_e32 vcc, 0, {vr(x_pairs[k] + e)}")
+                    a(f"\tv_cndmask_b32_e32 {vr(x_pairs[k] + e)}, 0, {vr(x_pairs[k] + e)}, vcc")
+        for k in range(4):      # (identity: nothing but the conversion)
+            a(f"\tv_cvt_pk_f16_f32 {vr(h + k)}, {vr(x_pairs[k])}, {vr(x_pairs[k] + 1)}")
+
+    def tiles(with_res, kind):
+        tag = ("r" if with_res else "n") + kind
         nstore = 0
         for j in range(NJ):
             a(f"\ts_cmp_le_u32 {sr(s_nj)}, {j}")
@@ -544,8 +555,8 @@ def epi_hook(w, hook, acc, B):
                 elif with_res:
                     rr = rreg[(j - JH) * npair + pr]
                 xs = []
-                for (kind, lo), tmp in ((ta, X), (tb, Y)):
-                    if kind == "a":
+                for (cls, lo), tmp in ((ta, X), (tb, Y)):
+                    if cls == "a":
                         for r in range(4):
                             a(f"\tv_accvgpr_read_b32 {vr(tmp + r)}, a{lo + r}")
                         xs.append(tmp)
@@ -564,15 +575,23 @@ def epi_hook(w, hook, acc, B):
                         a(f"\tv_fma_mix_f32 {vr(vals[q])}, {vr(rr + q // 2)}, 1.0, {vr(vals[q])} op_sel:[{q & 1},0,0] op_sel_hi:[1,0,0]")
                 h = Hs[nstore & 1]
                 nstore += 1
-                mish8([xa, xa + 2, xb, xb + 2], h)
+                act8(kind, [xa, xa + 2, xb, xb + 2], h)
                 a(f"\ts_and_saveexec_b64 {sr(s_save, 2)}, {sr(s_valid, 2)}")
                 a(f"\tglobal_store_dwordx4 {vr(v_so)}, {vr(h, 4)}, {sr(s_out, 2)}" + (f" offset:{64 * pr}" if pr else ""))
                 a(f"\ts_mov_b64 exec, {sr(s_save, 2)}")
         a(f"\ts_branch {L}_done")
 
-    tiles(True)
-    a(f"{L}_tiles_nores:")
-    tiles(False)
+    # one pair of tile loops (with / without residual) per activation the text covers
+    kinds = (("mish", hook["mish"]), ("relu", hook["relu"]), ("identity", hook["identity"]))
+    for with_res in (True, False):
+        a(f"{L}_tiles:" if with_res else f"{L}_tiles_nores:")
+        for kind, code in kinds[1:]:
+            a(f"\ts_cmp_eq_u32 {sr(s_act)}, {code}")
+            a(f"\ts_cbranch_scc1 {L}_{'r' if with_res else 'n'}{kind}")
+        for kind, code in kinds:
+            if kind != "mish":
+                a(f"{L}_{'r' if with_res else 'n'}{kind}:")
+            tiles(with_res, kind)
     a(f"{L}_done:")
     o.extend(far_jump(f"tower{w}_seam"))
     a(f"{L}_compiled:")
@@ -680,7 +699,7 @@ def main():
             key, _, val = tok.partition("=")
             hook[key] = val if key in ("elem", "tid") else int(val, 0)
         for key in ("elem", "tid", "wmt", "ui", "cols", "w1h", "w2h", "w1b", "w2b", "psum", "pmax", "gate", "kot", "res", "out", "couts",
-                    "slotpix", "act", "arith", "mish", "roword"):
+                    "slotpix", "act", "arith", "mish", "relu", "identity", "roword"):
             if key not in hook:
                 die(f"{conv['name']}: the hook statement names no `{key}`")
         if hook["wmt"] != w:

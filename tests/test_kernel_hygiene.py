@@ -150,6 +150,11 @@ def test_persistent_tower_code_object():
         # Mish of mish2 operation for operation, 16-byte stores) which leaves by a far jump to the seam, then the compiled epilogue
         gen = tail[first_store - 200:]
         assert any(x.startswith("v_fma_mix_f32") for x in tail) and any(x.startswith("v_cvt_pk_f16_f32") for x in gen)
+        # its three activations: Mish (per store 8 x v_exp_f32 + 8 x v_rcp_f32), ReLU (compare + select), none
+        stores = sum(x.startswith("global_store_dwordx4") for x in gen[:gen.index(next(x for x in gen if x.startswith("s_setpc_b64")))])
+        assert stores == 6 * 12 * (w // 2), stores
+        assert sum(x.startswith("v_exp_f32") for x in gen) >= 8 * stores // 3 and sum(x.startswith("v_rcp_f32") for x in gen) >= 8 * stores // 3
+        assert sum(x.startswith("v_cmp_lt_f32") for x in gen) >= 8 * stores // 3
         assert not [x for x in gen[:first_store + 3000 - (first_store - 200)] if x.startswith("v_permlane16_swap")][:1] or True
         assert sum(x.startswith("s_setpc_b64") for x in tail) >= 1, "the generated epilogue jumps to the seam"
         # the seam: every exit goes through  vmcnt(0) -> s_barrier -> (end | next element)

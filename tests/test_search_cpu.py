@@ -230,3 +230,24 @@ def test_search_benchmark_mode_on_the_dummy_backend():
     import math
     exp = 250.0 * math.log(r["playouts_per_second_per_search"]) / math.log(2.0) - 7.0 * (1600.0 / (800.0 + 120)) ** 0.85
     assert abs(r["elo"] - exp) < 1e-6 * abs(exp)
+
+
+def test_pruned_child_selection_against_the_full_loop():
+    """Node::PuctSelectChild skips every bare edge after the first one and everything beyond inflated_hi_ (tree.cc).  With
+    SAYURI_PUCT_CHECK=1 the engine runs the reference's loop over ALL children next to it at every selection and aborts when the
+    two pick different edges, when the children are not sorted by policy, or when an inflated edge sits beyond inflated_hi_.
+    A golden self-play game (Dirichlet noise, forced visits: the second entry of DUMMY_GAMES) and a `think` game under the
+    check, in a child process (the switch is read once)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import test_search_cpu as T\n"
+            "from sayuri_amd import search as S\n"
+            "seed, board, komi, scoring, opts = T.DUMMY_GAMES[1]\n"
+            "moves, _, _ = T.engine_selfplay_game(S.Network(options=T.options(opts)), seed, board, komi, scoring, opts, max_moves=60)\n"
+            "seed, board, komi, scoring, opts = T.THINK_GAMES[0]\n"
+            "moves += T.engine_think_game(seed, board, komi, scoring, opts, max_moves=40)\n"
+            "print('checked', len(moves))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, SAYURI_PUCT_CHECK="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "checked" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])

@@ -33,14 +33,14 @@ def main(src, tag):
     bd = os.path.join(src, "bench_default.json")
     if os.path.exists(bd):
         open(os.path.join(prof, f"{tag}_bench_default.json"), "w").write(open(bd).read().strip().split("\n")[-1] + "\n")
-    head = [f"# rocprofv3 --pmc <one set per pass> --kernel-trace -- python bench.py --steps 2 --warmup 1 ... with SAYURI_TOWER=0 (tools/gpu/profile.sh)",
-            "# first block of a set = conv_board_kernel<4> (plain tower layers incl. the input convolution), second = conv_board_se_kernel<4>;"
-            " calib_* = 1 GiB streams under the same set",
+    head = [f"# rocprofv3 --pmc <one set per pass> --kernel-trace -- python bench.py --steps 2 --warmup 1 ... (tools/gpu/profile.sh): counters of the",
+            "# persistent tower launch ITSELF (conv_tower_kernel<4>: 41 convolutions + 6 SE units of one forward); `per-layer` rows: the compiled"
+            " per-layer kernels of the same forward under SAYURI_TOWER=0; calib_* = 1 GiB streams under the same set",
             "# counters are sums over the 8 XCDs: GRBM_GUI_ACTIVE / 8 = cycles per launch.  MEDIANS over the dispatches (the means below include the"
             " first, cold launch of each kernel):"]
     p1 = glob.glob(os.path.join(src, "prof", "p1", "*counter_collection.csv"))
     p2 = glob.glob(os.path.join(src, "prof", "p2", "*counter_collection.csv"))
-    for kern in ("conv_board_kernel<4", "conv_board_se_kernel<4"):
+    for kern in ("conv_tower_kernel<4",):
         line = f"#   {kern}>"
         if p1:
             m = medians(p1[0], kern)
@@ -54,7 +54,7 @@ def main(src, tag):
         head.append(line)
     raw = os.path.join(src, "pmc_raw.txt")
     if os.path.exists(raw):
-        open(os.path.join(prof, f"{tag}_rocprofv3_pmc_conv_board.txt"), "w").write("\n".join(head) + "\n" + open(raw).read())
+        open(os.path.join(prof, f"{tag}_rocprofv3_pmc_conv_tower.txt"), "w").write("\n".join(head) + "\n" + open(raw).read())
         subprocess.check_call([sys.executable, os.path.join(root, "tools", "traffic_json.py"), raw, os.path.join(prof, f"{tag}_hbm_traffic")])
     print("\n".join(head[3:]))
 

@@ -2,7 +2,7 @@
 # Evidence pass of a round on one box (TAG=r03 ...): GPU suite, kernel-trace stats, PMC passes (one counter set per run,
 # --kernel-trace only), HBM-side traffic with calibration streams, the default bench line, configs[4], fp32.
 cd "$GRAFT_REPO_ROOT" || exit 1
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 O=gpurun_out/$TAG
 mkdir -p $O/prof
 export TMPDIR=/tmp
@@ -21,20 +21,25 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY S
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "TCC_WRITE_sum TCC_READ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  # counters are collected on the per-layer launches (SAYURI_TOWER=0: the same K loop, SE stage and epilogue code, one launch
-  # per convolution): under rocprofv3's counter collection the persistent tower launch faults (it does not under --kernel-trace)
-  (cd /tmp && SAYURI_TOWER=0 timeout 100 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof/p$i -o p --output-format csv -- $B --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/$O/prof/p$i.out 2> $GRAFT_REPO_ROOT/$O/prof/p$i.err)
+  # counters are collected on the persistent tower launch itself (round 4: its descriptor declares no private segment any more,
+  # which is what made rocprofv3's counter collection fault in rounds 2-3); the first set also on the per-layer launches
+  # (SAYURI_TOWER=0: the compiled kernels) for the per-layer rows
+  (cd /tmp && timeout 100 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof/p$i -o p --output-format csv -- $B --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/$O/prof/p$i.out 2> $GRAFT_REPO_ROOT/$O/prof/p$i.err)
   echo "## set $i [$set] rc=$?"
   grep -E "Memory access fault|Segmentation|rror" $O/prof/p$i.err | head -2
-  python tools/pmc_summary.py $O/prof/p$i "conv_board_kernel<4" 2>&1 | tail -n +2
-  python tools/pmc_summary.py $O/prof/p$i "conv_board_se_kernel<4" 2>&1 | tail -n +2
+  python tools/pmc_summary.py $O/prof/p$i "conv_tower_kernel<4" 2>&1 | tail -n +2
+  if [ $i -le 2 ]; then
+    (cd /tmp && SAYURI_TOWER=0 timeout 100 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof/l$i -o p --output-format csv -- $B --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/$O/prof/l$i.out 2> $GRAFT_REPO_ROOT/$O/prof/l$i.err)
+    python tools/pmc_summary.py $O/prof/l$i "conv_board_kernel<4" 2>&1 | tail -n +2 | sed "s/^/   per-layer plain  /"
+    python tools/pmc_summary.py $O/prof/l$i "conv_board_se_kernel<4" 2>&1 | tail -n +2 | sed "s/^/   per-layer SE     /"
+  fi
   if [ $i -ge 3 ]; then
     (cd /tmp && timeout 150 rocprofv3 --pmc $set --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof/c$i -o p --output-format csv -- $GRAFT_REPO_ROOT/tools/ubench/hbm_calib.so > $GRAFT_REPO_ROOT/$O/prof/c$i.out 2> $GRAFT_REPO_ROOT/$O/prof/c$i.err)
     for k in calib_read calib_write_kernel calib_write64; do python tools/pmc_summary.py $O/prof/c$i $k 2>&1 | tail -n +2 | sed "s/^/   $k (1 GiB)  /"; done
   fi
 done > $O/pmc_raw.txt 2>&1
 cat $O/pmc_raw.txt
-timeout 900 python bench.py --no-cpu-baseline --selfplay-seconds 0 --config5 > $O/config5.json 2> $O/config5.err; echo "config5 rc=$?"
+timeout 900 python bench.py --no-cpu-baseline --selfplay-seconds 0 --no-pump --config5 > $O/config5.json 2> $O/config5.err; echo "config5 rc=$?"
 python -c "import json;d=json.load(open('$O/config5.json'));print(d['value'], d['roofline']['frac'], d['config5'])"
 timeout 300 python bench.py --fp32 --steps 5 --warmup 1 --no-cpu-baseline --no-config5 --selfplay-seconds 0 > $O/bench_fp32.json 2> $O/bench_fp32.err; echo "fp32 rc=$?"
 python -c "import json;d=json.load(open('$O/bench_fp32.json'));print(d['value'], d['roofline'])"
