@@ -138,11 +138,11 @@ void Encoder::Packed(const GameState& state, int symmetry, int weights_version, 
     const int past = std::min(state.GetMoveNumber() + 1, kHistory);
     for (int p = 0; p < past; ++p) {
         const Frame& f = state.Past(p);
-        const std::uint64_t mine = bit(3 * p), yours = bit(3 * p + 1);
-        for (int i = 0; i < n; ++i) {
-            if (f.stones[i] == me) mask[i] |= mine;
-            else if (f.stones[i] == you) mask[i] |= yours;
-        }
+        // (a table lookup per cell instead of two compares and branches: which cells hold stones is not predictable)
+        std::uint64_t by_color[4] = {0, 0, 0, 0};
+        by_color[me] = bit(3 * p);
+        by_color[you] = bit(3 * p + 1);
+        for (int i = 0; i < n; ++i) mask[i] |= by_color[f.stones[i] & 3];
         const int lm = f.last_move;
         if (lm != kNoVertex && lm != kPassMove && lm != kResignMove) mask[b.VertexToIndex(lm)] |= bit(3 * p + 2);
     }

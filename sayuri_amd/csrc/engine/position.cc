@@ -472,17 +472,61 @@ bool Position::IsLadder(int v, int* vital, int* num_vital) const {
     ChainLiberties(v, lib, nl);
     int nodes = 0;
     if (nl == 1) {
-        Position work = *this;
-        if (PreyTurn(work, kNoVertex, prey, v, nodes) == kHunterWins) vital[(*num_vital)++] = lib[0];
+        // PreyTurn with no hunter move in front: its first look is at the board as it stands, so the working copy (5 KB) is
+        // only made when the prey has a move to try
+        int sel[kMaxPoints], n, verdict = kPreyWins;
+        if (++nodes < kLadderNodeLimit) {
+            verdict = PreyCandidates(prey, v, sel, n, false);
+            if (verdict == kLadderOpen) {
+                for (int i = 0; i < n; ++i) {
+                    Position work = *this;
+                    verdict = HunterTurn(work, sel[i], prey, v, nodes);
+                    if (verdict == kPreyWins) break;
+                }
+            }
+        }
+        if (verdict == kHunterWins) vital[(*num_vital)++] = lib[0];
     } else if (nl == 2) {
         for (int i = 0; i < 2; ++i) {
-            Position work = *this;
-            if (!work.IsLegal(lib[i], Opp(prey))) continue;
+            if (!IsLegal(lib[i], Opp(prey))) continue;
             // the hunter ataris first
+            if (AtariEscapesAtOnce(lib[i], lib[1 - i], prey)) {
+                ++nodes;  // the node PreyTurn would have counted before it found the same
+                continue;
+            }
+            Position work = *this;
             if (PreyTurn(work, lib[i], prey, v, nodes) == kHunterWins) vital[(*num_vital)++] = lib[i];
         }
     }
     return *num_vital > 0;
+}
+
+bool Position::AtariEscapesAtOnce(int atari, int extend, int prey) const {
+    // The hunter ataris a two-liberty chain at `atari`; the prey's answer is to extend at `extend`.  PreyCandidates calls the
+    // ladder off when that extension is legal and reaches three liberties by itself or by the chain it connects to
+    // (LadderLibertyBounds' lower bound without its capture term, which only adds).  If the hunter's stone captures nothing,
+    // the board after it is this board plus one stone: the bound can be read here, without the copy and the move.  Most
+    // two-liberty chains of a position are not in a ladder and leave through this door.
+    for (int k = 0; k < 4; ++k) {
+        const int a = atari + dir_[k];
+        if (cell_[a] == prey && libs_[head_[a]] == 1) return false;  // a capture: the board changes by more than the stone
+    }
+    int best = EmptyNeighbours(extend) - (IsAdjacent(atari, extend) ? 1 : 0);
+    for (int k = 0; k < 4; ++k) {
+        const int a = extend + dir_[k];
+        if (cell_[a] != prey) continue;
+        const int h = head_[a];
+        int l = libs_[h];
+        for (int kk = 0; kk < 4; ++kk) {
+            const int t = atari + dir_[kk];
+            if (cell_[t] == prey && head_[t] == h) {
+                l -= 1;  // the hunter's stone takes this liberty
+                break;
+            }
+        }
+        best = std::max(best, l - 1);
+    }
+    return best >= 3;
 }
 
 void Position::LadderMap(std::uint8_t* out) const {
@@ -534,40 +578,62 @@ int Position::ReachGroup(int start, int spread, bool* seen) const {
 void Position::ReachArea(int* out) const {
     // Tromp-Taylor: a point belongs to a colour when it is that colour or reaches only that colour through empties --
     // i.e. an empty region belongs to the one colour it borders (reference board.cc:1547-1579 does two breadth-first
-    // searches from the stones; one flood fill per empty region gives the same map)
-    bool seen[kMaxVertices];
-    std::memset(seen, 0, sizeof(seen));
-    int stack[kMaxVertices], members[kMaxPoints];
+    // searches from the stones; labelling the empty regions gives the same map).  The regions are labelled in one raster
+    // pass (a cell joins the label of its upper / left neighbour, two labels that meet are united, the smaller one
+    // staying the root) with the colours each label touches OR-ed along: no stack, and branches that follow the board's
+    // rows instead of a flood fill's frontier.  This runs once per evaluated position.
+    std::uint16_t lab[kMaxVertices];
+    std::memset(lab, 0, sizeof(lab));
+    std::uint16_t parent[kMaxPoints + 2];
+    std::uint8_t touch[kMaxPoints + 2];
+    int labels = 0;
+    const int l = letter_;
+    auto find = [&parent](int x) {
+        while (parent[x] != x) {
+            parent[x] = parent[parent[x]];
+            x = parent[x];
+        }
+        return x;
+    };
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        if (cell_[v] != kEmpty) continue;
+        int a = lab[v - l], b = lab[v - 1];
+        int mine;
+        if (a == 0 && b == 0) {
+            mine = ++labels;
+            parent[mine] = static_cast<std::uint16_t>(mine);
+            touch[mine] = 0;
+        } else if (a == 0 || b == 0 || a == b) {
+            mine = a ? a : b;
+        } else {
+            a = find(a);
+            b = find(b);
+            mine = a < b ? a : b;
+            parent[a < b ? b : a] = static_cast<std::uint16_t>(mine);
+        }
+        lab[v] = static_cast<std::uint16_t>(mine);
+        unsigned border = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int ca = cell_[v + dir_[k]];
+            if (ca == kBlack || ca == kWhite) border |= 1u << ca;
+        }
+        touch[mine] |= static_cast<std::uint8_t>(border);
+    }
+    // a label's parent is always a smaller label: fold the masks towards the roots from the top, then hand every label its root's
+    for (int x = labels; x >= 1; --x)
+        if (parent[x] != x) touch[parent[x]] |= touch[x];
+    for (int x = 1; x <= labels; ++x)
+        if (parent[x] != x) touch[x] = touch[parent[x]];
     for (int i = 0; i < points_; ++i) {
         const int v = IndexToVertex(i);
         const int c = cell_[v];
         if (c == kBlack || c == kWhite) {
             out[i] = c;
-            continue;
+        } else {
+            const unsigned border = touch[lab[v]];
+            out[i] = border == (1u << kBlack) ? kBlack : border == (1u << kWhite) ? kWhite : kEmpty;
         }
-        if (seen[v]) continue;
-        int sp = 0, nm = 0;
-        unsigned border = 0;
-        stack[sp++] = v;
-        seen[v] = true;
-        while (sp) {
-            const int p = stack[--sp];
-            members[nm++] = p;
-            for (int k = 0; k < 4; ++k) {
-                const int a = p + dir_[k];
-                const int ca = cell_[a];
-                if (ca == kEmpty) {
-                    if (!seen[a]) {
-                        seen[a] = true;
-                        stack[sp++] = a;
-                    }
-                } else if (ca == kBlack || ca == kWhite) {
-                    border |= 1u << ca;
-                }
-            }
-        }
-        const int owner = border == (1u << kBlack) ? kBlack : border == (1u << kWhite) ? kWhite : kEmpty;
-        for (int m = 0; m < nm; ++m) out[VertexToIndex(members[m])] = owner;
     }
 }
 
@@ -636,45 +702,71 @@ struct Position::Groups {
     int count;
 };
 
-void Position::Classify(int target, const std::uint8_t* feat, Groups& g) const {
-    for (int v = 0; v < kMaxVertices; ++v) {
-        g.id[v] = -1;
-        g.next[v] = kNoVertex;
-    }
-    for (int i = 0; i < points_; ++i) {
-        const int v = IndexToVertex(i);
-        g.id[v] = 0;
-        g.next[v] = static_cast<std::uint16_t>(v);
-    }
-    g.count = 0;
-    int stack[kMaxVertices];
-    for (int i = 0; i < points_; ++i) {
-        const int v = IndexToVertex(i);
-        if (g.id[v] != 0 || feat[v] != target) continue;
-        const int gid = ++g.count;
-        g.heads[gid - 1] = static_cast<std::uint16_t>(v);
-        int sp = 0;
-        stack[sp++] = v;
-        g.id[v] = static_cast<std::int16_t>(gid);
-        while (sp) {
-            const int p = stack[--sp];
-            for (int k = 0; k < 4; ++k) {
-                const int a = p + dir_[k];
-                if (g.id[a] == 0 && feat[a] == target) {
-                    g.id[a] = static_cast<std::int16_t>(gid);
-                    stack[sp++] = a;
-                }
-            }
+// Provisional labels of a raster labelling pass: lab[v] (from 1; 0 = not a cell of the labelled kind, or off the board), and a
+// union-find forest over the labels in which a label's parent is always a smaller label.
+struct Position::Labels {
+    std::uint16_t lab[kMaxVertices];
+    std::uint16_t parent[kMaxPoints + 2];
+    int count;
+    // the label of the cell at v, given the labels above and to the left of it
+    int Join(int v, int letter) {
+        int a = lab[v - letter], b = lab[v - 1];
+        int mine;
+        if (a == 0 && b == 0) {
+            mine = ++count;
+            parent[mine] = static_cast<std::uint16_t>(mine);
+        } else if (a == 0 || b == 0 || a == b) {
+            mine = a ? a : b;
+        } else {
+            while (parent[a] != a) a = parent[a];
+            while (parent[b] != b) b = parent[b];
+            mine = a < b ? a : b;
+            parent[a < b ? b : a] = static_cast<std::uint16_t>(mine);
         }
+        lab[v] = static_cast<std::uint16_t>(mine);
+        return mine;
     }
-    // link every group's members in ascending vertex order
+};
+
+void Position::Classify(int target, const std::uint8_t* feat, Groups& g) const {
+    // One raster pass with union-find instead of a flood fill per group (this is called two to four times per evaluated
+    // position and was the largest single item of the host profile on the GPU box): a cell takes the label of its upper /
+    // left neighbour, two labels that meet are united with the smaller one as the root.
+    Labels L;
+    std::memset(L.lab, 0, sizeof(L.lab));
+    L.count = 0;
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        if (feat[v] == target) L.Join(v, letter_);
+    }
+    LinkGroups(L, g);
+}
+
+void Position::LinkGroups(const Labels& L, Groups& g) const {
+    // A group's smallest label is the one its first cell in scan order opened, so numbering the roots in label order is
+    // numbering the groups by their first cell -- the order a flood fill from every unvisited cell finds them in.
+    static_assert(kNoVertex == 0, "next[] is cleared with memset");
+    std::memset(g.id, 0xff, sizeof(g.id));   // -1: off the board
+    std::memset(g.next, 0, sizeof(g.next));  // kNoVertex
+    // group ids: roots in label order; a label's parent is smaller than the label, so its id is already there
+    std::uint16_t gid[kMaxPoints + 2];
+    g.count = 0;
+    for (int x = 1; x <= L.count; ++x) gid[x] = L.parent[x] == x ? static_cast<std::uint16_t>(++g.count) : gid[L.parent[x]];
+    // members in ascending vertex order, each linking to its predecessor, the lowest (the head) to the highest
     std::uint16_t last[kMaxPoints + 1];
-    std::memset(last, 0, sizeof(last));
-    for (int v = 0; v < vertices_; ++v) {
-        const int gid = g.id[v];
-        if (gid <= 0) continue;
-        if (last[gid]) g.next[v] = last[gid];
-        last[gid] = static_cast<std::uint16_t>(v);
+    std::memset(last, 0, sizeof(last[0]) * static_cast<size_t>(g.count + 1));
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        if (!L.lab[v]) {
+            g.id[v] = 0;
+            g.next[v] = static_cast<std::uint16_t>(v);
+            continue;
+        }
+        const int id = gid[L.lab[v]];
+        g.id[v] = static_cast<std::int16_t>(id);
+        if (last[id]) g.next[v] = last[id];
+        else g.heads[id - 1] = static_cast<std::uint16_t>(v);
+        last[id] = static_cast<std::uint16_t>(v);
     }
     for (int k = 0; k < g.count; ++k) g.next[g.heads[k]] = last[k + 1];
 }
@@ -820,51 +912,54 @@ bool Position::RegionPassDead(int v, int c, const std::uint8_t* feat, const Grou
 }
 
 void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_pass_dead) const {
+    // Regions of non-`color` cells, labelled in one raster pass; a label is spoilt when it holds an empty cell that touches no
+    // `color` stone.  Benson's potentially vital regions are the unspoilt ones.
+    Labels L;
+    std::memset(L.lab, 0, sizeof(L.lab));
+    L.count = 0;
+    std::uint8_t spoilt[kMaxPoints + 2];
+    const int l = letter_;
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        const int c = cell_[v];
+        if (c == color) continue;
+        const int before = L.count;
+        const int mine = L.Join(v, l);
+        if (L.count != before) spoilt[mine] = 0;
+        if (c == kEmpty && cell_[v - l] != color && cell_[v - 1] != color && cell_[v + 1] != color && cell_[v + l] != color) spoilt[mine] = 1;
+    }
+    // fold the flags towards the roots (a parent is a smaller label), then hand every label its root's
+    bool any_vital = false;
+    for (int x = L.count; x >= 1; --x)
+        if (L.parent[x] != x) spoilt[L.parent[x]] |= spoilt[x];
+    for (int x = 1; x <= L.count; ++x) {
+        if (L.parent[x] != x) spoilt[x] = spoilt[L.parent[x]];
+        else any_vital |= !spoilt[x];
+    }
+    // The usual position of a game's first half has no potentially vital region at all.  Then no chain is pass-alive, no
+    // region is marked, and the pass-dead step below looks at one region holding the whole board, in which the other side has
+    // its two eyes as soon as three points are not its own stones (RegionPassDead's shortcut): nothing is written.
+    if (!any_vital) {
+        int free_points = 0;
+        for (int i = 0; i < points_ && free_points < 3; ++i) free_points += cell_[IndexToVertex(i)] != Opp(color);
+        if (free_points >= 3 || !mark_pass_dead) return;
+    }
     std::uint8_t occ[kMaxVertices];
     std::memset(occ, kWall, sizeof(occ));
+    bool vital[kMaxVertices];
+    std::memset(vital, 0, sizeof(vital));
     for (int i = 0; i < points_; ++i) {
         const int v = IndexToVertex(i);
         occ[v] = cell_[v] == color ? static_cast<std::uint8_t>(color) : static_cast<std::uint8_t>(kEmpty);
+        vital[v] = L.lab[v] != 0 && !spoilt[L.lab[v]];
     }
     Groups regions_store, chains_store;
     Groups* const regions = &regions_store;
     Groups* const chains = &chains_store;
-    Classify(kEmpty, occ, *regions);
+    LinkGroups(L, *regions);
     const int region_count = regions->count;
     std::uint16_t region_heads[kMaxPoints];
-    std::memcpy(region_heads, regions->heads, sizeof(region_heads));
-
-    // potentially vital regions: every empty point touches a `color` stone (enemy stones inside are fine)
-    bool vital[kMaxVertices];
-    std::memset(vital, 0, sizeof(vital));
-    for (int r = 0; r < region_count; ++r) {
-        const int h = region_heads[r];
-        bool ok = true;
-        int p = h;
-        do {
-            if (cell_[p] == kEmpty) {
-                bool touch = false;
-                for (int k = 0; k < 4; ++k) {
-                    if (occ[p + dir_[k]] == color) {
-                        touch = true;
-                        break;
-                    }
-                }
-                if (!touch) {
-                    ok = false;
-                    break;
-                }
-            }
-            p = regions->next[p];
-        } while (p != h);
-        if (ok) {
-            p = h;
-            do {
-                vital[p] = true;
-                p = regions->next[p];
-            } while (p != h);
-        }
-    }
+    std::memcpy(region_heads, regions->heads, sizeof(region_heads[0]) * static_cast<size_t>(region_count));
 
     // the chains of `color`: the board's own chain rings (ids = head vertex; which stone is the head and the order of the
     // ring do not matter below -- Benson's fixpoint is the same whatever order the chains are tested and dropped in)

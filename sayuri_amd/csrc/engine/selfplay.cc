@@ -392,6 +392,7 @@ void SelfplayPipe::SaveNetQueries(int games, const std::string& text) {
 }
 
 void SelfplayPipe::WriterLoop() {
+    pthread_setname_np(pthread_self(), "sayuri-writer");
     // chunks leave in random order, one game per file; a pool of `games` finished games is kept while the
     // workers run so that consecutive files do not come from consecutive games (pipe.cc:181-232)
     constexpr float kValidationRatio = 0.1f;

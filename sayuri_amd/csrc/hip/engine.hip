@@ -159,6 +159,7 @@ struct EngineFlags {
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
     int compute_streams = 1;
+    bool io_inorder = true;            // each ticket's upload, forward and download on the ticket's own stream (submit()); SAYURI_IO_INORDER=0: three streams and events
     int board_kot = 0;                 // experiments: only this channel tile
     int act_override = -1;             // experiments: activation of every board convolution
     int board_dbg = 0, heads_dbg = 0;  // experiments: in-kernel timelines
@@ -180,6 +181,7 @@ struct EngineFlags {
         f.heads_fused = !off("SAYURI_HEADS_FUSED");
         f.arith = !getenv("SAYURI_NO_ARITH");
         if (const char* e = getenv("SAYURI_COMPUTE_STREAMS")) f.compute_streams = atoi(e) == 2 ? 2 : 1;
+        if (const char* e = getenv("SAYURI_IO_INORDER")) f.io_inorder = atoi(e) != 0;
 #ifdef SAYURI_EXPERIMENTS
         if (const char* e = getenv("SAYURI_BOARD_KOT")) f.board_kot = atoi(e);
         if (const char* e = getenv("SAYURI_ACT_OVERRIDE")) f.act_override = atoi(e);
@@ -478,7 +480,6 @@ public:
         // 48.0 k vs 54.0 k evals/s through the queue, two graphs evict each other's weights and activations from L2.
         compute_[0] = stream_;
         compute_[1] = stream_;
-        if (flags_.compute_streams == 2) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
         HIP_OK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
         HIP_OK(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking));
         for (int t = 0; t < 2; ++t) {
@@ -498,6 +499,11 @@ public:
             tower_mod_ = nullptr;
             tower_fn_[0] = tower_fn_[1] = nullptr;
         }
+        // One stream per ticket only with the persistent launch: its workgroups hold every CU, so the two tickets' forwards
+        // follow one another whatever stream they are on.  Per-layer launches of two tickets would run side by side and evict
+        // each other's weights and activations from L2 (the measurement above): those keep the one compute stream.
+        inorder_ = flags_.io_inorder && tower_fn_[0] != nullptr;
+        if (flags_.compute_streams == 2 || inorder_) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
         return describe_layers();
     }
 
@@ -537,11 +543,20 @@ public:
         HIP_OK(hipSetDevice(device_));
         if (finalize()) return -1;
         select_slot(t);
-        HIP_OK(hipStreamWaitEvent(h2d_stream_, fwd_done_[t], 0));  // the forward that last read this slot's inputs
-        if (enqueue_inputs(n, planes, board_sizes, h2d_stream_, packed, binary)) return -1;
-        HIP_OK(hipEventRecord(h2d_done_[t], h2d_stream_));
-        HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
-        if (tick_ev_[t]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t], 0));  // the download that last read this slot's outputs
+        // Default (SAYURI_IO_INORDER=0 is the older arrangement below): everything of a ticket on the ticket's own stream, in
+        // order -- no event between streams at all.  Each record / wait is a marker the runtime's signal thread handles; the
+        // seven per batch of the three-stream arrangement kept that thread at a full host core during self-play (one of
+        // eight busy; profiles/r04_host_profile.txt), for the same evals/s.  The other ticket's stream overlaps its copies
+        // with this one's kernels as before; a ticket's slot is free when its stream gets to the next use.
+        const bool inorder = inorder_;
+        hipStream_t up = inorder ? stream_ : h2d_stream_, down = inorder ? stream_ : d2h_stream_;
+        if (!inorder) HIP_OK(hipStreamWaitEvent(h2d_stream_, fwd_done_[t], 0));  // the forward that last read this slot's inputs
+        if (enqueue_inputs(n, planes, board_sizes, up, packed, binary)) return -1;
+        if (!inorder) {
+            HIP_OK(hipEventRecord(h2d_done_[t], h2d_stream_));
+            HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
+            if (tick_ev_[t]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t], 0));  // the download that last read this slot's outputs
+        }
         have_batch_ = true;
         if (fwdstat_) {  // SAYURI_HIP_FWDSTAT (measuring aid): device time of every submitted forward
             for (int k = 0; k < 2; ++k)
@@ -570,20 +585,22 @@ public:
             fs_n_[t] = n;
             fs_uploads_ += table_uploads_ - uploads_before;
         }
-        HIP_OK(hipEventRecord(fwd_done_[t], stream_));
-        HIP_OK(hipStreamWaitEvent(d2h_stream_, fwd_done_[t], 0));
-        const size_t B2 = (size_t)board_ * board_;
-        HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, d2h_stream_));
-        if (!small_direct) {
-            HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, d2h_stream_));
-            HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, d2h_stream_));
+        if (!inorder) {
+            HIP_OK(hipEventRecord(fwd_done_[t], stream_));
+            HIP_OK(hipStreamWaitEvent(d2h_stream_, fwd_done_[t], 0));
         }
-        HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, d2h_stream_));
+        const size_t B2 = (size_t)board_ * board_;
+        HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, down));
+        if (!small_direct) {
+            HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, down));
+            HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, down));
+        }
+        HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, down));
         if (!tick_ev_[t]) HIP_OK(hipEventCreateWithFlags(&tick_ev_[t], hipEventDisableTiming));
-        HIP_OK(hipEventRecord(tick_ev_[t], d2h_stream_));
+        HIP_OK(hipEventRecord(tick_ev_[t], down));
         if (fwdstat_) {
             if (!fs_ev_[t][2]) HIP_OK(hipEventCreate(&fs_ev_[t][2]));
-            HIP_OK(hipEventRecord(fs_ev_[t][2], d2h_stream_));
+            HIP_OK(hipEventRecord(fs_ev_[t][2], down));
         }
         *ticket = t;
         return 0;
@@ -1772,6 +1789,7 @@ private:
     };
     IoSlot io_[2];
     hipStream_t compute_[2] = {nullptr, nullptr};
+    bool inorder_ = false;  // a ticket's copies on the ticket's compute stream (init(), submit())
     int cur_slot_ = 0;
     void select_slot(int t) {
         IoSlot& io = io_[t];

@@ -1,6 +1,7 @@
 #include "fiber.h"
 
 #include <linux/futex.h>
+#include <pthread.h>
 #include <sys/mman.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -152,6 +153,7 @@ void FiberPool::Run(int threads, const std::function<void(int)>& on_thread_start
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t)
         th.emplace_back([this, t, threads, &on_thread_start] {
+            pthread_setname_np(pthread_self(), "sayuri-games");  // (what a profile or `top -H` shows)
             if (on_thread_start) on_thread_start(t);
             std::vector<Fiber*> mine;
             for (std::size_t i = static_cast<std::size_t>(t); i < fibers_.size(); i += static_cast<std::size_t>(threads)) mine.push_back(fibers_[i]);

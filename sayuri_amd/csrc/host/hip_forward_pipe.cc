@@ -2,6 +2,7 @@
 #include "hip_forward_pipe.h"
 #include "fiber.h"
 
+#include <pthread.h>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -428,9 +429,9 @@ void HipForwardPipe::FinishBatch(Graph* g, Staging* s, int n) {
 void HipForwardPipe::Reopen(Graph* g, Staging* s) {
     s->ready.store(0, std::memory_order_relaxed);
     s->reserved.store(0, std::memory_order_release);  // re-open for callers
-    g->epoch.fetch_add(1, std::memory_order_release);
+    g->epoch.fetch_add(1, std::memory_order_seq_cst);
     FutexWakeAll(&g->epoch);
-    if (fibers_seen_.load(std::memory_order_relaxed)) sayuri_fiber::NotifyAll();  // fibers parked for a free staging set
+    if (epoch_parked_.load(std::memory_order_seq_cst) > 0) sayuri_fiber::NotifyAll();  // fibers parked for a free staging set (wake_callers)
 }
 
 // One persistent pump per GPU over a ring of staging sets.  Callers fill the set `fill` points at; when it holds
@@ -442,6 +443,7 @@ void HipForwardPipe::Reopen(Graph* g, Staging* s) {
 // happened the pump stops waiting until the fill set runs dry again (the adaptive 0 <-> base wait of
 // batch_forward_pipe.cc:99-193).
 void HipForwardPipe::PumpLoop(Graph* g) {
+    pthread_setname_np(pthread_self(), "sayuri-pump");
     using clock = std::chrono::steady_clock;
     constexpr int K = Graph::kSets;
     auto count = [](const Staging& s) { return s.reserved.load(std::memory_order_acquire) & ~Staging::kClosed; };
@@ -460,10 +462,12 @@ void HipForwardPipe::PumpLoop(Graph* g) {
 
     auto wake_callers = [&] {
         const auto t0 = clock::now();
-        g->epoch.fetch_add(1, std::memory_order_release);
+        g->epoch.fetch_add(1, std::memory_order_seq_cst);
         FutexWakeAll(&g->epoch);
         // fibers parked in Reserve() on the epoch word are woken by their scheduler threads, which may be asleep themselves
-        if (rotate_notify_ && fibers_seen_.load(std::memory_order_relaxed)) sayuri_fiber::NotifyAll();
+        // -- only when a fiber IS parked there (with four staging sets that is rare): a NotifyAll wakes every scheduler thread,
+        // and one per rotation was half of all wake-ups of a self-play rank (futex calls: 11 % of its host time)
+        if (rotate_notify_ && epoch_parked_.load(std::memory_order_seq_cst) > 0) sayuri_fiber::NotifyAll();
         pump_ns_[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0).count();
     };
     // close the fill set and point callers at the next one of the ring
@@ -658,8 +662,15 @@ HipForwardPipe::Ticket HipForwardPipe::Reserve(const InputData* input, const Pac
         }
         // both sets are taken (one on the GPU, one full or being rotated): sleep until the pump re-opens one
         if (!running_.load()) throw std::runtime_error("HipForwardPipe is shutting down");
-        if (fiber) sayuri_fiber::WaitWhileEqual(&g->epoch, epoch);  // let the thread's other games run meanwhile
-        else FutexWait(&g->epoch, epoch);
+        if (fiber) {
+            // let the thread's other games run meanwhile.  The count is raised BEFORE the word is looked at again (inside
+            // WaitWhileEqual) and the pump looks at the count AFTER it changed the word: one of the two sees the other.
+            epoch_parked_.fetch_add(1, std::memory_order_seq_cst);
+            sayuri_fiber::WaitWhileEqual(&g->epoch, epoch);
+            epoch_parked_.fetch_sub(1, std::memory_order_seq_cst);
+        } else {
+            FutexWait(&g->epoch, epoch);
+        }
     }
 }
 

@@ -189,6 +189,7 @@ private:
     // when do requests arrive relative to the last finished batch, how full are the batches and why were they closed
     bool trace_{false};
     bool rotate_notify_{true};  // SAYURI_AB_ROTATE_NOTIFY (measuring aid)
+    std::atomic<int> epoch_parked_{0};  // fibers suspended in Reserve() until a staging set re-opens
     std::atomic<long long> trace_last_done_ns_{0};
     std::atomic<long> trace_arrival_[32] = {};  // 250 us bins since the last finished batch
     std::atomic<long> trace_size_[17] = {};     // batch size / 16
