@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--games", type=int, default=4)
     ap.add_argument("--moves", type=int, default=330)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--kinds", default="3,2,1", help="3 = score + pass-alive, 2 = ladder map, 1 = packed encoding")
+    ap.add_argument("--from-move", type=int, default=0, help="time only positions from this move on")
     ap.add_argument("--repeat", type=int, default=5, help="each position is timed this many times, the fastest counts (shared hosts)")
     a = ap.parse_args()
     lib = _lib.host()
@@ -46,11 +48,13 @@ def main():
             if op != 0 or not lib.sayuri_go_play(h, mv, -1):
                 continue
             ph = next(i for i, (lo, hi) in enumerate(phases) if lo <= step < hi)
-            for kind in (3, 2, 1):
+            if step < a.from_move:
+                continue
+            for kind in [int(k) for k in a.kinds.split(",")]:
                 acc[(kind, ph)].append(min(lib.sayuri_go_encode_seconds(h, a.iters, kind, 0, 4) for _ in range(a.repeat)) / a.iters * 1e6)
         lib.sayuri_go_free(h)
     names = {3: "score + pass-alive", 2: "ladder map", 1: "packed encoding (areas cached)"}
-    for kind in (3, 2, 1):
+    for kind in [int(k) for k in a.kinds.split(",")]:
         row = "  ".join("moves %3d-%-4s %6.2f us" % (phases[ph][0], phases[ph][1] if phases[ph][1] < 10 ** 6 else "", float(np.mean(acc[(kind, ph)])))
                         for ph in range(len(phases)) if acc[(kind, ph)])
         print("%-32s %s   all %6.2f us" % (names[kind], row, float(np.mean(sum((acc[(kind, ph)] for ph in range(len(phases))), [])))))
