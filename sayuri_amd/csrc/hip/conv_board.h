@@ -152,6 +152,21 @@ template <int WMT_> struct BoardCfg {
     static constexpr size_t lds_bytes(int npos) { return ring_bytes(npos) <= 160 * 1024 ? 160 * 1024 : ring_bytes(npos); }
 };
 
+// Measuring builds only (tools/gpu/lds_streams.sh): -DSAYURI_DROP_STREAM=1 leaves out the K loop's A-fragment reads, =2 its
+// B-fragment reads (the MFMAs then multiply stale registers: wrong results, same instruction stream otherwise), so that the
+// LDS counters of the two streams can be told apart.
+#ifndef SAYURI_DROP_STREAM
+#define SAYURI_DROP_STREAM 0
+#endif
+template <int OFF> __device__ __forceinline__ void board_read_a(f16x8& dst, uint32_t addr) {
+    if constexpr (SAYURI_DROP_STREAM == 1) asm volatile("" : "+v"(dst) : "v"(addr));
+    else ds_read16<OFF>(dst, addr);
+}
+template <int OFF> __device__ __forceinline__ void board_read_b(f16x8& dst, uint32_t addr) {
+    if constexpr (SAYURI_DROP_STREAM == 2) asm volatile("" : "+v"(dst) : "v"(addr));
+    else ds_read16<OFF>(dst, addr);
+}
+
 namespace board_sched {
 // The fragment stream of one K group: MFMA block b = 12*dx + j (tap-in-row dx, column tile j) issues WMT MFMAs
 // with A(dx, 0..WMT-1) and B(b).  LDS reads in program order:
@@ -394,13 +409,17 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
                 }
             }
             const uint32_t abase = a_ring + (G & 1) * Cfg::A_BYTES + arow_off;
+#if SAYURI_DROP_STREAM
+            f16x8 afr[NA] = {}, bfr[3] = {};
+#else
             f16x8 afr[NA], bfr[3];
-            ds_read16<0>(bfr[0], bb[0]);
+#endif
+            board_read_b<0>(bfr[0], bb[0]);
             static_for<WMT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                ds_read16<i * 256>(afr[i], abase);
+                board_read_a<i * 256>(afr[i], abase);
             });
-            ds_read16<0>(bfr[1], bb[1]);
+            board_read_b<0>(bfr[1], bb[1]);
             static_for<kNB>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
                 constexpr int dx = b / NJ, j = b % NJ;
@@ -414,7 +433,7 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
                 }
                 if constexpr (b + 2 < kNB) {
                     constexpr int b2 = b + 2;
-                    ds_read16<16 * (b2 / NJ)>(bfr[b2 % 3], bb[b2 % NJ]);
+                    board_read_b<16 * (b2 / NJ)>(bfr[b2 % 3], bb[b2 % NJ]);
                 }
                 if constexpr (b == 0) wait_lgkm_all<young_b<WMT>(0), WMT>(afr, bfr[0]);
                 else if constexpr (j > 0) wait_lgkm1<young_b<WMT>(b)>(bfr[b % 3]);
@@ -428,7 +447,7 @@ __device__ __forceinline__ void board_mainloop(const BoardParams& bp, unsigned c
                         mma_tile<WMT, i, j>(acc[i][j], afr[i], bfr[b % 3]);
                     }
                     if constexpr (j == NJ - 1 && dx < 2)
-                        ds_read16<(dx + 1) * Cfg::A_TAP_BYTES + i * 256>(afr[i], abase);
+                        board_read_a<(dx + 1) * Cfg::A_TAP_BYTES + i * 256>(afr[i], abase);
                 });
             });
             // next kernel row: one halo row further; after the third row the other halo slot, two rows back
