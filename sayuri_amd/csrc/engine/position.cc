@@ -771,45 +771,6 @@ void Position::LinkGroups(const Labels& L, Groups& g) const {
     for (int k = 0; k < g.count; ++k) g.next[g.heads[k]] = last[k + 1];
 }
 
-bool Position::ChainPassAlive(int v, const bool* vital, const Groups& regions, const Groups& chains) const {
-    // Benson: a chain is unconditionally alive when at least two vital regions have all their empty points
-    // adjacent to it
-    const int me = chains.id[v];
-    int first = -1;
-    int p = v;
-    do {
-        for (int k = 0; k < 4; ++k) {
-            const int a = p + dir_[k];
-            if (!vital[a]) continue;
-            bool all_adjacent = true;
-            int r = a;
-            do {
-                if (cell_[r] == kEmpty) {
-                    bool adj = false;
-                    for (int kk = 0; kk < 4; ++kk) {
-                        if (chains.id[r + dir_[kk]] == me) {
-                            adj = true;
-                            break;
-                        }
-                    }
-                    if (!adj) {
-                        all_adjacent = false;
-                        break;
-                    }
-                }
-                r = regions.next[r];
-            } while (r != a);
-            if (all_adjacent) {
-                const int rid = regions.id[a];
-                if (first < 0) first = rid;
-                else if (rid != first) return true; // second distinct vital region
-            }
-        }
-        p = chains.next[p];
-    } while (p != v);
-    return false;
-}
-
 void Position::InnerRegions(int v, int c, const Groups& regions, bool* inner) const {
     // groups of the complement of this region that do not touch the edge are enclosed by it
     std::uint8_t surround[kMaxVertices];
@@ -944,88 +905,104 @@ void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_p
         for (int i = 0; i < points_ && free_points < 3; ++i) free_points += cell_[IndexToVertex(i)] != Opp(color);
         if (free_points >= 3 || !mark_pass_dead) return;
     }
+    // Benson's fixpoint over (region, chain) pairs instead of ring walks.  For every potentially vital region r and every
+    // `color` chain c that touches it (through an empty cell or through an enemy stone of r): near[r, c] = the empty cells of
+    // r next to c.  r is an eye of c when near[r, c] is ALL of r's empty cells; a chain with fewer than two eyes is dropped,
+    // and every region a dropped chain touches stops being vital.  Chains that fail are dropped together -- a chain below two
+    // eyes never gets one back, so the fixpoint is the one the one-at-a-time loop reaches (reference board.cc:1720-1901).
+    std::uint16_t root[kMaxPoints + 2], empties[kMaxPoints + 2];
+    for (int x = 1; x <= L.count; ++x) {
+        root[x] = L.parent[x] == x ? static_cast<std::uint16_t>(x) : root[L.parent[x]];
+        empties[x] = 0;
+    }
+    struct Pair { std::uint16_t r, c, near; };
+    Pair pairs[4 * kMaxPoints];
+    int npairs = 0;
+    constexpr int kSlots = 2048;  // open addressing over (r, c); <= 4 pairs per cell of a vital region
+    std::uint16_t slot_of[kSlots];
+    std::memset(slot_of, 0, sizeof(slot_of));
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        const int lb = L.lab[v];
+        if (!lb || spoilt[lb]) continue;
+        const int r = root[lb];
+        const bool empty = cell_[v] == kEmpty;
+        if (empty) empties[r]++;
+        int seen[4], ns = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int a = v + dir_[k];
+            if (cell_[a] != color) continue;
+            const int c = head_[a];
+            if (Contains(seen, ns, c)) continue;
+            seen[ns++] = c;
+            unsigned hpos = (static_cast<unsigned>(r) * 0x9e5u + static_cast<unsigned>(c) * 0x2bu) & (kSlots - 1);
+            for (;;) {
+                const int idx = slot_of[hpos];
+                if (idx == 0) {
+                    pairs[npairs] = Pair{static_cast<std::uint16_t>(r), static_cast<std::uint16_t>(c), static_cast<std::uint16_t>(empty ? 1 : 0)};
+                    slot_of[hpos] = static_cast<std::uint16_t>(++npairs);
+                    break;
+                }
+                Pair& pr = pairs[idx - 1];
+                if (pr.r == r && pr.c == c) {
+                    pr.near = static_cast<std::uint16_t>(pr.near + (empty ? 1 : 0));
+                    break;
+                }
+                hpos = (hpos + 1) & (kSlots - 1);
+            }
+        }
+    }
+    bool region_vital[kMaxPoints + 2];
+    for (int x = 1; x <= L.count; ++x) region_vital[x] = L.parent[x] == x && !spoilt[x];
+    std::uint8_t chain_state[kMaxVertices + 1];  // by head vertex: 0 = not a chain of `color`, 1 = alive so far, 2 = dropped
+    std::memset(chain_state, 0, sizeof(chain_state));
+    int alive_count = 0;
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        if (cell_[v] == color && head_[v] == v) {
+            chain_state[v] = 1;
+            ++alive_count;
+        }
+    }
+    std::uint8_t eyes[kMaxVertices + 1];
+    for (bool changed = alive_count > 0; changed;) {
+        changed = false;
+        std::memset(eyes, 0, sizeof(eyes));
+        for (int k = 0; k < npairs; ++k) {
+            const Pair& pr = pairs[k];
+            if (region_vital[pr.r] && pr.near == empties[pr.r] && eyes[pr.c] < 2) eyes[pr.c]++;
+        }
+        for (int i = 0; i < points_; ++i) {
+            const int v = IndexToVertex(i);
+            if (chain_state[v] == 1 && eyes[v] < 2) {
+                chain_state[v] = 2;
+                --alive_count;
+                changed = true;
+            }
+        }
+        if (changed)
+            for (int k = 0; k < npairs; ++k)
+                if (chain_state[pairs[k].c] == 2) region_vital[pairs[k].r] = false;
+    }
+
     std::uint8_t occ[kMaxVertices];
     std::memset(occ, kWall, sizeof(occ));
-    bool vital[kMaxVertices];
-    std::memset(vital, 0, sizeof(vital));
     for (int i = 0; i < points_; ++i) {
         const int v = IndexToVertex(i);
-        occ[v] = cell_[v] == color ? static_cast<std::uint8_t>(color) : static_cast<std::uint8_t>(kEmpty);
-        vital[v] = L.lab[v] != 0 && !spoilt[L.lab[v]];
-    }
-    Groups regions_store, chains_store;
-    Groups* const regions = &regions_store;
-    Groups* const chains = &chains_store;
-    LinkGroups(L, *regions);
-    const int region_count = regions->count;
-    std::uint16_t region_heads[kMaxPoints];
-    std::memcpy(region_heads, regions->heads, sizeof(region_heads[0]) * static_cast<size_t>(region_count));
-
-    // the chains of `color`: the board's own chain rings (ids = head vertex; which stone is the head and the order of the
-    // ring do not matter below -- Benson's fixpoint is the same whatever order the chains are tested and dropped in)
-    for (int v = 0; v < kMaxVertices; ++v) chains->id[v] = -1;
-    chains->count = 0;
-    for (int i = 0; i < points_; ++i) {
-        const int v = IndexToVertex(i);
+        std::uint8_t o = kEmpty;
         if (cell_[v] == color) {
-            chains->id[v] = static_cast<std::int16_t>(head_[v]);
-            chains->next[v] = next_[v];
-            if (head_[v] == v) chains->heads[chains->count++] = static_cast<std::uint16_t>(v);
-        } else {
-            chains->id[v] = 0;
+            if (chain_state[head_[v]] == 1) {
+                out[i] = true;
+                o = static_cast<std::uint8_t>(color);
+            }
+        } else if (mark_vitals && L.lab[v] && region_vital[root[L.lab[v]]]) {
+            out[i] = true;
+            o = static_cast<std::uint8_t>(color);
         }
+        occ[v] = o;
     }
-    int alive_count = chains->count;
-    for (bool changed = true; changed;) {
-        changed = false;
-        for (int i = 0; i < alive_count; ++i) {
-            const int h = chains->heads[i];
-            if (ChainPassAlive(h, vital, *regions, *chains)) continue;
-            // drop the chain; the regions it touches stop being vital
-            int p = h;
-            do {
-                chains->id[p] = 0;
-                occ[p] = kEmpty;
-                for (int k = 0; k < 4; ++k) {
-                    const int a = p + dir_[k];
-                    if (vital[a]) {
-                        int r = a;
-                        do {
-                            vital[r] = false;
-                            r = regions->next[r];
-                        } while (r != a);
-                    }
-                }
-                p = chains->next[p];
-            } while (p != h);
-            for (int j = i; j + 1 < alive_count; ++j) chains->heads[j] = chains->heads[j + 1];
-            alive_count -= 1;
-            changed = true;
-            break;
-        }
-    }
-
-    for (int i = 0; i < alive_count; ++i) {
-        const int h = chains->heads[i];
-        int p = h;
-        do {
-            out[VertexToIndex(p)] = true;
-            p = chains->next[p];
-        } while (p != h);
-    }
-    if (mark_vitals) {
-        for (int r = 0; r < region_count; ++r) {
-            const int h = region_heads[r];
-            int p = h;
-            do {
-                if (vital[p]) {
-                    out[VertexToIndex(p)] = true;
-                    occ[p] = static_cast<std::uint8_t>(color);
-                }
-                p = regions->next[p];
-            } while (p != h);
-        }
-    }
+    Groups regions_store;
+    Groups* const regions = &regions_store;
     if (mark_pass_dead) {
         bool all_empty = alive_count == 0;
         for (int i = 0; i < points_ && all_empty; ++i) all_empty = occ[IndexToVertex(i)] == kEmpty;
@@ -1034,6 +1011,7 @@ void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_p
             // empty all over -- the classification is one region holding every point (members ascending, each linking to
             // its predecessor, the lowest to the highest, as Classify links them)
             for (int v = 0; v < kMaxVertices; ++v) regions->id[v] = -1;
+            std::memset(regions->next, 0, sizeof(regions->next));
             int prev = -1, first = -1;
             for (int i = 0; i < points_; ++i) {
                 const int v = IndexToVertex(i);

@@ -139,7 +139,6 @@ private:
 
     struct Groups; // scratch for the region / chain classification of the Benson pass
     void Classify(int target, const std::uint8_t* feat, Groups& g) const;
-    bool ChainPassAlive(int v, const bool* vital, const Groups& regions, const Groups& chains) const;
     struct Labels; // provisional labels of the raster labelling pass behind Classify
     void LinkGroups(const Labels& labels, Groups& g) const;
     bool AtariEscapesAtOnce(int atari, int extend, int prey) const;

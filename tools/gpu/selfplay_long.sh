@@ -3,17 +3,17 @@
 # one generation); SHORT=1 adds 90 s at 2048 and 8192 games
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/sp
-SAYURI_MEMSTAT=1 timeout 1800 python tools/selfplay_bench.py --seconds 1620 --games 512 --num-games 100000 2> gpurun_out/sp/long.err | tail -1 > gpurun_out/sp/r03_selfplay_27min_512games.json
+SAYURI_MEMSTAT=1 timeout 1800 python tools/selfplay_bench.py --seconds 1620 --games 512 --num-games 100000 2> gpurun_out/sp/long.err | tail -1 > gpurun_out/sp/${TAG:-r04}_selfplay_27min_512games.json
 python -c "
 import json
-d=json.load(open('gpurun_out/sp/r03_selfplay_27min_512games.json'))
+d=json.load(open('gpurun_out/sp/${TAG:-r04}_selfplay_27min_512games.json'))
 print({k:d[k] for k in ('nn_evals_per_sec','games_done','games_per_hour','moves_per_sec','mean_batch','host_cpu_cores_busy','max_rss_gb','second_half')})"
 if [ -n "$SHORT" ]; then
 for g in 2048 8192; do
-  SAYURI_MEMSTAT=1 timeout 300 python tools/selfplay_bench.py --seconds 90 --games $g 2>gpurun_out/sp/g$g.err | tail -1 > gpurun_out/sp/r03_selfplay_g$g.json
+  SAYURI_MEMSTAT=1 timeout 300 python tools/selfplay_bench.py --seconds 90 --games $g 2>gpurun_out/sp/g$g.err | tail -1 > gpurun_out/sp/${TAG:-r04}_selfplay_g$g.json
   python -c "
 import json
-d=json.load(open('gpurun_out/sp/r03_selfplay_g$g.json'))
+d=json.load(open('gpurun_out/sp/${TAG:-r04}_selfplay_g$g.json'))
 print($g, {k:d[k] for k in ('nn_evals_per_sec','mean_batch','host_cpu_cores_busy','max_rss_gb','second_half')})"
 done
 fi
