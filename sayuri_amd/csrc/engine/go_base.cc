@@ -44,7 +44,9 @@ bool Rng::Chance(double prob) {
 }
 
 // ---------------------------------------------------------------------------------------------
-const ZobristKeys& ZobristKeys::Get() {
+std::atomic<const ZobristKeys*> ZobristKeys::ready_{nullptr};
+
+const ZobristKeys& ZobristKeys::Build() {
     static const ZobristKeys keys = [] {
         ZobristKeys k;
         Rng rng(0xabcdabcd12345678ULL);
@@ -64,6 +66,7 @@ const ZobristKeys& ZobristKeys::Get() {
         }
         return k;
     }();
+    ready_.store(&keys, std::memory_order_release);
     return keys;
 }
 

@@ -12,6 +12,7 @@
 //                                                  -- reference src/game/symmetry.cc:95-123
 #pragma once
 
+#include <atomic>
 #include <array>
 #include <cstdint>
 #include <cstddef>
@@ -75,7 +76,15 @@ struct ZobristKeys {
     std::uint64_t rule[2];
     std::uint64_t komi[kMaxVertices];
 
-    static const ZobristKeys& Get(); // built once, thread-safe
+    // built once, thread-safe; after that an inlined pointer read (stone placement asks for the table at every call)
+    static const ZobristKeys& Get() {
+        const ZobristKeys* k = ready_.load(std::memory_order_acquire);
+        return k ? *k : Build();
+    }
+
+private:
+    static const ZobristKeys& Build();
+    static std::atomic<const ZobristKeys*> ready_;
 };
 
 // ---------------------------------------------------------------------------------------------

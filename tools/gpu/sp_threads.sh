@@ -21,6 +21,7 @@ except Exception as e:
 PY
   grep -h "runs again:" gpurun_out/spth/$name.err | cut -c1-200
 }
+if [ -n "$SWEEP" ]; then for t in $SWEEP; do run t$t --game-threads $t; done; exit 0; fi
 run t64 --game-threads 64
 run t128 --game-threads 128
 run t256 --game-threads 256
