@@ -287,94 +287,64 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, f
     }
 }
 
-// kSeFcSamples samples per workgroup: the two FC images (0.7 MB for a 384-channel layer) are read once per workgroup, and with one
-// sample per workgroup that was 190 MB through L2 per launch -- the kernel's whole 27 us.  Every sample's sums are formed in the
-// order they had with one sample per workgroup (the weights of a row are loaded once and used by each sample in turn).
-constexpr int kSeFcSamples = 4;
-static inline size_t se_fc_lds(int C, int squeeze_out) { return sizeof(float) * ((size_t)kSeFcSamples * (3 * C + squeeze_out) + 256); }
 __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ part, float* __restrict__ gate,
                                                     BatchGeom g, int C, int cs, FcDev squeeze, FcDev excite, int act) {
-    constexpr int S = kSeFcSamples;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int so = squeeze.out;
-    float* pool = (float*)smem;             // [S][3C]
-    float* mid = pool + S * 3 * C;          // [S][se_size]
-    float* scratch = mid + S * so;          // [256]
-    const int n0 = blockIdx.x * S, tid = threadIdx.x;
-    const int ns = min(S, g.n_samples - n0);
-    for (int sm = 0; sm < ns; ++sm) {
-        const int n = n0 + sm;
-        const int bs = g.bsz[n];
-        const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
-        float* pl = pool + sm * 3 * C;
-        for (int c = tid; c < C; c += 256) {
-            float s = 0.f, m = -5000.f;
-            for (int sp = 0; sp < kSeSplit; ++sp) {
-                const float* src = part + ((size_t)(n * kSeSplit + sp) * 2) * cs;
-                s += src[c];
-                m = fmaxf(m, src[cs + c]);
-            }
-            const float mean = s / npix;
-            pl[c] = mean;
-            pl[C + c] = mean * (bd / 10.f);
-            pl[2 * C + c] = m;
+    float* pool = (float*)smem;          // [3C]
+    float* mid = pool + 3 * C;           // [se_size]
+    float* scratch = mid + squeeze.out;  // [256]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int bs = g.bsz[n];
+    const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f, m = -5000.f;
+        for (int sp = 0; sp < kSeSplit; ++sp) {
+            const float* src = part + ((size_t)(n * kSeSplit + sp) * 2) * cs;
+            s += src[c];
+            m = fmaxf(m, src[cs + c]);
         }
+        const float mean = s / npix;
+        pool[c] = mean;
+        pool[C + c] = mean * (bd / 10.f);
+        pool[2 * C + c] = m;
     }
     __syncthreads();
     // squeeze: 256 threads = (out/4 column quads) x (row groups); each thread streams 16-byte weight
     // loads (unrolled: 8 in flight), partial sums are folded through LDS
+    const int so = squeeze.out;
     if ((so & 3) == 0 && so <= 256) {
         const int quads = so / 4, groups = 256 / quads;
         const int oq = tid % quads, grp = tid / quads;
-        f32x4 s4[S];
-#pragma unroll
-        for (int sm = 0; sm < S; ++sm) s4[sm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
         if (grp < groups) {
             const float* w = squeeze.wt + oq * 4;
-#pragma unroll 4
-            for (int i = grp; i < squeeze.in; i += groups) {
-                const f32x4 w4 = *(const f32x4*)(w + (size_t)i * so);
-#pragma unroll
-                for (int sm = 0; sm < S; ++sm) s4[sm] += pool[sm * 3 * C + i] * w4;
-            }
+#pragma unroll 8
+            for (int i = grp; i < squeeze.in; i += groups) s4 += pool[i] * *(const f32x4*)(w + (size_t)i * so);
         }
-        __syncthreads();
-        float* red = scratch;  // [groups][so] would exceed 256 floats: fold in rounds of 256 floats, one sample after the other
-#pragma unroll
-        for (int sm = 0; sm < S; ++sm) {
-            if (sm >= ns) break;
-            float* md = mid + sm * so;
-            for (int g0 = 0; g0 < groups; g0 += 256 / so) {
-                if (grp >= g0 && grp < g0 + 256 / so) *(f32x4*)(red + (grp - g0) * so + oq * 4) = s4[sm];
-                __syncthreads();
-                if (tid < so) {
-                    float a = g0 == 0 ? squeeze.b[tid] : md[tid];
-                    for (int q = 0; q < 256 / so && g0 + q < groups; ++q) a += red[q * so + tid];
-                    md[tid] = a;
-                }
-                __syncthreads();
+        __syncthreads();  // pool no longer needed below this point except via s4
+        float* red = scratch;  // [groups][so] would exceed 256 floats: fold in rounds of 256 floats
+        for (int g0 = 0; g0 < groups; g0 += 256 / so) {
+            if (grp >= g0 && grp < g0 + 256 / so) *(f32x4*)(red + (grp - g0) * so + oq * 4) = s4;
+            __syncthreads();
+            if (tid < so) {
+                float a = g0 == 0 ? squeeze.b[tid] : mid[tid];
+                for (int q = 0; q < 256 / so && g0 + q < groups; ++q) a += red[q * so + tid];
+                mid[tid] = a;
             }
-            if (tid < so) md[tid] = activate(md[tid], act);
+            __syncthreads();
         }
+        if (tid < so) mid[tid] = activate(mid[tid], act);
     } else {
-        for (int sm = 0; sm < ns; ++sm) block_fc(squeeze, pool + sm * 3 * C, mid + sm * so, act, tid, 256);
+        block_fc(squeeze, pool, mid, act, tid, 256);
     }
     __syncthreads();
     for (int o = tid; o < excite.out; o += 256) {
-        float s[S];
-#pragma unroll
-        for (int sm = 0; sm < S; ++sm) s[sm] = excite.b[o];
+        float s = excite.b[o];
         const float* w = excite.wt + o;
-#pragma unroll 8
-        for (int i = 0; i < excite.in; ++i) {
-            const float wv = w[(size_t)i * excite.out];
-#pragma unroll
-            for (int sm = 0; sm < S; ++sm) s[sm] += mid[sm * so + i] * wv;
-        }
+#pragma unroll 16
+        for (int i = 0; i < excite.in; ++i) s += mid[i] * w[(size_t)i * excite.out];
         // gate[n][0][c] = sigmoid(gamma_c), gate[n][1][c] = beta_c; channel stride cs, pads stay 0
-#pragma unroll
-        for (int sm = 0; sm < S; ++sm)
-            if (sm < ns) gate[(size_t)(n0 + sm) * 2 * cs + (o < C ? o : cs + (o - C))] = o < C ? 1.0f / (1.0f + fast_exp(-s[sm])) : s[sm];
+        gate[(size_t)n * 2 * cs + (o < C ? o : cs + (o - C))] = o < C ? 1.0f / (1.0f + fast_exp(-s)) : s;
     }
 }
 
