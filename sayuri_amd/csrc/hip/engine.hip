@@ -1471,10 +1471,10 @@ private:
                                    d_separt_, g, cs);
             }))
             return -1;
-        const size_t smem = sizeof(float) * (3 * C + sq.out + 256);
+        const size_t smem = sizeof(float) * (3 * C + sq.out + kSeFcThreads);
         if (timed("se_fc", 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out),
                   4.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out), [&] {
-                      hipLaunchKernelGGL(se_fc_kernel, dim3(geom_.n), dim3(256), smem, stream_,
+                      hipLaunchKernelGGL(se_fc_kernel, dim3(geom_.n), dim3(kSeFcThreads), smem, stream_,
                                          (const float*)d_separt_, d_gate_, g, C, cs, sq.dev(), ex.dev(), act);
                   }))
             return -1;
@@ -2246,7 +2246,7 @@ static int test_se_unit_impl(int device, int n, const int* board_sizes, int max_
     if (!dx || (res && !dres) || !dw1 || !dw2 || !db1 || !db2 || !separt || !gate) return fail("test_se_unit: hipMalloc failed");
     const FcDev sq{dw1, db1, 3 * C, se}, ex{dw2, db2, se, 2 * C};
     hipLaunchKernelGGL(se_pool_kernel<T>, dim3(n * kSeSplit), dim3(256), 0, 0, (const T*)dx, separt, tg.g, cs);
-    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(256), sizeof(float) * (3 * C + se + 256), 0, (const float*)separt, gate, tg.g, C, cs, sq,
+    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(kSeFcThreads), sizeof(float) * (3 * C + se + kSeFcThreads), 0, (const float*)separt, gate, tg.g, C, cs, sq,
                        ex, act);
     const int ppr = cs / EPP;
     const dim3 grid((tg.slot * ppr + 256 * kScaleUnroll - 1) / (256 * kScaleUnroll), n);

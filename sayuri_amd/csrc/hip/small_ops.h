@@ -287,16 +287,21 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, f
     }
 }
 
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ part, float* __restrict__ gate,
+// kSeFcThreads threads per workgroup: the kernel is a chain of dependent L2 loads per thread (the squeeze FC's 3C rows split over the row
+// groups of the workgroup), so its time is the length of that chain -- 115 rows per thread with 256 threads (27 us for a 384-channel
+// layer), 28 with 1024.
+constexpr int kSeFcThreads = 1024;
+__global__ __launch_bounds__(kSeFcThreads) void se_fc_kernel(const float* __restrict__ part, float* __restrict__ gate,
                                                     BatchGeom g, int C, int cs, FcDev squeeze, FcDev excite, int act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* pool = (float*)smem;          // [3C]
     float* mid = pool + 3 * C;           // [se_size]
-    float* scratch = mid + squeeze.out;  // [256]
+    float* scratch = mid + squeeze.out;  // [NT]
+    constexpr int NT = kSeFcThreads;
     const int n = blockIdx.x, tid = threadIdx.x;
     const int bs = g.bsz[n];
     const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
         float s = 0.f, m = -5000.f;
         for (int sp = 0; sp < kSeSplit; ++sp) {
             const float* src = part + ((size_t)(n * kSeSplit + sp) * 2) * cs;
@@ -309,11 +314,11 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
         pool[2 * C + c] = m;
     }
     __syncthreads();
-    // squeeze: 256 threads = (out/4 column quads) x (row groups); each thread streams 16-byte weight
+    // squeeze: NT threads = (out/4 column quads) x (row groups); each thread streams 16-byte weight
     // loads (unrolled: 8 in flight), partial sums are folded through LDS
     const int so = squeeze.out;
     if ((so & 3) == 0 && so <= 256) {
-        const int quads = so / 4, groups = 256 / quads;
+        const int quads = so / 4, groups = NT / quads;
         const int oq = tid % quads, grp = tid / quads;
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
         if (grp < groups) {
@@ -322,23 +327,23 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
             for (int i = grp; i < squeeze.in; i += groups) s4 += pool[i] * *(const f32x4*)(w + (size_t)i * so);
         }
         __syncthreads();  // pool no longer needed below this point except via s4
-        float* red = scratch;  // [groups][so] would exceed 256 floats: fold in rounds of 256 floats
-        for (int g0 = 0; g0 < groups; g0 += 256 / so) {
-            if (grp >= g0 && grp < g0 + 256 / so) *(f32x4*)(red + (grp - g0) * so + oq * 4) = s4;
+        float* red = scratch;  // [groups][so] would exceed NT floats: fold in rounds of NT floats
+        for (int g0 = 0; g0 < groups; g0 += NT / so) {
+            if (grp < groups && grp >= g0 && grp < g0 + NT / so) *(f32x4*)(red + (grp - g0) * so + oq * 4) = s4;
             __syncthreads();
             if (tid < so) {
                 float a = g0 == 0 ? squeeze.b[tid] : mid[tid];
-                for (int q = 0; q < 256 / so && g0 + q < groups; ++q) a += red[q * so + tid];
+                for (int q = 0; q < NT / so && g0 + q < groups; ++q) a += red[q * so + tid];
                 mid[tid] = a;
             }
             __syncthreads();
         }
         if (tid < so) mid[tid] = activate(mid[tid], act);
     } else {
-        block_fc(squeeze, pool, mid, act, tid, 256);
+        block_fc(squeeze, pool, mid, act, tid, NT);
     }
     __syncthreads();
-    for (int o = tid; o < excite.out; o += 256) {
+    for (int o = tid; o < excite.out; o += NT) {
         float s = excite.b[o];
         const float* w = excite.wt + o;
 #pragma unroll 16
