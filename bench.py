@@ -294,6 +294,13 @@ def main():
     from sayuri_amd.pipe import HipForwardPipe
 
     lib = _lib.hip()
+    if os.environ.get("SAYURI_BENCH_SHARE_DEVICE"):
+        # TEST HOOK (tests/test_gpu_dropin.py): the ranks of a multi-rank launch share the devices that exist, so that this file's
+        # multi-rank path (barrier, max-over-ranks timing, stats gather, exchange rounds) runs against the real runtime on a
+        # one-GPU box.  The throughput of such a run means nothing.
+        device = local_rank % max(1, lib.sayuri_hip_device_count())
+    else:
+        device = local_rank
     spec = W.spec_20b256()
     # a directory of its own: the self-play loop watches it for newer networks (reference ShouldHalt, engine.cc:63-90)
     wdir = f"/tmp/sayuri_bench_weights_{os.getuid()}"
@@ -310,7 +317,7 @@ def main():
 
     fp16 = not args.fp32
     n = args.batch
-    pipe = HipForwardPipe(wpath, board_size=19, batch_size=n, fp16=fp16, device=local_rank)
+    pipe = HipForwardPipe(wpath, board_size=19, batch_size=n, fp16=fp16, device=device)
     ctx = pipe.ctx(0)
     planes = W.synthetic_planes(n, 19, seed=1000 + rank)
     grid = np.ascontiguousarray(np.stack(planes), np.float32)  # [n][43][361]

@@ -155,3 +155,29 @@ def test_selfplay_configs2_workload_keeps_full_batches(tmp_weights_dir, tmp_path
     lines = gzip.open(chunks[0]).read().decode().split("\n")
     assert (len(lines) - 1) % 53 == 0 and lines[1] == "0"   # version line, then the mode line of a 19x19 record
     pipe.Destroy()
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """bench.py's multi-rank path against the real runtime: the driver's command line for N = 2 (torch.distributed.run, one
+    process per rank), on gloo, the two ranks sharing this box's one GPU (SAYURI_BENCH_SHARE_DEVICE).  What is checked is
+    that the path runs -- barrier, max-over-ranks timing, the stats gather, the exchange rounds of the self-play window, ONE
+    JSON line from rank 0 -- not the throughput of two processes on one device (tests/test_dropin_cpu.py runs the same on the
+    fake device with N = 2; profiles/r04_fake8_bench.json with N = 8)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAYURI_BENCH_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--dist-backend", "gloo", "--selfplay-seconds", "10", "--selfplay-games", "64", "--selfplay-visits", "16"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    sp = d["selfplay"]
+    assert sp["exchange_rounds"] > 0 and sp["nn_evals_per_sec"] > 0 and not sp["halt_seen"]
+    assert "cpu_baseline" not in d
