@@ -328,6 +328,12 @@ int Position::ChainLiberties(int v, int* buf, int& n) const {
     const bool fresh = n == 0;
     int found = 0, p = v;
     do {
+        // (a stone whose neighbour counts show no empty point -- the inside of a chain -- is passed without looking around it;
+        // on the edge the wall counts as one, those stones are looked at as before)
+        if (((nbr_[p] >> kEmptyShift) & 0xf) == 0) {
+            p = next_[p];
+            continue;
+        }
         for (int k = 0; k < 4; ++k) {
             const int a = p + dir_[k];
             if (cell_[a] != kEmpty) continue;
@@ -344,11 +350,14 @@ int Position::ChainLiberties(int v, int* buf, int& n) const {
 
 int Position::CaptureGainLiberties(int v, int* buf, int& n) const {
     const int opp = Opp(cell_[v]);
+    const int opp_shift = opp == kBlack ? kBlackShift : kWhiteShift;
     int found = 0, p = v;
     do {
-        for (int k = 0; k < 4; ++k) {
-            const int a = p + dir_[k];
-            if (cell_[a] == opp && libs_[head_[a]] == 1) found += ChainLiberties(a, buf, n);
+        if (((nbr_[p] >> opp_shift) & 0xf) != 0) {  // (stones without an enemy neighbour are passed)
+            for (int k = 0; k < 4; ++k) {
+                const int a = p + dir_[k];
+                if (cell_[a] == opp && libs_[head_[a]] == 1) found += ChainLiberties(a, buf, n);
+            }
         }
         p = next_[p];
     } while (p != v);
@@ -879,11 +888,16 @@ void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_p
     std::memset(L.lab, 0, sizeof(L.lab));
     L.count = 0;
     std::uint8_t spoilt[kMaxPoints + 2];
+    std::uint16_t chain_head[kMaxPoints];  // the chains of `color`, by their head stones, in scan order
+    int nchains = 0;
     const int l = letter_;
     for (int i = 0; i < points_; ++i) {
         const int v = IndexToVertex(i);
         const int c = cell_[v];
-        if (c == color) continue;
+        if (c == color) {
+            if (head_[v] == v) chain_head[nchains++] = static_cast<std::uint16_t>(v);
+            continue;
+        }
         const int before = L.count;
         const int mine = L.Join(v, l);
         if (L.count != before) spoilt[mine] = 0;
@@ -954,28 +968,21 @@ void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_p
     }
     bool region_vital[kMaxPoints + 2];
     for (int x = 1; x <= L.count; ++x) region_vital[x] = L.parent[x] == x && !spoilt[x];
-    std::uint8_t chain_state[kMaxVertices + 1];  // by head vertex: 0 = not a chain of `color`, 1 = alive so far, 2 = dropped
-    std::memset(chain_state, 0, sizeof(chain_state));
-    int alive_count = 0;
-    for (int i = 0; i < points_; ++i) {
-        const int v = IndexToVertex(i);
-        if (cell_[v] == color && head_[v] == v) {
-            chain_state[v] = 1;
-            ++alive_count;
-        }
-    }
+    std::uint8_t chain_state[kMaxVertices + 1];  // by head vertex: 1 = alive so far, 2 = dropped (read for heads of `color` chains only)
     std::uint8_t eyes[kMaxVertices + 1];
+    for (int k = 0; k < nchains; ++k) chain_state[chain_head[k]] = 1;
+    int alive_count = nchains;
     for (bool changed = alive_count > 0; changed;) {
         changed = false;
-        std::memset(eyes, 0, sizeof(eyes));
+        for (int k = 0; k < nchains; ++k) eyes[chain_head[k]] = 0;
         for (int k = 0; k < npairs; ++k) {
             const Pair& pr = pairs[k];
             if (region_vital[pr.r] && pr.near == empties[pr.r] && eyes[pr.c] < 2) eyes[pr.c]++;
         }
-        for (int i = 0; i < points_; ++i) {
-            const int v = IndexToVertex(i);
-            if (chain_state[v] == 1 && eyes[v] < 2) {
-                chain_state[v] = 2;
+        for (int k = 0; k < nchains; ++k) {
+            const int h = chain_head[k];
+            if (chain_state[h] == 1 && eyes[h] < 2) {
+                chain_state[h] = 2;
                 --alive_count;
                 changed = true;
             }
