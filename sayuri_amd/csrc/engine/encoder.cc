@@ -160,37 +160,34 @@ void Encoder::Packed(const GameState& state, int symmetry, int weights_version, 
             int owner[kMaxPoints];
             bool safe[kMaxPoints];
             state.ScoreAndSafeAreaCached(owner, safe);
-            for (int i = 0; i < n; ++i) {
-                if (safe[i]) {
-                    if (owner[i] == me) mask[i] |= bit(plane);
-                    else if (owner[i] == you) mask[i] |= bit(plane + 1);
-                }
-                if (owner[i] == me) mask[i] |= bit(plane + 2);
-                else if (owner[i] == you) mask[i] |= bit(plane + 3);
-            }
+            std::uint64_t own_bits[4] = {0, 0, 0, 0}, safe_bits[4] = {0, 0, 0, 0};
+            own_bits[me] = bit(plane + 2);
+            own_bits[you] = bit(plane + 3);
+            safe_bits[me] = bit(plane);
+            safe_bits[you] = bit(plane + 1);
+            for (int i = 0; i < n; ++i) mask[i] |= own_bits[owner[i] & 3] | (safe[i] ? safe_bits[owner[i] & 3] : std::uint64_t{0});
         }
         plane += 4;
     }
-    for (int i = 0; i < n; ++i) {
-        const int v = b.IndexToVertex(i);
-        const int s = b.At(v);
-        if (s == kBlack || s == kWhite) {
-            const int l = b.Liberties(v);
-            if (l >= 1 && l <= 4) mask[i] |= bit(plane + l - 1);
+    // liberties (1-4 of a stone's chain) and ladder marks: one pass, table lookups instead of branches per cell
+    std::uint8_t marks[kMaxPoints];
+    b.LadderMap(marks);
+    {
+        const int lib_plane = plane, ladder_plane = plane + 4;
+        std::uint64_t by_libs[6] = {0, bit(lib_plane), bit(lib_plane + 1), bit(lib_plane + 2), bit(lib_plane + 3), 0};
+        std::uint64_t by_mark[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        by_mark[kLadderDeath] = bit(ladder_plane);
+        by_mark[kLadderEscapable] = bit(ladder_plane + 1);
+        by_mark[kLadderAtari] = bit(ladder_plane + 2);
+        by_mark[kLadderTake] = bit(ladder_plane + 3);
+        for (int i = 0; i < n; ++i) {
+            const int v = b.IndexToVertex(i);
+            const int s = b.At(v);
+            const int l = (s == kBlack || s == kWhite) ? std::min(b.Liberties(v), 5) : 0;
+            mask[i] |= by_libs[l] | by_mark[marks[i] & 7];
         }
     }
     plane += 4;
-    std::uint8_t marks[kMaxPoints];
-    b.LadderMap(marks);
-    for (int i = 0; i < n; ++i) {
-        switch (marks[i]) {
-            case kLadderDeath: mask[i] |= bit(plane); break;
-            case kLadderEscapable: mask[i] |= bit(plane + 1); break;
-            case kLadderAtari: mask[i] |= bit(plane + 2); break;
-            case kLadderTake: mask[i] |= bit(plane + 3); break;
-            default: break;
-        }
-    }
     // output cell d shows raw cell Index(symmetry, d)
     const SymmetryTables& t = SymmetryTables::Get();
     const int bs = state.GetBoardSize();
