@@ -549,13 +549,20 @@ public:
         // eight busy; profiles/r04_host_profile.txt), for the same evals/s.  The other ticket's stream overlaps its copies
         // with this one's kernels as before; a ticket's slot is free when its stream gets to the next use.
         const bool inorder = inorder_;
-        hipStream_t up = inorder ? stream_ : h2d_stream_, down = inorder ? stream_ : d2h_stream_;
+        // One exception: fp32 planes (62 KB per sample, 16 MB per batch).  On the ticket's own stream, behind kernels, the runtime
+        // moves them with a copy KERNEL, which cannot run beside the other ticket's persistent launch: the upload waited for that
+        // launch to end (72.1 -> 65.0 k evals/s through submit / wait; packed planes are 0.5 MB and do not show it).  They keep the
+        // upload stream and one event; the slot is free for them when the ticket's last completion event has fired, which the
+        // caller has normally seen already.
+        const bool big_upload = inorder && packed == nullptr;
+        hipStream_t up = inorder && !big_upload ? stream_ : h2d_stream_, down = inorder ? stream_ : d2h_stream_;
         if (!inorder) HIP_OK(hipStreamWaitEvent(h2d_stream_, fwd_done_[t], 0));  // the forward that last read this slot's inputs
+        else if (big_upload && tick_ev_[t]) HIP_OK(hipStreamWaitEvent(h2d_stream_, tick_ev_[t], 0));
         if (enqueue_inputs(n, planes, board_sizes, up, packed, binary)) return -1;
-        if (!inorder) {
+        if (!inorder || big_upload) {
             HIP_OK(hipEventRecord(h2d_done_[t], h2d_stream_));
             HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
-            if (tick_ev_[t]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t], 0));  // the download that last read this slot's outputs
+            if (!inorder && tick_ev_[t]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t], 0));  // the download that last read this slot's outputs
         }
         have_batch_ = true;
         if (fwdstat_) {  // SAYURI_HIP_FWDSTAT (measuring aid): device time of every submitted forward
