@@ -535,9 +535,8 @@ public:
     // asynchronous: H2D, graph, D2H enqueued on the stream, an event marks the end
     int submit(int n, const float* planes, const int* board_sizes, float* prob, float* pass, float* misc, float* own,
                int* ticket, const unsigned* packed = nullptr, int binary = 0) override {
-        // Three streams: uploads, the forward graph, downloads.  The planes of batch k+1 cross PCIe while batch k
-        // computes, and the results of batch k while batch k+1 computes; each of the two tickets owns its own device
-        // input / geometry / output buffers.
+        // The planes of batch k+1 cross PCIe while batch k computes, and the results of batch k while batch k+1 computes; each
+        // of the two tickets owns its own device input / geometry / output buffers (and, by default, its own stream: below).
         const int t = next_ticket_;
         next_ticket_ ^= 1;
         HIP_OK(hipSetDevice(device_));
