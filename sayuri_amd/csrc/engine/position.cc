@@ -584,6 +584,32 @@ int Position::ReachGroup(int start, int spread, bool* seen) const {
     return n;
 }
 
+// Provisional labels of a raster labelling pass: lab[v] (from 1; 0 = not a cell of the labelled kind, or off the board), and a
+// union-find forest over the labels in which a label's parent is always a smaller label.
+struct Position::Labels {
+    std::uint16_t lab[kMaxVertices];
+    std::uint16_t parent[kMaxPoints + 2];
+    int count;
+    // the label of the cell at v, given the labels above and to the left of it
+    int Join(int v, int letter) {
+        int a = lab[v - letter], b = lab[v - 1];
+        int mine;
+        if (a == 0 && b == 0) {
+            mine = ++count;
+            parent[mine] = static_cast<std::uint16_t>(mine);
+        } else if (a == 0 || b == 0 || a == b) {
+            mine = a ? a : b;
+        } else {
+            while (parent[a] != a) a = parent[a];
+            while (parent[b] != b) b = parent[b];
+            mine = a < b ? a : b;
+            parent[a < b ? b : a] = static_cast<std::uint16_t>(mine);
+        }
+        lab[v] = static_cast<std::uint16_t>(mine);
+        return mine;
+    }
+};
+
 void Position::ReachArea(int* out) const {
     // Tromp-Taylor: a point belongs to a colour when it is that colour or reaches only that colour through empties --
     // i.e. an empty region belongs to the one colour it borders (reference board.cc:1547-1579 does two breadth-first
@@ -670,12 +696,72 @@ void Position::ScoreArea(int* out, int scoring, const int* helper) const {
 }
 
 void Position::ScoreAndSafeArea(int* owner, bool* safe) const {
-    ReachArea(owner);
+    // ReachArea + PassAliveArea for both colours, with ONE pass over the board for their three labellings (the empty regions,
+    // the regions of non-black cells, the regions of non-white cells): once per evaluated position, and each labelling pass of its
+    // own was a loop of 361 hard-to-predict branches.  Same labels, same flags, same results as the three separate functions.
+    Labels E, NB, NW;  // empty regions | regions without black stones | regions without white stones
+    std::memset(E.lab, 0, sizeof(E.lab));
+    std::memset(NB.lab, 0, sizeof(NB.lab));
+    std::memset(NW.lab, 0, sizeof(NW.lab));
+    E.count = NB.count = NW.count = 0;
+    std::uint8_t touch[kMaxPoints + 2], spoilt_b[kMaxPoints + 2], spoilt_w[kMaxPoints + 2];
+    std::uint16_t heads_b[kMaxPoints], heads_w[kMaxPoints];
+    int nb = 0, nw = 0;
+    const int l = letter_;
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        const int c = cell_[v];
+        if (c == kBlack) {
+            if (head_[v] == v) heads_b[nb++] = static_cast<std::uint16_t>(v);
+            const int before = NW.count;
+            const int mine = NW.Join(v, l);
+            if (NW.count != before) spoilt_w[mine] = 0;
+        } else if (c == kWhite) {
+            if (head_[v] == v) heads_w[nw++] = static_cast<std::uint16_t>(v);
+            const int before = NB.count;
+            const int mine = NB.Join(v, l);
+            if (NB.count != before) spoilt_b[mine] = 0;
+        } else {
+            unsigned border = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int ca = cell_[v + dir_[k]];
+                if (ca == kBlack || ca == kWhite) border |= 1u << ca;
+            }
+            int before = E.count;
+            int mine = E.Join(v, l);
+            if (E.count != before) touch[mine] = 0;
+            touch[mine] |= static_cast<std::uint8_t>(border);
+            before = NB.count;
+            mine = NB.Join(v, l);
+            if (NB.count != before) spoilt_b[mine] = 0;
+            if (!(border & (1u << kBlack))) spoilt_b[mine] = 1;
+            before = NW.count;
+            mine = NW.Join(v, l);
+            if (NW.count != before) spoilt_w[mine] = 0;
+            if (!(border & (1u << kWhite))) spoilt_w[mine] = 1;
+        }
+    }
+    // Tromp-Taylor owner of the empty regions (ReachArea)
+    for (int x = E.count; x >= 1; --x)
+        if (E.parent[x] != x) touch[E.parent[x]] |= touch[x];
+    for (int x = 1; x <= E.count; ++x)
+        if (E.parent[x] != x) touch[x] = touch[E.parent[x]];
+    for (int i = 0; i < points_; ++i) {
+        const int v = IndexToVertex(i);
+        const int c = cell_[v];
+        if (c == kBlack || c == kWhite) {
+            owner[i] = c;
+        } else {
+            const unsigned border = touch[E.lab[v]];
+            owner[i] = border == (1u << kBlack) ? kBlack : border == (1u << kWhite) ? kWhite : kEmpty;
+        }
+    }
     std::memset(safe, 0, points_ * sizeof(bool));
     bool alive[kMaxPoints];
     for (int c = 0; c < 2; ++c) {
         std::memset(alive, 0, sizeof(alive));
-        PassAliveArea(alive, c, true, true);
+        if (c == kBlack) PassAliveFromLabels(alive, kBlack, true, true, NB, spoilt_b, heads_b, nb);
+        else PassAliveFromLabels(alive, kWhite, true, true, NW, spoilt_w, heads_w, nw);
         for (int i = 0; i < points_; ++i) {
             if (alive[i]) {
                 owner[i] = c;
@@ -709,32 +795,6 @@ struct Position::Groups {
     std::uint16_t next[kMaxVertices];
     std::uint16_t heads[kMaxPoints];
     int count;
-};
-
-// Provisional labels of a raster labelling pass: lab[v] (from 1; 0 = not a cell of the labelled kind, or off the board), and a
-// union-find forest over the labels in which a label's parent is always a smaller label.
-struct Position::Labels {
-    std::uint16_t lab[kMaxVertices];
-    std::uint16_t parent[kMaxPoints + 2];
-    int count;
-    // the label of the cell at v, given the labels above and to the left of it
-    int Join(int v, int letter) {
-        int a = lab[v - letter], b = lab[v - 1];
-        int mine;
-        if (a == 0 && b == 0) {
-            mine = ++count;
-            parent[mine] = static_cast<std::uint16_t>(mine);
-        } else if (a == 0 || b == 0 || a == b) {
-            mine = a ? a : b;
-        } else {
-            while (parent[a] != a) a = parent[a];
-            while (parent[b] != b) b = parent[b];
-            mine = a < b ? a : b;
-            parent[a < b ? b : a] = static_cast<std::uint16_t>(mine);
-        }
-        lab[v] = static_cast<std::uint16_t>(mine);
-        return mine;
-    }
 };
 
 void Position::Classify(int target, const std::uint8_t* feat, Groups& g) const {
@@ -903,6 +963,11 @@ void Position::PassAliveArea(bool* out, int color, bool mark_vitals, bool mark_p
         if (L.count != before) spoilt[mine] = 0;
         if (c == kEmpty && cell_[v - l] != color && cell_[v - 1] != color && cell_[v + 1] != color && cell_[v + l] != color) spoilt[mine] = 1;
     }
+    PassAliveFromLabels(out, color, mark_vitals, mark_pass_dead, L, spoilt, chain_head, nchains);
+}
+
+void Position::PassAliveFromLabels(bool* out, int color, bool mark_vitals, bool mark_pass_dead, const Labels& L, std::uint8_t* spoilt,
+                                   const std::uint16_t* chain_head, int nchains) const {
     // fold the flags towards the roots (a parent is a smaller label), then hand every label its root's
     bool any_vital = false;
     for (int x = L.count; x >= 1; --x)

@@ -141,6 +141,8 @@ private:
     void Classify(int target, const std::uint8_t* feat, Groups& g) const;
     struct Labels; // provisional labels of the raster labelling pass behind Classify
     void LinkGroups(const Labels& labels, Groups& g) const;
+    void PassAliveFromLabels(bool* out, int color, bool mark_vitals, bool mark_pass_dead, const Labels& L, std::uint8_t* spoilt,
+                             const std::uint16_t* chain_head, int nchains) const;
     bool AtariEscapesAtOnce(int atari, int extend, int prey) const;
     bool RegionPassDead(int v, int c, const std::uint8_t* feat, const Groups& regions) const;
     void InnerRegions(int v, int c, const Groups& regions, bool* inner) const;

@@ -113,7 +113,8 @@ def test_ko_and_superko():
 @pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref is only built in the dev container")
 @pytest.mark.parametrize("seed,board,komi,scoring,handicap,version",
                          [(101, 19, 7.5, 0, 0, 4), (102, 19, 5.5, 1, 3, 4), (103, 13, 7.5, 0, 0, 2), (104, 9, 7.0, 0, 0, 4),
-                          (105, 6, 4.0, 0, 0, 4), (106, 4, 2.0, 1, 0, 4), (107, 19, 7.5, 0, 0, 4), (108, 9, 6.0, 1, 0, 5)])
+                          (105, 6, 4.0, 0, 0, 4), (106, 4, 2.0, 1, 0, 4), (107, 19, 7.5, 0, 0, 4), (108, 9, 6.0, 1, 0, 5),
+                          (109, 19, 6.5, 1, 0, 4), (110, 19, 7.5, 0, 2, 3), (111, 13, 5.5, 1, 0, 4), (112, 19, 0.5, 0, 0, 5)])
 def test_live_against_reference(seed, board, komi, scoring, handicap, version):
     ref = GoApi(ctypes.CDLL(REF_SO), "ref_game_")
     a, b = Game(board, komi, scoring, api_=ref), Game(board, komi, scoring)
