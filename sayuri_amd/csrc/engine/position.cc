@@ -439,8 +439,10 @@ int Position::PreyTurn(Position& b, int hunter_move, int prey, int target, int& 
     int verdict = b.PreyCandidates(prey, target, sel, n, hunter_move != kNoVertex);
     if (verdict != kLadderOpen) return verdict;
     for (int i = 0; i < n; ++i) {
-        if (n == 1) {
-            verdict = HunterTurn(b, sel[i], prey, target, nodes); // forced line: continue in place
+        if (i == n - 1) {
+            // the last (or only) candidate continues in place: nobody looks at this board again -- the caller handed over
+            // either a fork of its own or, by this same rule, the board of ITS last candidate
+            verdict = HunterTurn(b, sel[i], prey, target, nodes);
         } else {
             auto fork = std::make_unique<Position>(b);
             verdict = HunterTurn(*fork, sel[i], prey, target, nodes);
@@ -457,8 +459,8 @@ int Position::HunterTurn(Position& b, int prey_move, int prey, int target, int& 
     int verdict = b.HunterCandidates(prey, target, sel, n);
     if (verdict != kLadderOpen) return verdict;
     for (int i = 0; i < n; ++i) {
-        if (n == 1) {
-            verdict = PreyTurn(b, sel[i], prey, target, nodes);
+        if (i == n - 1) {
+            verdict = PreyTurn(b, sel[i], prey, target, nodes);  // the last candidate in place (see PreyTurn)
         } else {
             auto fork = std::make_unique<Position>(b);
             verdict = PreyTurn(*fork, sel[i], prey, target, nodes);
