@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <vector>
 
 namespace sayuri_go {
 
@@ -432,6 +433,35 @@ int Position::HunterCandidates(int prey, int target, int* sel, int& n) const {
     return n == 0 ? kPreyWins : kLadderOpen;
 }
 
+namespace {
+// A board for one branch of the ladder reading.  The boards of a thread are recycled: a reading never leaves its thread (no
+// network call inside), and the allocator was visible in the profile of a self-play rank (a 5 KB malloc / free per fork).
+class ForkBoard {
+public:
+    explicit ForkBoard(const Position& src) {
+        auto& pool = Pool();
+        if (pool.empty()) {
+            p_ = std::make_unique<Position>(src);
+        } else {
+            p_ = std::move(pool.back());
+            pool.pop_back();
+            *p_ = src;
+        }
+    }
+    ~ForkBoard() { Pool().push_back(std::move(p_)); }
+    ForkBoard(const ForkBoard&) = delete;
+    ForkBoard& operator=(const ForkBoard&) = delete;
+    Position& operator*() { return *p_; }
+
+private:
+    static std::vector<std::unique_ptr<Position>>& Pool() {
+        static thread_local std::vector<std::unique_ptr<Position>> pool;
+        return pool;
+    }
+    std::unique_ptr<Position> p_;
+};
+}  // namespace
+
 int Position::PreyTurn(Position& b, int hunter_move, int prey, int target, int& nodes) const {
     if (++nodes >= kLadderNodeLimit) return kPreyWins;
     if (hunter_move != kNoVertex) b.Play(hunter_move, Opp(prey));
@@ -444,7 +474,7 @@ int Position::PreyTurn(Position& b, int hunter_move, int prey, int target, int& 
             // either a fork of its own or, by this same rule, the board of ITS last candidate
             verdict = HunterTurn(b, sel[i], prey, target, nodes);
         } else {
-            auto fork = std::make_unique<Position>(b);
+            ForkBoard fork(b);
             verdict = HunterTurn(*fork, sel[i], prey, target, nodes);
         }
         if (verdict == kPreyWins) break;
@@ -462,7 +492,7 @@ int Position::HunterTurn(Position& b, int prey_move, int prey, int target, int& 
         if (i == n - 1) {
             verdict = PreyTurn(b, sel[i], prey, target, nodes);  // the last candidate in place (see PreyTurn)
         } else {
-            auto fork = std::make_unique<Position>(b);
+            ForkBoard fork(b);
             verdict = PreyTurn(*fork, sel[i], prey, target, nodes);
         }
         if (verdict == kHunterWins) break;
