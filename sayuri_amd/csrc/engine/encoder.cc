@@ -133,18 +133,30 @@ void Encoder::Packed(const GameState& state, int symmetry, int weights_version, 
     out->komi = state.GetKomi();
 
     std::uint64_t mask[kMaxPoints];
-    std::fill(mask, mask + n, std::uint64_t{0});
     auto bit = [](int plane) { return std::uint64_t{1} << plane; };
     const int past = std::min(state.GetMoveNumber() + 1, kHistory);
-    for (int p = 0; p < past; ++p) {
-        const Frame& f = state.Past(p);
-        // (a table lookup per cell instead of two compares and branches: which cells hold stones is not predictable)
-        std::uint64_t by_color[4] = {0, 0, 0, 0};
-        by_color[me] = bit(3 * p);
-        by_color[you] = bit(3 * p + 1);
-        for (int i = 0; i < n; ++i) mask[i] |= by_color[f.stones[i] & 3];
-        const int lm = f.last_move;
-        if (lm != kNoVertex && lm != kPassMove && lm != kResignMove) mask[b.VertexToIndex(lm)] |= bit(3 * p + 2);
+    {
+        // history planes: per frame a table from the cell's colour to its plane bit (which cells hold stones is not predictable:
+        // no compares and branches), and ONE pass over the cells that reads the frames side by side and writes each mask once
+        const std::uint8_t* stones[kHistory];
+        std::uint64_t by_color[kHistory][4];
+        for (int p = 0; p < kHistory; ++p) {
+            stones[p] = state.Past(p < past ? p : 0).stones;
+            for (int c = 0; c < 4; ++c) by_color[p][c] = 0;
+            if (p < past) {
+                by_color[p][me] = bit(3 * p);
+                by_color[p][you] = bit(3 * p + 1);
+            }
+        }
+        static_assert(kHistory == 8, "the loop below is written out for eight frames");
+        for (int i = 0; i < n; ++i) {
+            mask[i] = by_color[0][stones[0][i] & 3] | by_color[1][stones[1][i] & 3] | by_color[2][stones[2][i] & 3] | by_color[3][stones[3][i] & 3] |
+                      by_color[4][stones[4][i] & 3] | by_color[5][stones[5][i] & 3] | by_color[6][stones[6][i] & 3] | by_color[7][stones[7][i] & 3];
+        }
+        for (int p = 0; p < past; ++p) {
+            const int lm = state.Past(p).last_move;
+            if (lm != kNoVertex && lm != kPassMove && lm != kResignMove) mask[b.VertexToIndex(lm)] |= bit(3 * p + 2);
+        }
     }
     int plane = 3 * kHistory;
     if (b.KoMove() != kNoVertex) mask[b.VertexToIndex(b.KoMove())] |= bit(plane);
