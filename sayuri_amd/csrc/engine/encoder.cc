@@ -1,5 +1,7 @@
 #include "encoder.h"
 
+#include <emmintrin.h>
+
 #include <algorithm>
 #include <cstring>
 
@@ -135,26 +137,39 @@ void Encoder::Packed(const GameState& state, int symmetry, int weights_version, 
     std::uint64_t mask[kMaxPoints];
     auto bit = [](int plane) { return std::uint64_t{1} << plane; };
     const int past = std::min(state.GetMoveNumber() + 1, kHistory);
+    std::fill(mask, mask + n, std::uint64_t{0});
     {
-        // history planes: per frame a table from the cell's colour to its plane bit (which cells hold stones is not predictable:
-        // no compares and branches), and ONE pass over the cells that reads the frames side by side and writes each mask once
-        const std::uint8_t* stones[kHistory];
-        std::uint64_t by_color[kHistory][4];
-        for (int p = 0; p < kHistory; ++p) {
-            stones[p] = state.Past(p < past ? p : 0).stones;
-            for (int c = 0; c < 4; ++c) by_color[p][c] = 0;
-            if (p < past) {
-                by_color[p][me] = bit(3 * p);
-                by_color[p][you] = bit(3 * p + 1);
-            }
-        }
-        static_assert(kHistory == 8, "the loop below is written out for eight frames");
-        for (int i = 0; i < n; ++i) {
-            mask[i] = by_color[0][stones[0][i] & 3] | by_color[1][stones[1][i] & 3] | by_color[2][stones[2][i] & 3] | by_color[3][stones[3][i] & 3] |
-                      by_color[4][stones[4][i] & 3] | by_color[5][stones[5][i] & 3] | by_color[6][stones[6][i] & 3] | by_color[7][stones[7][i] & 3];
-        }
+        // The 16 stone planes of the history hold most of the record's bits.  They do not go through the per-cell masks: a
+        // frame's stones, taken through the symmetry map once (output cell d shows raw cell Index(symmetry, d)), are compared
+        // with the colour 16 cells at a time and the compare mask IS the plane's next 16 bits (SSE2, part of x86-64).
+        const SymmetryTables& st = SymmetryTables::Get();
+        const int bs0 = state.GetBoardSize();
+        const bool ident = symmetry == SymmetryTables::kIdentity;
+        alignas(16) std::uint8_t turned[kMaxPoints + 16];
+        const __m128i vme = _mm_set1_epi8(static_cast<char>(me)), vyou = _mm_set1_epi8(static_cast<char>(you));
         for (int p = 0; p < past; ++p) {
-            const int lm = state.Past(p).last_move;
+            const Frame& f = state.Past(p);
+            const std::uint8_t* src = f.stones;  // (reading 16 bytes from the last chunk's start stays inside the Frame)
+            static_assert(sizeof(Frame) >= ((kMaxPoints + 15) / 16) * 16, "the last 16-byte chunk of a frame's stones must lie inside the frame");
+            if (!ident) {
+                for (int d = 0; d < n; ++d) turned[d] = f.stones[st.Index(bs0, symmetry, d)];
+                src = turned;
+            }
+            std::uint32_t* mine = out->bits[3 * p];
+            std::uint32_t* yours = out->bits[3 * p + 1];
+            for (int c16 = 0; c16 * 16 < n; ++c16) {
+                const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + c16 * 16));
+                std::uint32_t a = static_cast<std::uint32_t>(_mm_movemask_epi8(_mm_cmpeq_epi8(v, vme)));
+                std::uint32_t y = static_cast<std::uint32_t>(_mm_movemask_epi8(_mm_cmpeq_epi8(v, vyou)));
+                const int left = n - c16 * 16;
+                if (left < 16) {
+                    a &= (1u << left) - 1;
+                    y &= (1u << left) - 1;
+                }
+                mine[c16 >> 1] |= a << (16 * (c16 & 1));
+                yours[c16 >> 1] |= y << (16 * (c16 & 1));
+            }
+            const int lm = f.last_move;
             if (lm != kNoVertex && lm != kPassMove && lm != kResignMove) mask[b.VertexToIndex(lm)] |= bit(3 * p + 2);
         }
     }

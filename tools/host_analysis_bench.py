@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--kinds", default="3,2,1", help="3 = score + pass-alive, 2 = ladder map, 1 = packed encoding")
     ap.add_argument("--from-move", type=int, default=0, help="time only positions from this move on")
+    ap.add_argument("--symmetry", type=int, default=0, help="symmetry of the encodings (self-play draws one of 8 per evaluation)")
     ap.add_argument("--repeat", type=int, default=5, help="each position is timed this many times, the fastest counts (shared hosts)")
     a = ap.parse_args()
     lib = _lib.host()
@@ -51,7 +52,7 @@ def main():
             if step < a.from_move:
                 continue
             for kind in [int(k) for k in a.kinds.split(",")]:
-                acc[(kind, ph)].append(min(lib.sayuri_go_encode_seconds(h, a.iters, kind, 0, 4) for _ in range(a.repeat)) / a.iters * 1e6)
+                acc[(kind, ph)].append(min(lib.sayuri_go_encode_seconds(h, a.iters, kind, a.symmetry, 4) for _ in range(a.repeat)) / a.iters * 1e6)
         lib.sayuri_go_free(h)
     names = {3: "score + pass-alive", 2: "ladder map", 1: "packed encoding (areas cached)"}
     for kind in [int(k) for k in a.kinds.split(",")]:
