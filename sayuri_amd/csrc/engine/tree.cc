@@ -135,20 +135,20 @@ bool Node::ExpandChildren(Network& network, GameState& state, NodeEvals& evals, 
             plain = plain && p >= 0.0f && bits != 0x80000000u && list_buf[i].second >= 0 && list_buf[i].second < 65536;
             keys[i] = (static_cast<std::uint64_t>(bits) << 16) | static_cast<std::uint64_t>(list_buf[i].second & 0xffff);
         }
+        children_.reserve(list.size());
         if (plain) {
             std::sort(keys, keys + list_n, std::greater<std::uint64_t>());
-            for (int i = 0; i < list_n; ++i) {
+            for (int i = 0; i < list_n; ++i) {  // the edges straight from the sorted keys
                 const std::uint32_t bits = static_cast<std::uint32_t>(keys[i] >> 16);
                 float p;
                 std::memcpy(&p, &bits, sizeof(p));
-                list_buf[i] = std::make_pair(p, static_cast<int>(keys[i] & 0xffff));
+                children_.emplace_back(static_cast<int>(keys[i] & 0xffff), p);
             }
         } else {
             std::sort(list.begin(), list.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a > b; });
+            for (const auto& e : list) children_.emplace_back(e.second, e.first);
         }
     }
-    children_.reserve(list.size());
-    for (const auto& e : list) children_.emplace_back(e.second, e.first);
     expanded_ = true;
     return true;
 }
