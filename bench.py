@@ -268,7 +268,15 @@ def main():
                     help="skip configs[4] (40-block x 384 net, batch 256 of mixed 9/13/19 boards; single-GPU runs only; ~20 s: the "
                          "generated weights are cached under /tmp)")
     ap.add_argument("--selfplay-games", type=int, default=512, help="concurrent self-play games per GPU")
+    ap.add_argument("--selfplay-chunk-pool", type=int, default=16,
+                    help="finished games the data writer holds back in its shuffle pool (0 = the reference's rule: as many as "
+                         "there are concurrent games, which in a window of minutes puts all the writing behind the window)")
     ap.add_argument("--selfplay-visits", type=int, default=400)
+    ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("SAYURI_BENCH_FORCE_DIST")),
+                    help="initialise torch.distributed even for one rank (world size 1): the barrier, the stats all-gather and the "
+                         "periodic exchange of the self-play window then really go through RCCL on a one-GPU box (also "
+                         "SAYURI_BENCH_FORCE_DIST=1)")
+    ap.add_argument("--no-exchange", action="store_true", help="self-play window without the periodic exchange (A/B of its cost)")
     ap.add_argument("--dist-backend", default=os.environ.get("SAYURI_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend of the multi-rank run: nccl (= RCCL, the default) or gloo (CPU tests on the "
                          "fake device; also SAYURI_DIST_BACKEND)")
@@ -280,12 +288,17 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if args.force_dist and "RANK" not in os.environ:  # a plain `python bench.py --force-dist`: a world of one
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if args.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dev_index = local_rank % max(1, torch.cuda.device_count()) if os.environ.get("SAYURI_BENCH_SHARE_DEVICE") else local_rank
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=args.dist_backend)
 
@@ -376,6 +389,15 @@ def main():
                        random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
                        resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
                        selfplay_query=["bkp:19:7:1"], stagger_moves=args.selfplay_stagger, weights_dir=wdir, weights_file=wpath)
+        # The data writer is part of the reference's games/hour (SaveChunk + gzip, pipe.cc:116-159,181-233): every finished game's
+        # records go through StreamOut and gzip level 9 into tdata/ vdata/ sgf/ net_queries/ under a scratch directory, which is
+        # removed afterwards.  The reference holds `parallel_games` finished games back in its shuffle pool; in a window of minutes
+        # that would put all the writing behind the window, so the pool is cut to --selfplay-chunk-pool games here (the writer's
+        # steady state is one chunk out per finished game either way; the 27-minute profile keeps the reference's pool).
+        import shutil
+        import tempfile
+        sp_dir = tempfile.mkdtemp(prefix=f"sayuri_bench_selfplay_r{rank}_")
+        sp_opts.update(target_directory=sp_dir, chunk_pool_games=args.selfplay_chunk_pool)
         if dist is not None:
             dist.barrier()
         # the path's only exchange: every 2 s each rank contributes its counters and its halt wish (newer weights seen);
@@ -389,9 +411,17 @@ def main():
                     "elapsed": st["elapsed"]}
 
         st = S.selfplay(pipe, sp_opts, seconds=args.selfplay_seconds, name_suffix=f"-r{rank}",
-                        on_stats=lambda snap, halt: pg.tick(local_record(snap), halt=halt), stats_interval=2.0)
+                        on_stats=None if args.no_exchange else (lambda snap, halt: pg.tick(local_record(snap), halt=halt)),
+                        stats_interval=2.0)
         tot = pg.drain(local_record(st))
         fin = gather_stats({"games_done": st["finished_moves"], "moves": st["prerolled_moves"], "elapsed": st["elapsed"]})
+        # the writer's counters of all ranks, through the same record (the keys are only slots here)
+        wr = gather_stats({"games_done": st["chunks_saved"], "nn_queries": st["chunks_saved_window"], "nn_batches": st["bytes_written"],
+                           "cache_hits": st["text_bytes"], "moves": st["writer_cpu_seconds"] * 1e6,
+                           "playouts": st["writer_cpu_seconds_window"] * 1e6, "records": st["writer_flush_seconds"] * 1e6,
+                           "elapsed": st["elapsed"]})
+        files_on_disk = sum(len(fs) for _, _, fs in os.walk(sp_dir))
+        shutil.rmtree(sp_dir, ignore_errors=True)
         el = tot["elapsed_max"]
         games, finished_moves = int(tot["games_done"]), int(fin["games_done"])
         moves_per_sec = tot["moves"] / el
@@ -403,19 +433,33 @@ def main():
                     "seconds": round(el, 2), "nn_evals_per_sec": round(tot["nn_queries"] / el, 1),
                     "playouts_per_sec": round(tot["playouts"] / el, 1), "moves_per_sec": round(moves_per_sec, 2),
                     "games_done": games,
+                    # the reference's definition: games finished / wall (played_games_ over the run, src/selfplay/pipe.cc:272-280),
+                    # every one of them written out (chunks_saved).  The window's first generation starts at pre-rolled positions
+                    # (--selfplay-stagger), so over a window of minutes this is an upper bound of the long-run rate; the 27-minute
+                    # profiles (profiles/r05_selfplay_27min_*.json) measure it from the empty board
+                    "games_per_hour": round(games / el * 3600, 1) if games else None,
+                    "games_per_hour_definition": "finished games / wall over the window, chunks written inside it (reference "
+                                                 "pipe.cc:272-280); the first generation of games starts at pre-rolled positions, see "
+                                                 "games_per_hour_from_move_rate for the figure that does not depend on the pre-roll",
                     # the steady-state rate: searched moves per second / moves a finished game had (independent of where the
                     # pre-rolled openings put the games of the first generation)
-                    "games_per_hour": round(moves_per_sec * 3600 / mean_len, 1) if mean_len else None,
-                    "games_per_hour_definition": "moves_per_sec * 3600 / mean_moves_per_finished_game (steady-state move rate); the "
-                                                 "reference's finished-games / wall (pipe.cc:272-280) over this window is "
-                                                 "games_per_hour_prerolled_window",
+                    "games_per_hour_from_move_rate": round(moves_per_sec * 3600 / mean_len, 1) if mean_len else None,
                     "mean_moves_per_finished_game": round(mean_len, 1) if mean_len else None,
-                    # games that FINISHED inside the window / wall (reference definition, src/selfplay/pipe.cc:272-280, but the
-                    # window's games started at pre-rolled positions: an upper bound, kept for continuity with round 2)
-                    "games_per_hour_prerolled_window": round(games / el * 3600, 1) if games else None,
                     "prerolled_moves": int(fin["moves"]),
+                    # the data writer: one gzip'ed tdata + vdata chunk and one SGF line per finished game
+                    "chunks_saved": int(wr["games_done"]), "chunks_saved_in_window": int(wr["nn_queries"]),
+                    "chunk_pool_games": args.selfplay_chunk_pool,
+                    "records_written": int(tot["records"]),
+                    "bytes_written": int(wr["nn_batches"]), "record_text_bytes": int(wr["cache_hits"]),
+                    "files_on_disk": files_on_disk,
+                    "writer_cpu_seconds": round(wr["moves"] / 1e6, 3), "writer_cpu_seconds_in_window": round(wr["playouts"] / 1e6, 3),
+                    "writer_cores_in_window": round(wr["playouts"] / 1e6 / el / world, 4),
+                    "writer_flush_seconds_after_window": round(wr["records"] / 1e6 / world, 3),
                     "mean_batch": round(tot["nn_queries"] / max(tot["nn_batches"], 1), 1),
                     "exchange_rounds": pg.rounds, "halt_seen": bool(pg.any_halt),
+                    # the path's one collective: issue -> landed per round, on the self-play loop's calling thread, beside the
+                    # persistent tower launches of the two batches in flight (sayuri_amd/shard.py)
+                    "exchange": pg.latency_summary(),
                     "frac_of_microbench_evals": None}
 
     result = None

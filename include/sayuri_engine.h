@@ -99,8 +99,12 @@ int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options
  * own halt wish -- 1 once the newest file in the option weights_dir is no longer weights_file (reference
  * Engine::ShouldHalt, src/selfplay/engine.cc:88-90).  A non-zero return makes the loop wind down as the reference
  * does (src/selfplay/pipe.cc:246-258: max games = games in flight + 25, rounded up to 25).  stats (and the hook's
- * stats10) have TWELVE slots here: the ten of sayuri_selfplay_run, [9] = the final max-games value, [10] = sum of the
- * move numbers of the finished games, [11] = policy-sampled moves played by the stagger_moves option.  The driver all-gathers the records inside the hook (sayuri_amd/shard.py). */
+ * stats10) have TWENTY slots here: the ten of sayuri_selfplay_run, [9] = the final max-games value, [10] = sum of the
+ * move numbers of the finished games, [11] = policy-sampled moves played by the stagger_moves option; the data writer
+ * (reference SaveChunk + gzip, pipe.cc:116-159,181-233): [12] = chunks on disk when the window ended ([8] counts the
+ * flush of the writer's pool behind it too), [13] = CPU nanoseconds of the writer thread, [14] = the same when the
+ * window ended, [15] = bytes written to disk, [16] = bytes of record text before gzip, [17] = wall nanoseconds of the
+ * final flush, [18..19] = 0.  The driver all-gathers the records inside the hook (sayuri_amd/shard.py). */
 typedef int (*sayuri_selfplay_stats_fn)(const uint64_t* stats10, double elapsed, int local_halt, void* user);
 int sayuri_selfplay_run_ex(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
                            int move_cap, sayuri_selfplay_stats_fn on_stats, void* user, double interval_seconds,

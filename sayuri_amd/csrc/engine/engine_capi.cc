@@ -171,10 +171,13 @@ void sayuri_engine_search_update_territory_helper(void* s) { static_cast<Search*
 static thread_local std::string g_engine_err;
 const char* sayuri_engine_last_error() { return g_engine_err.c_str(); }
 namespace {
-void PackStats(const SelfplayStats& st, std::uint64_t* v) {  // the 12 slots of sayuri_selfplay_run_ex
-    const std::uint64_t a[12] = {st.games_started, st.games_done, st.moves, st.playouts, st.nn_queries,
-                                 st.cache_lookups, st.cache_hits, st.records, st.chunks_saved, 0,
-                                 st.finished_moves, st.prerolled_moves};
+constexpr int kStatSlots = 20;
+void PackStats(const SelfplayStats& st, std::uint64_t* v) {  // the 20 slots of sayuri_selfplay_run_ex
+    const std::uint64_t a[kStatSlots] = {st.games_started, st.games_done, st.moves, st.playouts, st.nn_queries,
+                                         st.cache_lookups, st.cache_hits, st.records, st.chunks_saved, 0,
+                                         st.finished_moves, st.prerolled_moves,
+                                         st.chunks_saved_window, st.writer_cpu_ns, st.writer_cpu_ns_window, st.bytes_written,
+                                         st.text_bytes, st.flush_ns, 0, 0};
     std::memcpy(v, a, sizeof(a));
 }
 struct StatsHook {
@@ -183,7 +186,7 @@ struct StatsHook {
 };
 int StatsTrampoline(const SelfplayStats* st, int local_halt, void* user) {
     const StatsHook* h = static_cast<const StatsHook*>(user);
-    std::uint64_t v[12];
+    std::uint64_t v[kStatSlots];
     PackStats(*st, v);
     return h->fn(v, st->elapsed, local_halt, h->user);
 }
@@ -214,7 +217,7 @@ int sayuri_selfplay_run_ex(void* raw_pipe, int weights_version, const char* opti
 
 int sayuri_selfplay_run(void* raw_pipe, int weights_version, const char* options, const char* name_suffix, double seconds,
                         int move_cap, std::uint64_t* stats, double* elapsed) {
-    std::uint64_t v[12];
+    std::uint64_t v[kStatSlots];
     const int rc = sayuri_selfplay_run_ex(raw_pipe, weights_version, options, name_suffix, seconds, move_cap, nullptr, nullptr, 0.0, v, elapsed);
     if (rc == 0) std::memcpy(stats, v, sizeof(std::uint64_t) * 10);
     return rc;

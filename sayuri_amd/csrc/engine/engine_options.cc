@@ -96,6 +96,7 @@ void EngineOptions::Parse(const std::string& text) {
         else if (k == "weights_file") selfplay.weights_file = v;
         OPT_INT("stagger_moves", selfplay.stagger_moves);
         OPT_INT("game_threads", selfplay.game_threads);
+        OPT_INT("chunk_pool_games", selfplay.chunk_pool_games);
         else if (k == "seed") selfplay.seed = std::stoull(v);
         else throw std::invalid_argument("unknown engine option: " + k);
 #undef OPT_INT

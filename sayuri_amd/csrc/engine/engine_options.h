@@ -34,6 +34,12 @@ struct SelfplayOptions {
     // extension: how the concurrent games are scheduled (selfplay.cc): 0 = fibers on a few threads per usable core from 256
     // games on, one OS thread per game below; N > 0 = fibers on N threads; -1 = always one thread per game
     int game_threads{0};
+    // extension (measurement only): how many finished games the data writer holds back while the workers run.  0 = the
+    // reference's rule, `parallel_games` (pipe.cc:206-208: chunks leave in shuffled order out of a pool that large, so the
+    // first `parallel_games` finished games are written only when as many more have finished or the run ends).  A short
+    // measuring window sets it small, so that the writer's steady state -- one chunk out per finished game, what hours of
+    // self-play see -- falls inside the window instead of behind it.
+    int chunk_pool_games{0};
 };
 
 struct EngineOptions {

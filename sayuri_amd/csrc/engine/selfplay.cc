@@ -357,15 +357,17 @@ SelfplayPipe::SelfplayPipe(std::shared_ptr<NetworkForwardPipe> pipe, int weights
     }
 }
 
-namespace {
-bool WriteGzip(const std::string& name, const std::string& text) {
-    gzFile f = gzopen((name + ".gz").c_str(), "wb9");
+bool SelfplayPipe::WriteGzip(const std::string& name, const std::string& text) {
+    const std::string path = name + ".gz";
+    gzFile f = gzopen(path.c_str(), "wb9");
     if (!f) return false;
     const int n = text.empty() ? 0 : gzwrite(f, text.data(), static_cast<unsigned>(text.size()));
     gzclose(f);
+    struct stat sb;
+    if (::stat(path.c_str(), &sb) == 0) bytes_written_.fetch_add(static_cast<std::uint64_t>(sb.st_size), std::memory_order_relaxed);
+    text_bytes_.fetch_add(text.size(), std::memory_order_relaxed);
     return text.empty() || n > 0;
 }
-} // namespace
 
 bool SelfplayPipe::SaveChunk(int id, float vdata_prob, std::vector<TrainingData>& chunk, Rng& rng) {
     std::ostringstream tdata, vdata;
@@ -384,11 +386,13 @@ bool SelfplayPipe::SaveChunk(int id, float vdata_prob, std::vector<TrainingData>
 void SelfplayPipe::SaveSgf(const std::string& sgf) {
     std::ofstream f(sgf_dir_ + "/" + hash_ + ".sgf", std::ios_base::app);
     if (f.is_open()) f << sgf << std::endl;
+    bytes_written_.fetch_add(sgf.size() + 1, std::memory_order_relaxed);
 }
 
 void SelfplayPipe::SaveNetQueries(int games, const std::string& text) {
     std::ofstream f(queries_dir_ + "/" + hash_ + ".txt", std::ios_base::app);
     if (f.is_open()) f << games << " " << text << std::endl;
+    bytes_written_.fetch_add(text.size() + 8, std::memory_order_relaxed);
 }
 
 void SelfplayPipe::WriterLoop() {
@@ -399,8 +403,15 @@ void SelfplayPipe::WriterLoop() {
     const int games = engine_.GetParallelGames();
     Rng rng(opt_.selfplay.seed ^ 0x5eedf00dULL);
     std::vector<std::shared_ptr<DataSgf>> pool;
+    const int pool_games = opt_.selfplay.chunk_pool_games > 0 ? std::min(opt_.selfplay.chunk_pool_games, games) : games;
+    auto publish_cpu = [this]() {
+        struct timespec ts;
+        if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0)
+            writer_cpu_ns_.store(static_cast<std::uint64_t>(ts.tv_sec) * 1000000000ull + static_cast<std::uint64_t>(ts.tv_nsec), std::memory_order_relaxed);
+    };
     bool keep = true;
     while (keep) {
+        publish_cpu();
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
         keep = writer_running_.load(std::memory_order_relaxed);
         std::deque<std::pair<int, std::string>> queries;
@@ -413,7 +424,41 @@ void SelfplayPipe::WriterLoop() {
             }
             queries.swap(queries_queue_);
         }
-        const size_t hold = writer_running_.load(std::memory_order_relaxed) ? static_cast<size_t>(games) : 1;
+        const bool running = writer_running_.load(std::memory_order_relaxed);
+        const size_t hold = running ? static_cast<size_t>(pool_games) : 1;
+        if (!running && pool.size() > 8 && !opt_.selfplay.target_directory.empty()) {
+            // The run is over and the pool is flushed (pipe.cc:206-208 drops the hold to 1): hundreds of games at gzip level 9,
+            // 0.15 s each.  Every chunk is a file of its own, so the flush goes over a few threads -- ids, the shuffle and the
+            // tdata / vdata split of every game are drawn here, in order, from the one generator; the SGF lines follow in id order.
+            std::shuffle(pool.begin(), pool.end(), rng);
+            struct Job { std::shared_ptr<DataSgf> item; int id; std::uint64_t seed; bool ok; };
+            std::vector<Job> jobs;
+            int id = static_cast<int>(chunks_.load());
+            while (!pool.empty()) {
+                jobs.push_back(Job{pool.back(), id++, rng.Next(), false});
+                pool.pop_back();
+            }
+            std::atomic<size_t> next{0};
+            const unsigned nthreads = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> helpers;
+            std::atomic<std::uint64_t> helper_cpu_ns{0};
+            auto work = [&]() {
+                for (size_t k = next.fetch_add(1); k < jobs.size(); k = next.fetch_add(1)) {
+                    Rng local(jobs[k].seed);
+                    jobs[k].ok = SaveChunk(jobs[k].id, kValidationRatio, jobs[k].item->first, local);
+                }
+                struct timespec ts;
+                if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0)
+                    helper_cpu_ns.fetch_add(static_cast<std::uint64_t>(ts.tv_sec) * 1000000000ull + static_cast<std::uint64_t>(ts.tv_nsec));
+            };
+            for (unsigned t = 0; t < nthreads; ++t) helpers.emplace_back(work);
+            for (auto& h : helpers) h.join();
+            for (auto& j : jobs) {
+                if (j.ok) chunks_.fetch_add(1);
+                SaveSgf(j.item->second);
+            }
+            flush_helper_cpu_ns_ = helper_cpu_ns.load();
+        }
         while (pool.size() >= hold && !pool.empty()) {
             std::shuffle(pool.begin(), pool.end(), rng);
             auto item = pool.back();
@@ -421,6 +466,7 @@ void SelfplayPipe::WriterLoop() {
             if (!opt_.selfplay.target_directory.empty()) {
                 if (SaveChunk(static_cast<int>(chunks_.load()), kValidationRatio, item->first, rng)) chunks_.fetch_add(1);
                 SaveSgf(item->second);
+                publish_cpu();
             } else {
                 for (auto& d : item->first)
                     if (!d.discard) records_.fetch_add(1, std::memory_order_relaxed);
@@ -429,6 +475,7 @@ void SelfplayPipe::WriterLoop() {
         if (!opt_.selfplay.target_directory.empty())
             for (auto& q : queries) SaveNetQueries(q.first, q.second);
     }
+    publish_cpu();
 }
 
 void SelfplayPipe::WindDown() {
@@ -618,6 +665,8 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
         st.cache_hits = engine_.network().cache().hits();
         st.finished_moves = finished_moves_.load();
         st.prerolled_moves = prerolled_moves_.load();
+        st.chunks_saved_window = chunks_.load();
+        st.writer_cpu_ns_window = writer_cpu_ns_.load();
         st.elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     };
     SelfplayStats st;
@@ -659,8 +708,13 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                      games, slabs / 1048576.0, biggest / 1048576.0, live, mi.uordblks / 1048576.0, mi.fordblks / 1048576.0, mi.hblkhd / 1048576.0);
     }
     if (!timed_out) snapshot(st);
+    const auto flush0 = std::chrono::steady_clock::now();
     writer_running_.store(false);
     writer.join();
+    st.flush_ns = static_cast<std::uint64_t>(std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - flush0).count());
+    st.writer_cpu_ns = writer_cpu_ns_.load() + flush_helper_cpu_ns_;
+    st.bytes_written = bytes_written_.load();
+    st.text_bytes = text_bytes_.load();
     if (!error_.empty()) throw std::runtime_error("self-play worker failed: " + error_);
     st.records = records_.load();
     st.chunks_saved = chunks_.load();

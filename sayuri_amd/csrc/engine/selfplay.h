@@ -26,6 +26,13 @@ struct SelfplayStats {
     std::uint64_t nn_queries{0}, cache_lookups{0}, cache_hits{0}, records{0}, chunks_saved{0};
     std::uint64_t finished_moves{0};   // sum of the move numbers of the finished games (their full length)
     std::uint64_t prerolled_moves{0};  // policy-sampled moves played by the stagger_moves option (not searched, not recorded)
+    // the data writer (pipe.cc:116-159,181-233).  `*_window` = as of the moment the time window ended (or the last game
+    // finished); the others include the flush of the writer's pool behind it
+    std::uint64_t chunks_saved_window{0};
+    std::uint64_t writer_cpu_ns{0}, writer_cpu_ns_window{0};  // CPU time of the writer thread (CLOCK_THREAD_CPUTIME_ID)
+    std::uint64_t bytes_written{0};    // on disk: the gzip'ed tdata / vdata chunks, the SGF and net-queries lines
+    std::uint64_t text_bytes{0};       // the records' text before gzip
+    std::uint64_t flush_ns{0};         // wall time from the workers' end until the writer has emptied its pool
     double elapsed{0};
 };
 
@@ -97,6 +104,7 @@ private:
     using DataSgf = std::pair<std::vector<TrainingData>, std::string>;
     void WriterLoop();
     bool SaveChunk(int id, float vdata_prob, std::vector<TrainingData>& chunk, Rng& rng);
+    bool WriteGzip(const std::string& name, const std::string& text);
     void SaveSgf(const std::string& sgf);
     void SaveNetQueries(int games, const std::string& text);
 
@@ -110,6 +118,8 @@ private:
     std::atomic<int> accumulation_games_{0}, played_games_{0};
     std::atomic<bool> stop_{false};
     std::atomic<std::uint64_t> records_{0}, chunks_{0}, finished_moves_{0}, prerolled_moves_{0};
+    std::atomic<std::uint64_t> writer_cpu_ns_{0}, bytes_written_{0}, text_bytes_{0};
+    std::uint64_t flush_helper_cpu_ns_{0};   // CPU time of the threads that share the final flush of the writer's pool
     std::atomic<int> max_games_{0};
     std::atomic<bool> halt_wish_{false};     // set by worker 0 (ShouldHalt) or by the stats callback's verdict
     void WindDown();                         // pipe.cc:248-254

@@ -175,13 +175,14 @@ def selfplay(pipe=None, options: dict | None = None, seconds: float = 0.0, move_
     if pipe is not None:
         raw = h.sayuri_pipe_raw(pipe._h)
         version = h.sayuri_pipe_weights_version(pipe._h)
-    stats, el = np.zeros(12, np.uint64), ctypes.c_double(0)
+    stats, el = np.zeros(20, np.uint64), ctypes.c_double(0)
     failure = []
 
     def hook(st, elapsed, local_halt, _user):
         try:
             snap = {k: int(st[i]) for i, k in enumerate(STAT_NAMES)}
             snap["finished_moves"], snap["prerolled_moves"] = int(st[10]), int(st[11])
+            snap["chunks_saved_window"], snap["writer_cpu_seconds"] = int(st[12]), st[14] / 1e9
             snap["elapsed"] = float(elapsed)
             return 1 if on_stats(snap, bool(local_halt)) else 0
         except BaseException as e:  # an exception must not unwind through the C frames
@@ -199,6 +200,11 @@ def selfplay(pipe=None, options: dict | None = None, seconds: float = 0.0, move_
     out = {k: int(stats[i]) for i, k in enumerate(STAT_NAMES)}
     out["max_games"] = int(stats[9])
     out["finished_moves"], out["prerolled_moves"] = int(stats[10]), int(stats[11])
+    # the data writer (csrc/engine/selfplay.cc WriterLoop): `_window` = when the time window ended, the others after the
+    # final flush of its pool
+    out["chunks_saved_window"] = int(stats[12])
+    out["writer_cpu_seconds"], out["writer_cpu_seconds_window"] = stats[13] / 1e9, stats[14] / 1e9
+    out["bytes_written"], out["text_bytes"], out["writer_flush_seconds"] = int(stats[15]), int(stats[16]), stats[17] / 1e9
     out["elapsed"] = el.value
     return out
 

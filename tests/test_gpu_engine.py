@@ -181,3 +181,33 @@ def test_bench_two_ranks_share_the_gpu():
     sp = d["selfplay"]
     assert sp["exchange_rounds"] > 0 and sp["nn_evals_per_sec"] > 0 and not sp["halt_seen"]
     assert "cpu_baseline" not in d
+
+
+def test_bench_exchange_over_rccl_beside_the_persistent_launch():
+    """The path's one collective on the backend the 8-GPU run uses: bench.py with torch.distributed initialised on "nccl"
+    (= RCCL) for a world of one, so that the start / stop barriers, the stats all-gather and the periodic exchange of the
+    self-play window go through RCCL kernels and small copies on a torch stream WHILE the two tickets' persistent tower
+    launches hold every CU of the device.  The exchange must land every round, without holding the
+    window up, and the writer must have put every finished game on disk."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--force-dist", "--dist-backend", "nccl",
+           "--selfplay-seconds", "30", "--no-cpu-baseline", "--no-config5", "--no-pump"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    sp = d["selfplay"]
+    ex = sp["exchange"]
+    print("exchange over RCCL beside the tower launches:", ex, "self-play evals/s", sp["nn_evals_per_sec"], "microbench", d["value"])
+    assert ex["backend"] == "nccl" and ex["world"] == 1
+    assert sp["exchange_rounds"] >= 10 and ex["rounds"] == sp["exchange_rounds"]      # a round every 2 s of a 30 s window
+    assert ex["late_rounds"] == 0 and ex["skipped_ticks"] == 0 and ex["max_ms"] < 1000.0, ex
+    assert sp["mean_batch"] > 200 and sp["nn_evals_per_sec"] > 0.85 * d["value"], sp
+    assert sp["games_done"] > 0 and sp["chunks_saved"] == sp["games_done"] and sp["bytes_written"] > 0, sp

@@ -111,6 +111,10 @@ def test_selfplay_pipe_dummy_backend(tmp_path):
     assert (len(lines) - 1) % 53 == 0 and lines[0] == "2" and lines[1] == "0"
     sgf = open(glob.glob(str(tmp_path / "sgf" / "*.sgf"))[0]).read()
     assert sgf.count("(;GM[1]FF[4]") == 8 and "RE[" in sgf
+    # the writer's own account (selfplay.cc WriterLoop): bytes on disk = the files', CPU time of its thread, nothing left in the pool
+    on_disk = sum(os.path.getsize(f) for f in glob.glob(str(tmp_path / "*" / "*-r0" / "game_*.txt.gz")))
+    assert 0 < on_disk <= st["bytes_written"] <= on_disk + 40000 and st["text_bytes"] > 5 * on_disk
+    assert st["writer_cpu_seconds"] > 0 and st["chunks_saved_window"] <= st["chunks_saved"]
     # A seed fixes a game only when nothing is shared between concurrently running games: the games of one pipe share the
     # NN result cache (network.cc Insert / Lookup), and with the dummy backend + random symmetry whichever game inserts a
     # position first decides what the others read.  So the reproducibility claim is for ONE game at a time; parallel
@@ -144,6 +148,32 @@ def test_training_chunks_parse_with_reference_reader(tmp_path):
         assert d.board_size == 9 and d.planes.shape == (37, 81) and abs(float(np.sum(d.prob)) - 1.0) < 1e-3
         assert len(d.ownership) == 81 and d.result in (-1, 0, 1) and d.to_move in (0, 1)
     assert count == text.count("\n") // 53 and count > 10
+
+
+def test_writer_pool_and_parallel_flush(tmp_path):
+    """The data writer holds `parallel_games` finished games back while the workers run (reference pipe.cc:206-208) unless
+    chunk_pool_games says otherwise, and flushes what is left over several threads when the run ends: every finished game
+    ends up as one tdata + one vdata chunk with distinct ids and one SGF record, whichever way it left."""
+    import glob
+    import gzip
+    base = dict(playouts=4, parallel_games=12, num_games=36, seed=11, selfplay_query=["bkp:7:7:1"], first_pass_bonus=1)
+    totals = {}
+    for name, extra in (("ref_pool", {}), ("small_pool", dict(chunk_pool_games=2))):
+        d = tmp_path / name
+        d.mkdir()
+        st = S.selfplay(None, dict(base, target_directory=str(d), **extra), move_cap=40)
+        assert st["games_done"] == st["chunks_saved"] >= 36, st
+        t = sorted(glob.glob(str(d / "tdata" / "*" / "game_*.txt.gz")))
+        v = sorted(glob.glob(str(d / "vdata" / "*" / "game_*.txt.gz")))
+        assert len(t) == len(v) == st["chunks_saved"]
+        ids = sorted(int(os.path.basename(f)[5:-7]) for f in t)
+        assert ids == list(range(st["chunks_saved"]))
+        recs = sum(gzip.open(f).read().count(b"\n") for f in t + v)
+        assert recs == 53 * st["records"]
+        assert open(glob.glob(str(d / "sgf" / "*.sgf"))[0]).read().count("(;GM[1]") == st["chunks_saved"]
+        totals[name] = st
+    # with the reference's pool the first 12 finished games wait for 12 more; the small pool writes as the games finish
+    assert totals["small_pool"]["chunks_saved_window"] >= totals["ref_pool"]["chunks_saved_window"]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -31,7 +31,12 @@ def main():
     ap.add_argument("--move-cap", type=int, default=0)
     ap.add_argument("--waittime", type=int, default=2)
     ap.add_argument("--fp32", action="store_true")
-    ap.add_argument("--out", default="")
+    ap.add_argument("--out", default="", help="target directory of the chunks (tdata/ vdata/ sgf/ net_queries/); default: a scratch "
+                                              "directory under /tmp that is removed afterwards")
+    ap.add_argument("--no-writer", action="store_true", help="no target directory: finished games are counted and dropped (the writer's "
+                                                             "SaveChunk + gzip is NOT in the measurement then)")
+    ap.add_argument("--chunk-pool", type=int, default=0, help="finished games held back in the writer's shuffle pool (0 = the reference's "
+                                                              "rule: as many as there are concurrent games)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--game-threads", type=int, default=0, help="0 = one OS thread per game up to 1024 games, fibers above; N = fibers on N threads; -1 = threads")
     ap.add_argument("--stagger", type=int, default=0, help="game g of the first generation starts after g * N / games policy-sampled moves (0: all from the empty board)")
@@ -46,13 +51,18 @@ def main():
     wpath = f"/tmp/sayuri_selfplay_{args.net}_{os.getuid()}.bin"
     if not os.path.exists(wpath):
         W.write_weights(wpath, spec, seed=22)
+    import shutil
+    import tempfile
+    scratch = None
+    if not args.out and not args.no_writer:
+        scratch = args.out = tempfile.mkdtemp(prefix="sayuri_selfplay_chunks_")
     pipe = HipForwardPipe(wpath, board_size=args.board, batch_size=args.batch, fp16=not args.fp32, waittime_ms=args.waittime)
     opts = dict(playouts=args.playouts, parallel_games=args.games, num_games=max(args.num_games, args.games), seed=args.seed,
                 dirichlet_noise=1, dirichlet_epsilon=0.25, dirichlet_init=0.03, dirichlet_factor=361, first_pass_bonus=1,
                 random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
                 resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
                 selfplay_query=([f"bkp:{b}:7:1" for b in args.boards.split(",")] if args.boards else [f"bkp:{args.board}:7:1"]),
-                target_directory=args.out, game_threads=args.game_threads, stagger_moves=args.stagger)
+                target_directory=args.out, game_threads=args.game_threads, stagger_moves=args.stagger, chunk_pool_games=args.chunk_pool)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.time()
@@ -64,6 +74,11 @@ def main():
     pt = pipe.pump_times()
     el = st["elapsed"]
     out = dict(st)
+    if args.out:
+        out["files_on_disk"] = sum(len(fs) for _, _, fs in os.walk(args.out))
+        out["writer_cores_in_window"] = round(st["writer_cpu_seconds_window"] / el, 4)
+    if scratch:
+        shutil.rmtree(scratch, ignore_errors=True)
     out.update(net=args.net, board=args.board, concurrent_games=args.games, playouts_per_move=args.playouts,
                nn_evals_per_sec=round(st["nn_queries"] / el, 1), playouts_per_sec=round(st["playouts"] / el, 1),
                moves_per_sec=round(st["moves"] / el, 2), games_per_hour=round(st["games_done"] / el * 3600, 1),
