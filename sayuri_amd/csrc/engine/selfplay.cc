@@ -617,11 +617,15 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
                     break;
                 }
                 search.UpdateTerritoryHelper();
-                finished_moves_.fetch_add(static_cast<std::uint64_t>(engine_.state(g).GetMoveNumber()));
                 engine_.GatherTrainingData(item->first, g);
                 item->second = engine_.GatherSgfString(g);
-                const int played = played_games_.fetch_add(1) + 1;
+                // a game is counted and handed to the writer in one step under the lock the window's end is taken under (Run):
+                // what finishes after the window has closed is dropped like a game in progress, so that the games counted, the
+                // moves counted for them and the chunks on disk are the same set
                 std::lock_guard<std::mutex> lock(data_mu_);
+                if (window_closed_) break;
+                finished_moves_.fetch_add(static_cast<std::uint64_t>(engine_.state(g).GetMoveNumber()));
+                const int played = played_games_.fetch_add(1) + 1;
                 data_queue_.push_back(item);
                 queries_queue_.emplace_back(played, std::string("hip ") + std::to_string(engine_.network().GetNumQueries()));
             }
@@ -689,6 +693,8 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
         if (seconds > 0 && played_games_.load() < max_games_.load() && !stop_.load()) {
+            std::lock_guard<std::mutex> lock(data_mu_);
+            window_closed_ = true;
             snapshot(st); // the window ends here: what the workers do while winding down is not counted
             timed_out = true;
         }

@@ -119,6 +119,7 @@ private:
     std::atomic<bool> stop_{false};
     std::atomic<std::uint64_t> records_{0}, chunks_{0}, finished_moves_{0}, prerolled_moves_{0};
     std::atomic<std::uint64_t> writer_cpu_ns_{0}, bytes_written_{0}, text_bytes_{0};
+    bool window_closed_{false};              // under data_mu_: the time window has ended, finished games are no longer taken
     std::uint64_t flush_helper_cpu_ns_{0};   // CPU time of the threads that share the final flush of the writer's pool
     std::atomic<int> max_games_{0};
     std::atomic<bool> halt_wish_{false};     // set by worker 0 (ShouldHalt) or by the stats callback's verdict

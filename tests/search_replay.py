@@ -44,6 +44,8 @@ NN_GAMES = [
     (11, 9, 7.0, 0, dict(playouts=24, dirichlet_noise=1, first_pass_bonus=1), 10),
     (12, 9, 7.0, 0, dict(playouts=24, gumbel=1, gumbel_playouts_threshold=16), 8),
     (13, 13, 6.5, 0, dict(playouts=16, early_symm_cache=1), 6),
+    # BASELINE.json configs[0] at its stated size: 9x9, 6b x 96 net, the CPU pipe, one thread, 100 visits per move
+    (14, 9, 7.0, 0, dict(playouts=100), 10),
 ]
 
 

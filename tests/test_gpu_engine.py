@@ -211,3 +211,17 @@ def test_bench_exchange_over_rccl_beside_the_persistent_launch():
     assert ex["late_rounds"] == 0 and ex["skipped_ticks"] == 0 and ex["max_ms"] < 1000.0, ex
     assert sp["mean_batch"] > 200 and sp["nn_evals_per_sec"] > 0.85 * d["value"], sp
     assert sp["games_done"] > 0 and sp["chunks_saved"] == sp["games_done"] and sp["bytes_written"] > 0, sp
+
+
+def test_configs0_game_at_its_stated_size_fp32(golden, w6b96):
+    """BASELINE.json configs[0] at the size it states -- 9x9, 6b x 96 network, 100 visits per move, one playout at a time --
+    played by the reference search on the reference's CPU pipe (tests/golden/make_golden_search.py, NN_GAMES[3]); the product
+    search on the fp32 HIP pipe must choose the same ten moves and write the same records."""
+    seed, board, komi, scoring, opts, nmoves = NN_GAMES[3]
+    assert opts["playouts"] == 100 and board == 9
+    pipe = HipForwardPipe(w6b96, board_size=board, batch_size=8, fp16=False, waittime_ms=0)
+    net = S.Network(pipe=pipe, options=options(opts))
+    moves, text, racy = play(net, seed, board, komi, scoring, opts, nmoves)
+    assert moves == golden["nn3_moves"].tolist()
+    assert records_close(zlib.decompress(golden["nn3_records"].tobytes()), text, rel=2e-3, abs_=2e-4, racy_records=racy) is None
+    pipe.Destroy()
