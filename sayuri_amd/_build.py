@@ -64,6 +64,22 @@ def _files(d: str, exts):
     return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
 
 
+_TOOLCHAIN = None
+
+
+def _toolchain() -> str:
+    """What `hipcc --version` says (and where ROCm is): part of every digest of a device-side output.  tower_seam.py
+    depends on the exact register assignment hipcc produced; a stamped library must not survive a ROCm upgrade."""
+    global _TOOLCHAIN
+    if _TOOLCHAIN is None:
+        try:
+            v = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=120).stdout
+        except Exception as e:  # noqa: BLE001
+            v = "hipcc --version failed: %r" % (e,)
+        _TOOLCHAIN = v.strip() + "|" + os.environ.get("ROCM_PATH", "")
+    return _TOOLCHAIN
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -91,9 +107,61 @@ def _seam_options():
             ["--align=" + os.environ.get("SAYURI_TOWER_ALIGN", "8"), "--pad=" + os.environ.get("SAYURI_TOWER_PAD", "32")])
 
 
+def _write_blob(objdir: str, hsaco: str | None, verbose: bool = False) -> str:
+    """tower_blob.o: the code object as the byte array `sayuri_tower_hsaco` + its length `sayuri_tower_hsaco_size`.
+    hsaco = None writes the EMPTY blob (size 0): libsayuri_hip.so then carries no persistent tower kernel, the engine says so
+    once at creation and runs one launch per layer (engine.hip: load_tower_module, tower_ok)."""
+    stub, blob = os.path.join(objdir, "tower_blob.S"), os.path.join(objdir, "tower_blob.o")
+    with open(stub, "w") as f:
+        f.write('\t.section .rodata\n\t.globl sayuri_tower_hsaco\n\t.type sayuri_tower_hsaco,@object\n\t.balign 4096\n'
+                'sayuri_tower_hsaco:\n' +
+                ('\t.incbin "%s"\n' % os.path.basename(hsaco) if hsaco else '\t.quad 0\n') +
+                '.Lsayuri_tower_hsaco_end:\n\t.size sayuri_tower_hsaco, .-sayuri_tower_hsaco\n'
+                '\t.globl sayuri_tower_hsaco_size\n\t.type sayuri_tower_hsaco_size,@object\n\t.balign 8\n'
+                'sayuri_tower_hsaco_size:\n\t.quad ' + ('.Lsayuri_tower_hsaco_end - sayuri_tower_hsaco' if hsaco else '0') + '\n'
+                '\t.size sayuri_tower_hsaco_size, 8\n'
+                '\t.section .note.GNU-stack,"",@progbits\n')
+    cmd = ["gcc", "-c", os.path.basename(stub), "-o", os.path.basename(blob)]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd, cwd=objdir)  # .incbin is looked up relative to the working directory: no absolute path in the stub
+    return blob
+
+
+def tower_blob_from_asm(asm: str, objdir: str, verbose: bool = False):
+    """hipcc's assembly of tower.hip -> (tower_blob.o, seamed).  tower_seam.py closes the layer loop in it and checks, line by
+    line, that the assembly looks like what it was written against (anchors, clobber ranges, the FC body's registers: it
+    depends on hipcc's register assignment, validated on ROCm 7.2's hipcc).  When it REJECTS the assembly -- another compiler
+    version moved an anchor -- the build goes on without the persistent kernel: the empty blob is linked, the engine reports
+    the fallback at creation and runs the same convolutions one launch per layer (tower_ok() is false).  SAYURI_TOWER_REQUIRED=1
+    turns the rejection back into a build failure (development)."""
+    seam = os.path.join(HIP_SRC, "tower_seam.py")
+    seamed = os.path.join(objdir, "tower_seamed.s")
+    elf, hsaco = os.path.join(objdir, "tower_dev.o"), os.path.join(objdir, "tower.hsaco")
+    cmd = [sys.executable, seam, asm, seamed] + _seam_options()
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        msg = (r.stderr or r.stdout).strip().splitlines()[-1:] or ["(no message)"]
+        if os.environ.get("SAYURI_TOWER_REQUIRED"):
+            raise RuntimeError("tower_seam.py rejected the compiler's assembly: " + msg[0])
+        print("[sayuri build] WARNING: tower_seam.py rejected hipcc's assembly of tower.hip (%s).\n"
+              "[sayuri build]          libsayuri_hip.so is built WITHOUT the persistent tower kernel; the engine will run one launch "
+              "per layer.\n[sayuri build]          The seam is validated on ROCm 7.2's hipcc; SAYURI_TOWER_REQUIRED=1 makes this an error."
+              % msg[0], file=sys.stderr)
+        return _write_blob(objdir, None, verbose), False
+    for cmd in ([os.path.join(_llvm_bin(), "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", seamed, "-o", elf],
+                [os.path.join(_llvm_bin(), "ld.lld"), "-shared", elf, "-o", hsaco]):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return _write_blob(objdir, hsaco, verbose), True
+
+
 def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
-    """The persistent tower kernels (csrc/hip/conv_tower.h): tower.hip -> gfx950 assembly -> tower_seam.py closes the
-    layer loop in it -> code object -> a host object that carries it as the byte array `sayuri_tower_hsaco`."""
+    """The persistent tower kernels (csrc/hip/conv_tower.h): tower.hip -> gfx950 assembly -> tower_seam.py closes the layer
+    loop in it -> code object -> a host object that carries it as the byte array `sayuri_tower_hsaco`."""
     objdir = os.path.join(LIB, "obj")
     os.makedirs(objdir, exist_ok=True)
     blob = os.path.join(objdir, "tower_blob.o")
@@ -103,30 +171,17 @@ def build_tower_blob(force: bool = False, verbose: bool = False) -> str:
     hip_flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-w"]
     if os.environ.get("SAYURI_EXPERIMENTS"):
         hip_flags.insert(0, "-DSAYURI_EXPERIMENTS")
-    digest = _stale(blob, srcs, hip_flags + _seam_options())
+    extra = hip_flags + _seam_options() + [_toolchain(), "required" if os.environ.get("SAYURI_TOWER_REQUIRED") else ""]
+    digest = _stale(blob, srcs, extra)
     if not (force or digest):
         return blob
-    digest = digest or _digest(srcs, hip_flags + _seam_options())
-    asm, seamed = os.path.join(objdir, "tower.s"), os.path.join(objdir, "tower_seamed.s")
-    elf, hsaco, stub = os.path.join(objdir, "tower_dev.o"), os.path.join(objdir, "tower.hsaco"), os.path.join(objdir, "tower_blob.S")
-    cmds = [
-        [_hipcc()] + hip_flags + [os.path.join(HIP_SRC, "tower.hip"), "-o", asm],
-        [sys.executable, seam, asm, seamed] + _seam_options(),
-        [os.path.join(_llvm_bin(), "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", seamed, "-o", elf],
-        [os.path.join(_llvm_bin(), "ld.lld"), "-shared", elf, "-o", hsaco],
-    ]
-    for cmd in cmds:
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-    with open(stub, "w") as f:
-        f.write('\t.section .rodata\n\t.globl sayuri_tower_hsaco\n\t.type sayuri_tower_hsaco,@object\n\t.balign 4096\n'
-                'sayuri_tower_hsaco:\n\t.incbin "%s"\n\t.size sayuri_tower_hsaco, .-sayuri_tower_hsaco\n'
-                '\t.section .note.GNU-stack,"",@progbits\n' % os.path.basename(hsaco))
-    cmd = ["gcc", "-c", os.path.basename(stub), "-o", os.path.basename(blob)]
+    digest = digest or _digest(srcs, extra)
+    asm = os.path.join(objdir, "tower.s")
+    cmd = [_hipcc()] + hip_flags + [os.path.join(HIP_SRC, "tower.hip"), "-o", asm]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd, cwd=objdir)  # .incbin is looked up relative to the working directory: no absolute path in the stub
+    subprocess.check_call(cmd)
+    tower_blob_from_asm(asm, objdir, verbose)
     _stamp(blob, digest)
     return blob
 
@@ -137,9 +192,10 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w"]
     if os.environ.get("SAYURI_EXPERIMENTS"):  # in-kernel timelines and forced variants (measuring builds only)
         flags.insert(0, "-DSAYURI_EXPERIMENTS")
-    digest = _stale(HIP_SO, srcs, flags + _seam_options())
+    extra = flags + _seam_options() + [_toolchain()]
+    digest = _stale(HIP_SO, srcs, extra)
     if force or digest:
-        digest = digest or _digest(srcs, flags + _seam_options())
+        digest = digest or _digest(srcs, extra)
         blob = build_tower_blob(force, verbose)
         obj = os.path.join(LIB, "obj", "engine_hip.o")
         cmd = [_hipcc()] + flags + ["-c", os.path.join(HIP_SRC, "engine.hip"), "-o", obj]
@@ -182,13 +238,14 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(subprocess.check_call, jobs))
         for obj, digest in stamps:
             _stamp(obj, digest)
-    link_digest = _stale(HOST_SO, objs)
+    cmd = ["g++", "-shared", "-o", HOST_SO] + objs + ["-L" + LIB, "-lsayuri_hip", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lz"]
+    link_extra = [" ".join(os.path.relpath(c, ROOT) if os.path.isabs(c) else c for c in cmd)]  # the link line decides the output too
+    link_digest = _stale(HOST_SO, objs, link_extra)
     if jobs or force or link_digest:
-        cmd = ["g++", "-shared", "-o", HOST_SO] + objs + ["-L" + LIB, "-lsayuri_hip", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lz"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-        _stamp(HOST_SO, _digest(objs))
+        _stamp(HOST_SO, _digest(objs, link_extra))
     return HOST_SO
 
 

@@ -405,7 +405,9 @@ Node* Node::PuctSelectChild(int color, bool is_root) {
     }
     if (!bare_seen && hi < size) consider(children_[static_cast<size_t>(hi)], best, best_value);  // the best of the bare edges beyond
     // SAYURI_PUCT_CHECK=1 (tests): the reference's loop over ALL children must pick the same edge, and the two conditions the
-    // pruning rests on must hold -- children sorted by policy, nothing but bare edges beyond inflated_hi_
+    // pruning rests on must hold -- children sorted by policy, nothing but bare edges beyond inflated_hi_.  For ONE playout per
+    // tree at a time (this engine's own search): with several threads in one tree (virtual loss) the statistics may change
+    // between the two loops and the comparison can abort a correct search.
     static const bool check = std::getenv("SAYURI_PUCT_CHECK") != nullptr;
     if (check) {
         Edge* full = nullptr;

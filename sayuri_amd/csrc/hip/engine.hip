@@ -432,8 +432,12 @@ static HeadFn make_head_images(int C, int Cp, int Cv, int prob_ch, int board, co
 // the persistent tower kernels (conv_tower.h) out of the embedded code object: [0] 256-channel tile, [1] 128-channel tile
 }  // namespace sayuri
 extern "C" const unsigned char sayuri_tower_hsaco[];
+extern "C" const unsigned long long sayuri_tower_hsaco_size;
 namespace sayuri {
 static int load_tower_module(hipModule_t* mod, hipFunction_t fn[2]) {
+    // an EMPTY blob: the build went on without the persistent kernel because tower_seam.py did not recognise the compiler's
+    // assembly (sayuri_amd/_build.py tower_blob_from_asm); the caller reports the fallback and launches per layer
+    if (sayuri_tower_hsaco_size == 0) return fail("this build carries no persistent tower kernel: tower_seam.py rejected the compiler's assembly at build time");
     HIP_OK(hipModuleLoadData(mod, sayuri_tower_hsaco));
     HIP_OK(hipModuleGetFunction(&fn[0], *mod, "_ZN6sayuri17conv_tower_kernelILi4EEEvPKNS_10TowerLayerE"));
     HIP_OK(hipModuleGetFunction(&fn[1], *mod, "_ZN6sayuri17conv_tower_kernelILi2EEEvPKNS_10TowerLayerE"));
@@ -463,7 +467,7 @@ public:
 template <typename T> class Engine : public EngineBase {
 public:
     struct TileTabs { int* src = nullptr; int2* pix = nullptr; bool fresh = false; };
-    struct BoardTabs { int* src = nullptr; int2* pix = nullptr; int* cols = nullptr; int npos_built = 0; bool fresh = false; };
+    struct BoardTabs { int* src = nullptr; int2* pix = nullptr; int* cols = nullptr; int npos_built = 0; int ntiles_built = 0; bool fresh = false; };
     Engine(int device, const sayuri_hip_netdesc& d, int max_batch, int board, const EngineFlags& flags)
         : flags_(flags), device_(device), desc_(d), max_batch_(max_batch), board_(board) {
         blocks_.assign(d.blocks, d.blocks + d.residual_blocks);
@@ -502,9 +506,26 @@ public:
         // One stream per ticket only with the persistent launch: its workgroups hold every CU, so the two tickets' forwards
         // follow one another whatever stream they are on.  Per-layer launches of two tickets would run side by side and evict
         // each other's weights and activations from L2 (the measurement above): those keep the one compute stream.
-        inorder_ = flags_.io_inorder && tower_fn_[0] != nullptr;
+        // ... and only for networks whose tower the persistent launch actually covers: every 3x3 convolution of the blocks
+        // must have a channel tile that covers the layer (tower_ok: 256 or 128 padded output channels).  A 384- or
+        // 192-channel network has the code object loaded and still runs one launch per layer.
+        if (describe_layers()) return -1;
+        inorder_ = flags_.io_inorder && tower_fn_[0] != nullptr && tower_covers_net();
         if (flags_.compute_streams == 2 || inorder_) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
-        return describe_layers();
+        return 0;
+    }
+    // every 3x3 convolution of the residual tower has 128 or 256 (padded) output channels and there is at least one
+    bool tower_covers_net() const {
+        int n3 = 0;
+        for (const auto& kv : convs_) {
+            const ConvLayerDev& L = kv.second;
+            if (L.k != 3 || L.depthwise || kv.first == SAYURI_L_INPUT_CONV) continue;
+            const int cs = round_up(L.cout, 32);
+            if (cs != 256 && cs != 128) return false;
+            ++n3;
+        }
+        const int c0 = round_up(desc_.residual_channels, 32);
+        return n3 > 0 && (c0 == 256 || c0 == 128);
     }
 
     // -------------------------------------------------------------- weights
@@ -579,8 +600,9 @@ public:
         // So nothing small is copied any more: the heads kernel stores pass / misc straight into the caller's pinned
         // buffers (20 KB of posted PCIe writes), a uniform batch uses geometry arrays that are resident (enqueue_inputs),
         // and the tower table does not depend on the batch size (tower_append).  The two large outputs keep their DMA copies.
-        zc_pass_ = flags_.io_zc ? pass : nullptr;
-        zc_misc_ = flags_.io_zc ? misc : nullptr;
+        zc_pass_ = flags_.io_zc ? zc_device_pointer(pass) : nullptr;
+        zc_misc_ = zc_pass_ ? zc_device_pointer(misc) : nullptr;
+        if (!zc_misc_) zc_pass_ = nullptr;  // both or neither: the heads kernel takes one path
         const int frc = forward();
         const bool small_direct = zc_pass_ != nullptr;
         zc_pass_ = zc_misc_ = nullptr;
@@ -653,6 +675,25 @@ public:
         have_batch_ = true;
         return 0;
     }
+
+    // The heads kernel stores pass / misc straight into the caller's buffers when the device can address them: page-locked
+    // memory that is MAPPED (sayuri_hip_host_alloc, hipHostMalloc, hipHostRegister with the mapped flag).  Anything else --
+    // pinned but unmapped, pageable, another allocator's -- would fault the GPU inside the kernel with no error returned, so a
+    // pointer is asked about once (hipHostGetDevicePointer) and the answer kept; a buffer that is not device-addressable gets
+    // its results through the device-side copies and hipMemcpyAsync as before.
+    float* zc_device_pointer(float* host) {
+        if (!host) return nullptr;
+        auto it = zc_known_.find(host);
+        if (it != zc_known_.end()) return it->second;
+        void* dp = nullptr;
+        float* ans = nullptr;
+        if (hipHostGetDevicePointer(&dp, host, 0) == hipSuccess && dp) ans = (float*)dp;
+        else (void)hipGetLastError();  // not an error of this engine: the fallback path is taken
+        if (zc_known_.size() >= 64) zc_known_.clear();
+        zc_known_[host] = ans;
+        return ans;
+    }
+    std::map<float*, float*> zc_known_;
 
     // resident geometry arrays of a uniform batch of `bs` x `bs` boards (valid for every n <= max_batch)
     struct IdentGeom { int *off = nullptr, *bsz = nullptr, *perm = nullptr; };
@@ -1298,12 +1339,15 @@ private:
                 dev_alloc(&t.cols, max_batch_))
                 return -1;
         }
-        if (!t.fresh || t.npos_built != board_plan_.npos) {
+        // (a slot's tables may be kept for a shorter batch of the same geometry -- enqueue_inputs' prefix rule trusts the
+        // sizes recorded at enqueue time; what counts here is how many tiles the tables were BUILT for)
+        if (!t.fresh || t.npos_built != board_plan_.npos || board_plan_.ntiles > t.ntiles_built) {
             hipLaunchKernelGGL(board_setup_kernel, dim3(board_plan_.ntiles), dim3(256), 0, stream_, dgeom(), board_plan_.npos, t.src,
                                t.pix, t.cols);
             HIP_OK(hipGetLastError());
             t.fresh = true;
             t.npos_built = board_plan_.npos;
+            t.ntiles_built = board_plan_.ntiles;
         }
         *out = &t;
         return 0;
