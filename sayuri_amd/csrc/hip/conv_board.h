@@ -987,7 +987,9 @@ __global__ __launch_bounds__(512, 2) void conv_board_kernel(const BoardParams bp
     const ConvParams& p = bp.c;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x % p.num_pix_tiles;
+    // (ConvParams::npos, the generic kernels' halo bound, is this launch's FIRST tile here: a launch may cover the tile range
+    // [npos, npos + num_pix_tiles) of the batch -- Engine::conv_se splits an SE layer of a mixed batch by board size)
+    const int tile = p.npos + blockIdx.x % p.num_pix_tiles;
     const int kt = blockIdx.x / p.num_pix_tiles;
     // column tiles: wave column 0 (waves 0-3) takes the first ceil(n/2), wave column 1 (waves 4-7, the SIMD partners
     // of 0-3) the rest

@@ -154,6 +154,7 @@ struct ConvOverride { bool v0 = false, no_board = false; int wnt = 0; };
 struct EngineFlags {
     ConvOverride conv;
     bool tower = true, se_fused = true, heads_fused = true, arith = true;
+    bool se_by_geometry = true;        // which samples take the fused SE form depends on their board size alone (conv_se); SAYURI_SE_BY_GEOMETRY=0: on the tiles' occupancy
     bool io_v2 = true;                 // SAYURI_IO_V2=0: geometry / small outputs by copies again (A/B; see submit())
     bool io_zc = true, io_geom = true, io_prefix = true;  // its three parts, one at a time (SAYURI_IO_ZC / _GEOM / _PREFIX = 0)
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
@@ -178,6 +179,7 @@ struct EngineFlags {
         f.io_geom = f.io_v2 && !off("SAYURI_IO_GEOM");
         f.io_prefix = f.io_v2 && !off("SAYURI_IO_PREFIX");
         f.se_fused = !off("SAYURI_SE_FUSED");
+        f.se_by_geometry = !off("SAYURI_SE_BY_GEOMETRY");
         f.heads_fused = !off("SAYURI_HEADS_FUSED");
         f.arith = !getenv("SAYURI_NO_ARITH");
         if (const char* e = getenv("SAYURI_COMPUTE_STREAMS")) f.compute_streams = atoi(e) == 2 ? 2 : 1;
@@ -1381,10 +1383,21 @@ private:
         if (!off && choose_board(L, &bkt))
             for (const auto& e : kBoardEntries)
                 if (e.fn_se && e.kot == L.ko_pad && e.lds(board_plan_.npos) <= kMaxLds) be = &e;
-        if (!be || !board_plan_.single || C > be->kot) return 1;
+        if (!be || C > be->kot) return 1;
         const bool staged = sq.img16 && ex.img16;
         if (!staged && (sq.out % 4 || sq.out > 512 || ex.out % 4 || ex.out > 2048 || 512 % (sq.out / 4) || 512 % (ex.out / 4))) return 1;
         if constexpr (sizeof(T) != 2) return 1;
+        // WHICH samples take the fused form is a property of the sample alone, never of its batch mates (a position's result
+        // must not depend on what else the queue collected: the fused form pools the fp32 accumulators, the separate kernels
+        // pool x rounded to fp16): a board too large to share a tile with another of its size (2 bs^2 > 384 pixel slots, i.e.
+        // bs >= 14) is ALWAYS alone in its tile and ALWAYS fused; a smaller board ALWAYS goes through the separate kernels, also
+        // when it happens to sit alone in a tile.  The device order is largest first, so the fused samples -- and their tiles,
+        // one each -- lead the batch: tiles [0, nbig) fused, tiles [nbig, ntiles) = samples [nbig, n) plain convolution + SE unit.
+        int nbig = 0;
+        while (nbig < geom_.n && 2 * geom_.bsz[nbig] * geom_.bsz[nbig] > kBoardPT) ++nbig;
+        if (!flags_.se_by_geometry) nbig = board_plan_.single ? geom_.n : 0;  // SAYURI_SE_BY_GEOMETRY=0: round 4's rule (A/B, tests)
+        if (nbig == 0) return 1;
+        const bool split = nbig < geom_.n;
         const BoardTabs* tabs = nullptr;
         if (board_tabs(&tabs)) return -1;
         BoardSeParams sp;
@@ -1411,11 +1424,23 @@ private:
         const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out);
         const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
         if (board_row_order_ok(L, be, bp, act)) { p.w = L.w_board; p.bias = L.bias_board; bp.row_order = 1; }
-        if (tower_ok(be->kot) && !bp.dbg) return tower_append(be->kot, sp, true, flops, bytes);
+        if (!split && tower_ok(be->kot) && !bp.dbg) return tower_append(be->kot, sp, true, flops, bytes);
         const auto fn = be->fn_se;
         const size_t lds = be->lds(board_plan_.npos);
-        const int grid = board_plan_.ntiles;
-        return timed("conv3x3_tower_se", flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, sp); });
+        const int grid = split ? nbig : board_plan_.ntiles;
+        if (timed("conv3x3_tower_se", flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, sp); })) return -1;
+        if (!split) return 0;
+        // the small boards of the batch: the same convolution without epilogue extras on the tiles behind, then the unit's
+        // three kernels on the samples behind
+        BoardParams rest = bp;
+        rest.row_order = 0;
+        rest.c.w = L.w; rest.c.bias = L.bias; rest.c.res = nullptr; rest.c.act = kIdentity;
+        rest.c.npos = nbig;  // first tile of the launch (conv_board_kernel)
+        rest.c.num_pix_tiles = board_plan_.ntiles - nbig;
+        const auto fn2 = be->fn;
+        const int grid2 = rest.c.num_pix_tiles;  // be->kot covers the layer: one channel tile
+        if (timed("conv3x3_tower", flops, bytes, [&] { hipLaunchKernelGGL(fn2, dim3(grid2), dim3(512), lds, stream_, rest); })) return -1;
+        return se_unit(sq, ex, out, res, C, round_up(C, 32), act, nbig);
     }
 
     int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
@@ -1511,28 +1536,30 @@ private:
         });
     }
 
-    int se_unit(const FcLayerDev& sq, const FcLayerDev& ex, T* x, const T* res, int C, int cs, int act) {
+    // n0: the unit runs on the samples [n0, n) of the batch (conv_se's split of a mixed batch)
+    int se_unit(const FcLayerDev& sq, const FcLayerDev& ex, T* x, const T* res, int C, int cs, int act, int n0 = 0) {
         const BatchGeom g = dgeom();
-        const double px = geom_.total;
+        const int ns = geom_.n - n0;
+        const double px = geom_.total - geom_.off[n0];
         constexpr int EPP = ElemTraits<T>::kPieceElems;
         if (cs / EPP > 256) return fail("SE unit: more than 256*8 channels is not supported");
         if (timed("se_pool", 2.0 * px * C, sizeof(T) * px * C, [&] {
-                hipLaunchKernelGGL(se_pool_kernel<T>, dim3(geom_.n * kSeSplit), dim3(256), 0, stream_, (const T*)x,
-                                   d_separt_, g, cs);
+                hipLaunchKernelGGL(se_pool_kernel<T>, dim3(ns * kSeSplit), dim3(256), 0, stream_, (const T*)x,
+                                   d_separt_, g, cs, n0);
             }))
             return -1;
         const size_t smem = sizeof(float) * (3 * C + sq.out + kSeFcThreads);
-        if (timed("se_fc", 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out),
-                  4.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out), [&] {
-                      hipLaunchKernelGGL(se_fc_kernel, dim3(geom_.n), dim3(kSeFcThreads), smem, stream_,
-                                         (const float*)d_separt_, d_gate_, g, C, cs, sq.dev(), ex.dev(), act);
+        if (timed("se_fc", 2.0 * ns * ((double)sq.in * sq.out + (double)ex.in * ex.out),
+                  4.0 * ns * ((double)sq.in * sq.out + (double)ex.in * ex.out), [&] {
+                      hipLaunchKernelGGL(se_fc_kernel, dim3(ns), dim3(kSeFcThreads), smem, stream_,
+                                         (const float*)d_separt_, d_gate_, g, C, cs, sq.dev(), ex.dev(), act, n0);
                   }))
             return -1;
         const int ppr = cs / EPP;
-        const dim3 grid((slot_pix_ * ppr + 256 * kScaleUnroll - 1) / (256 * kScaleUnroll), geom_.n);
+        const dim3 grid((slot_pix_ * ppr + 256 * kScaleUnroll - 1) / (256 * kScaleUnroll), ns);
         return timed("se_scale", 3.0 * px * C, sizeof(T) * px * C * 3, [&] {
             hipLaunchKernelGGL(se_scale_kernel<T>, grid, dim3(256), 0, stream_, (const T*)x, res, x,
-                               (const float*)d_gate_, g, C, cs, act);
+                               (const float*)d_gate_, g, C, cs, act, n0);
         });
     }
 

@@ -242,10 +242,10 @@ constexpr int kSeSplit = 4;
 
 template <typename T>
 __global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, float* __restrict__ part, BatchGeom g,
-                                                      int cs) {
+                                                      int cs, int n0 = 0) {  // n0: first sample of the launch
     constexpr int EPP = ElemTraits<T>::kPieceElems;
     __shared__ float red[2][256 * 8 / 8 * 8];  // [sum|max][thread][EPP<=8]
-    const int n = blockIdx.x / kSeSplit, sp = blockIdx.x % kSeSplit;
+    const int n = n0 + blockIdx.x / kSeSplit, sp = blockIdx.x % kSeSplit;
     const int tid = threadIdx.x;
     const int bs = g.bsz[n], npix = bs * bs;
     const int ppr = cs / EPP;                 // 16-byte pieces per pixel row
@@ -292,13 +292,13 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, f
 // layer), 28 with 1024.
 constexpr int kSeFcThreads = 1024;
 __global__ __launch_bounds__(kSeFcThreads) void se_fc_kernel(const float* __restrict__ part, float* __restrict__ gate,
-                                                    BatchGeom g, int C, int cs, FcDev squeeze, FcDev excite, int act) {
+                                                    BatchGeom g, int C, int cs, FcDev squeeze, FcDev excite, int act, int n0 = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* pool = (float*)smem;          // [3C]
     float* mid = pool + 3 * C;           // [se_size]
     float* scratch = mid + squeeze.out;  // [NT]
     constexpr int NT = kSeFcThreads;
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n = n0 + blockIdx.x, tid = threadIdx.x;
     const int bs = g.bsz[n];
     const float npix = (float)(bs * bs), bd = (float)bs - 14.f;
     for (int c = tid; c < C; c += NT) {
@@ -359,9 +359,9 @@ constexpr int kScaleUnroll = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ out, const float* __restrict__ gate,
-                                                       BatchGeom g, int C, int cs, int act) {
+                                                       BatchGeom g, int C, int cs, int act, int n0 = 0) {
     constexpr int EPP = ElemTraits<T>::kPieceElems;
-    const int n = blockIdx.y;
+    const int n = n0 + blockIdx.y;
     const int bs = g.bsz[n], npix = bs * bs;
     const int ppr = cs / EPP, total = npix * ppr;
     const size_t base = (size_t)n * g.slot_pix * cs;

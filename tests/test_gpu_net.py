@@ -287,8 +287,8 @@ def test_packed_planes_give_identical_outputs(name, fp16, tmp_weights_dir):
         for x, y, what in zip(a, b, ("prob", "pass", "misc", "own")):
             assert np.array_equal(x, y), what
         assert np.abs(a[0]).max() > 0
-        # through the queue the batches form as the callers arrive; a full-size board's result does not depend on its
-        # batch mates, so those compare exactly, the small boards (which may or may not share a tile) within the gate
+        # through the queue the batches form as the callers arrive; no sample's result depends on its batch mates, so all of
+        # them compare exactly between the three routes (and to the oracle within the gate)
         q_fp32 = pipe.Forward(planes, bsz)
         q_pack = pipe.ForwardPacked(planes, bsz)
         q_mix = pipe.ForwardPacked(planes, bsz, mixed=True)
@@ -302,11 +302,62 @@ def test_packed_planes_give_identical_outputs(name, fp16, tmp_weights_dir):
                 assert np.array_equal(q_fp32[i], q_pack[i]), what()
                 assert np.array_equal(q_fp32[i], q_mix[i]), what()
             else:
+                # a small board too: which kernels it meets depends on its own size only (test_a_position_does_not_depend_on_its_batch_mates)
                 exp = oracle.forward(planes[i], bs)
                 for q in (q_fp32, q_pack, q_mix):
                     assert np.abs(q[i] - exp).max() <= tol(exp), i
+                assert np.array_equal(q_fp32[i], q_pack[i]) and np.array_equal(q_fp32[i], q_mix[i]), (i, bs)
         exp = oracle.forward(planes[0], bsz[0])
         assert np.abs(q_pack[0] - exp).max() <= tol(exp)
+    finally:
+        pipe.Destroy()
+
+
+@pytest.mark.parametrize("name", ["net_20b256", "net_40b384"])
+def test_a_position_does_not_depend_on_its_batch_mates(name, tmp_weights_dir, capsys):
+    """Reference batch_forward_pipe.cc:15-33,48-68: a request's result is a function of the request.  Here the kernels a sample
+    meets depend on the batch geometry (which samples share a tile, which kernel family a layer takes), so this pins it: one
+    9x9, one 13x13 and one 19x19 position, each evaluated ALONE and inside four different mixed batches (at different places,
+    with different mates, batches of every kernel plan), must come out BIT-equal in fp16.  What makes it hold: the SE unit's
+    form (fused into the convolution or three separate kernels, which round at different points) is chosen by the sample's
+    board size alone (Engine::conv_se), and the convolution kernels accumulate in one order whatever the tile plan."""
+    from sayuri_amd.pipe import hip_forward_raw
+    g = Golden(name, tmp_weights_dir)
+    B = 19
+    probes = {bs: W.synthetic_planes(1, bs, seed=4200 + bs)[0] for bs in (9, 13, 19)}
+    rng = np.random.default_rng(77)
+
+    def grid_of(planes, bsz):
+        gr = np.zeros((len(bsz), 43, B * B), np.float32)
+        for i, (p, bs) in enumerate(zip(planes, bsz)):
+            gr[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+        return gr
+
+    def sample(out, i):
+        return [np.array(t[i]) for t in out]
+
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=64, fp16=True)
+    try:
+        ctx = pipe.ctx(0)
+        for bs, probe in probes.items():
+            alone = sample(hip_forward_raw(ctx, grid_of([probe], [bs]), [bs], B), 0)
+            assert np.abs(alone[0]).max() > 0
+            mates = [
+                [19] * 5 + [9] * 7 + [13] * 3,            # a bit of everything
+                [9] * 40,                                 # small boards only: four per tile
+                [19] * 30 + [13] * 3 + [9] * 2,           # mostly full boards
+                [13] * 9 + [7] * 6 + [19] * 2 + [9] * 21 + [16] * 3,
+            ]
+            for k, sizes in enumerate(mates):
+                sizes = list(sizes)
+                rng.shuffle(sizes)
+                at = int(rng.integers(0, len(sizes) + 1))
+                sizes.insert(at, bs)
+                planes = W.synthetic_planes(len(sizes), sizes, seed=900 + 10 * bs + k)
+                planes[at] = probe
+                got = sample(hip_forward_raw(ctx, grid_of(planes, sizes), sizes, B), at)
+                for a, b, what in zip(alone, got, ("prob", "pass", "misc", "own")):
+                    assert np.array_equal(a, b), (name, bs, k, what, float(np.abs(a - b).max()))
     finally:
         pipe.Destroy()
 
