@@ -217,12 +217,12 @@ def test_se_unit_fused_into_the_convolution_matches_the_separate_kernels(tmp_wei
     each other: they differ only by where x is rounded to fp16."""
     g = Golden("net_20b256", tmp_weights_dir)
     oracle = PortNet(g.weights_path)
-    bsz = [19, 13, 19, 9, 19, 19, 7, 19]  # no two neighbours of one size: every tile holds one sample
+    bsz = [19, 13, 19, 9, 19, 19, 7, 19, 16, 14]  # full boards and boards that can share a tile, in one batch
     planes = W.synthetic_planes(len(bsz), bsz, seed=4242)
     outs = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("SAYURI_SE_FUSED", mode)
-        pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=8, fp16=True)
+        pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=16, fp16=True)
         try:
             outs[mode] = pipe.BatchForward(planes, bsz)
         finally:
@@ -232,7 +232,13 @@ def test_se_unit_fused_into_the_convolution_matches_the_separate_kernels(tmp_wei
         assert np.abs(outs["1"][i] - exp).max() <= fp16_tol(exp), (i, bs)
         assert np.abs(outs["0"][i] - exp).max() <= fp16_tol(exp), (i, bs)
         assert np.abs(outs["1"][i] - outs["0"][i]).max() <= fp16_tol(exp)
-        assert np.abs(outs["1"][i] - outs["0"][i]).max() > 0, "the switch did not change the path"
+        # which samples the fused form takes is decided by their board size alone (Engine::conv_se: a board that can never
+        # share a tile, bs >= 14): for those the switch changes the path, the smaller boards go through the separate kernels
+        # either way -- bit for bit the same
+        if 2 * bs * bs > 384:
+            assert np.abs(outs["1"][i] - outs["0"][i]).max() > 0, "the switch did not change the path"
+        else:
+            assert np.array_equal(outs["1"][i], outs["0"][i]), (i, bs)
 
 
 @pytest.mark.parametrize("name", ["net_20b256", "net_40b384", "net_6b96", "tiny_res", "tiny_all"])
