@@ -67,6 +67,19 @@ struct SearchParams {
     int board_size{sayuri_go::kMaxBoard};
     float recent_expected_black_score{0.0f};
     std::array<float, sayuri_go::kMaxVertices + 10> dirichlet_buffer{};
+
+    // Selection at the root (tree.cc Node::PuctSelectChild): all ~360 root children carry nodes, and looking at every one of
+    // them for every playout was most of the selection's cost (a cache line per child).  A child that was never chosen has no
+    // visits and scores fpu + cpuct * psa * sqrt(N): monotone in its search policy psa, which is fixed for the whole search.  So
+    // the root keeps its children's indices by descending psa and the (sorted) list of the children chosen so far; a call looks
+    // at those and at the head of the never-chosen ones.  Built by PrepareRootNode, valid while `root_index_owner` is the root.
+    struct RootIndex {
+        const void* owner{nullptr};
+        std::vector<std::int16_t> by_psa;     // child indices, psa descending, ties: lower index first
+        std::vector<std::int16_t> chosen;     // child indices that were returned by the selection, ascending
+        std::vector<std::uint8_t> is_chosen;  // per child index
+        int cursor{0};                        // by_psa[0 .. cursor) are all chosen
+    } root_index;
 };
 
 // Expected score utility E[2/pi * atan(x / board)] for x ~ N(mean, stddev), from a table integrated once

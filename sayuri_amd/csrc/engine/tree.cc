@@ -137,8 +137,15 @@ bool Node::ExpandChildren(Network& network, GameState& state, NodeEvals& evals, 
         }
         children_.reserve(list.size());
         if (plain) {
-            std::sort(keys, keys + list_n, std::greater<std::uint64_t>());
-            for (int i = 0; i < list_n; ++i) {  // the edges straight from the sorted keys
+            // the best kSortedAtExpansion in place and in order, the others behind them as they fall (tree.h: sorted_n_)
+            int sorted = list_n;
+            if (list_n > 2 * kSortedAtExpansion && !is_root) {
+                sorted = kSortedAtExpansion;
+                std::nth_element(keys, keys + sorted, keys + list_n, std::greater<std::uint64_t>());
+            }
+            std::sort(keys, keys + sorted, std::greater<std::uint64_t>());
+            sorted_n_ = static_cast<std::int16_t>(sorted);
+            for (int i = 0; i < list_n; ++i) {  // the edges straight from the keys
                 const std::uint32_t bits = static_cast<std::uint32_t>(keys[i] >> 16);
                 float p;
                 std::memcpy(&p, &bits, sizeof(p));
@@ -147,10 +154,25 @@ bool Node::ExpandChildren(Network& network, GameState& state, NodeEvals& evals, 
         } else {
             std::sort(list.begin(), list.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a > b; });
             for (const auto& e : list) children_.emplace_back(e.second, e.first);
+            sorted_n_ = static_cast<std::int16_t>(list_n);
         }
     }
     expanded_ = true;
     return true;
+}
+
+// The rest of the children's order (tree.h: sorted_n_): bare edges only, by (policy, vertex) descending -- the keys of
+// ExpandChildren's plain path (non-negative policies order like their bit patterns).
+void Node::SortTail() const {
+    auto* self = const_cast<Node*>(this);
+    auto key = [](const Edge& e) {
+        std::uint32_t bits;
+        const float p = e.policy;
+        std::memcpy(&bits, &p, sizeof(bits));
+        return (static_cast<std::uint64_t>(bits) << 16) | static_cast<std::uint64_t>(static_cast<std::uint16_t>(e.vertex));
+    };
+    std::sort(self->children_.begin() + sorted_n_, self->children_.end(), [&key](const Edge& a, const Edge& b) { return key(a) > key(b); });
+    sorted_n_ = static_cast<std::int16_t>(children_.size());
 }
 
 bool Node::SetTerminal(const NodeEvals* evals) {
@@ -163,6 +185,7 @@ bool Node::SetTerminal(const NodeEvals* evals) {
 }
 
 void Node::RecomputePolicy(Network& network, GameState& state, NodeEvals& evals, bool is_root, Rng& rng) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     if (!HasChildren()) return;
     const Network::Result net = GetNetOutput(network, state, is_root, rng);
     FillNodeEvalsFromNet(net, evals, state.GetToMove());
@@ -179,6 +202,7 @@ void Node::RecomputePolicy(Network& network, GameState& state, NodeEvals& evals,
 
 bool Node::PrepareRootNode(Network& network, GameState& state, NodeEvals& evals, Rng& rng) {
     const bool fresh = ExpandChildren(network, state, evals, true, rng);
+    EnsureSorted();  // a reused subtree's node may still carry its lazily ordered tail: finish it before any edge there gets a node
     InflateAllChildren();
     // a reused root may carry a policy computed with other settings (temperature): refresh it
     if (!fresh) RecomputePolicy(network, state, evals, true, rng);
@@ -188,10 +212,41 @@ bool Node::PrepareRootNode(Network& network, GameState& state, NodeEvals& evals,
     }
     KillRootSuperkos(state);
     UpdateScoreBonus(state, evals);
+    BuildRootIndex();
     return fresh;
 }
 
+// search_params.h RootIndex: the root's children by descending search policy, and those that already carry visits (a reused
+// subtree's) as the first "chosen" ones.  Called last in PrepareRootNode: the policies, the noise and the set of children are final.
+void Node::BuildRootIndex() {
+    auto& ri = param_->root_index;
+    const int size = static_cast<int>(children_.size());
+    ri.owner = nullptr;
+    if (param_->gumbel || size == 0) return;  // Gumbel's own selection also descends root children: the full loop stays
+    std::vector<std::pair<float, std::int16_t>> order(static_cast<size_t>(size));
+    ri.chosen.clear();
+    ri.is_chosen.assign(static_cast<size_t>(size), 0);
+    for (int i = 0; i < size; ++i) {
+        const Edge& c = children_[static_cast<size_t>(i)];
+        Node* n = c.Get();
+        if (!n) return;  // (never: InflateAllChildren ran)
+        order[static_cast<size_t>(i)] = {GetSearchPolicy(c, true), static_cast<std::int16_t>(i)};
+        if (n->GetVisits() > 0 || !n->IsActive() || n->HasChildren()) {  // anything but a fresh node is looked at individually
+            ri.is_chosen[static_cast<size_t>(i)] = 1;
+            ri.chosen.push_back(static_cast<std::int16_t>(i));
+        }
+    }
+    std::sort(order.begin(), order.end(), [](const std::pair<float, std::int16_t>& a, const std::pair<float, std::int16_t>& b) {
+        return a.first > b.first || (a.first == b.first && a.second < b.second);
+    });
+    ri.by_psa.resize(static_cast<size_t>(size));
+    for (int i = 0; i < size; ++i) ri.by_psa[static_cast<size_t>(i)] = order[static_cast<size_t>(i)].second;
+    ri.cursor = 0;
+    ri.owner = this;
+}
+
 void Node::ApplyDirichletNoise(float alpha, Rng& rng) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     const size_t n = children_.size();
     std::vector<float> buf(n);
     std::gamma_distribution<float> gamma(alpha, 1.0f);
@@ -205,6 +260,7 @@ void Node::ApplyDirichletNoise(float alpha, Rng& rng) {
 }
 
 void Node::KillRootSuperkos(GameState& state) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     for (auto& c : children_) {
         const int vtx = c.GetVertex();
         GameState fork = state;
@@ -217,6 +273,7 @@ void Node::KillRootSuperkos(GameState& state) {
 }
 
 void Node::UpdateScoreBonus(GameState& state, NodeEvals& evals) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     if (!param_->first_pass_bonus) return;
     black_sb_ = 0.0f;
     InflateAllChildren();
@@ -272,6 +329,7 @@ Node* Node::Inflate(Edge& e) {
 }
 
 void Node::InflateAllChildren() {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     for (auto& c : children_) Inflate(c);
 }
 
@@ -283,6 +341,7 @@ Node* Node::DescentSelectChild(int color, bool is_root, Rng& rng) {
 }
 
 Node* Node::ProbSelectChild(bool allow_pass) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     Edge* best = nullptr;
     float best_prob = std::numeric_limits<float>::lowest();
     for (auto& c : children_) {
@@ -353,9 +412,13 @@ Node* Node::PuctSelectChild(int color, bool is_root) {
     // descended ones: the two loops were 8 % of all host time of a self-play rank.
     const int size = static_cast<int>(children_.size());
     const int hi = is_root ? size : std::min<int>(inflated_hi_, size);
+    EnsureSorted(hi + 1);  // the children looked at below: [0, hi] (tree.h: the order is finished on demand)
+    // the root's index (search_params.h RootIndex): the children chosen so far + the head of the others by search policy
+    auto& ri = param_->root_index;
+    const bool indexed = is_root && ri.owner == this && static_cast<int>(ri.by_psa.size()) == size;
     int children_visits = 0;
     float visited_policy = 0.0f;
-    for (int i = 0; i < hi; ++i) {
+    auto tally = [&](int i) {
         Edge& c = children_[static_cast<size_t>(i)];
         Node* n = c.Get();
         if (n && n->IsValid()) {
@@ -363,6 +426,11 @@ Node* Node::PuctSelectChild(int color, bool is_root) {
             children_visits += v;
             if (v > 0) visited_policy += c.GetPolicy();
         }
+    };
+    if (indexed) {
+        for (const std::int16_t i : ri.chosen) tally(i);  // ascending: the float sum adds the same terms in the same order
+    } else {
+        for (int i = 0; i < hi; ++i) tally(i);
     }
     const float raw_cpuct = GetCpuct(children_visits);
     const float numerator = std::sqrt(static_cast<float>(children_visits));
@@ -395,21 +463,54 @@ Node* Node::PuctSelectChild(int color, bool is_root) {
             best = &c;
         }
     };
-    for (int i = 0; i < hi; ++i) {
-        Edge& c = children_[static_cast<size_t>(i)];
-        if (!c.Get() && !is_root) {
-            if (bare_seen) continue;
-            bare_seen = true;
+    if (indexed) {
+        // the chosen children one by one (ascending index: the first of equal values wins, as in the full loop) ...
+        for (const std::int16_t i : ri.chosen) consider(children_[static_cast<size_t>(i)], best, best_value);
+        // ... and of the never-chosen ones (fresh nodes: no visits, active, value = fpu + cpuct * psa * sqrt(N), monotone in psa)
+        // those that share the largest value, i.e. the head of the psa order down to the first strictly smaller value
+        while (ri.cursor < size && ri.is_chosen[static_cast<size_t>(ri.by_psa[static_cast<size_t>(ri.cursor)])]) ++ri.cursor;
+        Edge* fresh_best = nullptr;
+        float fresh_value = std::numeric_limits<float>::lowest();
+        for (int k = ri.cursor; k < size; ++k) {
+            const int i = ri.by_psa[static_cast<size_t>(k)];
+            if (ri.is_chosen[static_cast<size_t>(i)]) continue;
+            Edge* e = nullptr;
+            float v = std::numeric_limits<float>::lowest();
+            consider(children_[static_cast<size_t>(i)], e, v);
+            if (!e) continue;
+            if (!fresh_best) { fresh_best = e; fresh_value = v; }
+            else if (v < fresh_value) break;
+            else if (e < fresh_best) fresh_best = e;  // an equal value at a lower index
         }
-        consider(c, best, best_value);
+        if (fresh_best && (fresh_value > best_value || (fresh_value == best_value && fresh_best < best))) {
+            best = fresh_best;
+            best_value = fresh_value;
+        }
+        if (best) {
+            const int bi = static_cast<int>(best - children_.data());
+            if (!ri.is_chosen[static_cast<size_t>(bi)]) {
+                ri.is_chosen[static_cast<size_t>(bi)] = 1;
+                ri.chosen.insert(std::lower_bound(ri.chosen.begin(), ri.chosen.end(), static_cast<std::int16_t>(bi)), static_cast<std::int16_t>(bi));
+            }
+        }
+    } else {
+        for (int i = 0; i < hi; ++i) {
+            Edge& c = children_[static_cast<size_t>(i)];
+            if (!c.Get() && !is_root) {
+                if (bare_seen) continue;
+                bare_seen = true;
+            }
+            consider(c, best, best_value);
+        }
+        if (!bare_seen && hi < size) consider(children_[static_cast<size_t>(hi)], best, best_value);  // the best of the bare edges beyond
     }
-    if (!bare_seen && hi < size) consider(children_[static_cast<size_t>(hi)], best, best_value);  // the best of the bare edges beyond
     // SAYURI_PUCT_CHECK=1 (tests): the reference's loop over ALL children must pick the same edge, and the two conditions the
     // pruning rests on must hold -- children sorted by policy, nothing but bare edges beyond inflated_hi_.  For ONE playout per
     // tree at a time (this engine's own search): with several threads in one tree (virtual loss) the statistics may change
     // between the two loops and the comparison can abort a correct search.
     static const bool check = std::getenv("SAYURI_PUCT_CHECK") != nullptr;
     if (check) {
+        EnsureSorted();
         Edge* full = nullptr;
         float full_value = std::numeric_limits<float>::lowest();
         for (int i = 0; i < size; ++i) {
@@ -513,6 +614,7 @@ std::vector<std::pair<float, int>> Node::GetSortedLcbUtilityList(int color) {
 }
 
 std::vector<std::pair<float, int>> Node::GetSortedLcbUtilityList(int color, int children_visits) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     const float reduction = std::min(std::max(0.f, param_->lcb_reduction), 1.f);
     std::vector<std::pair<float, int>> list;
     for (const auto& c : children_) {
@@ -530,6 +632,7 @@ std::vector<std::pair<float, int>> Node::GetSortedLcbUtilityList(int color, int 
 }
 
 int Node::GetBestMove(bool allow_pass) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     const auto list = GetSortedLcbUtilityList(color_);
     float best_value = std::numeric_limits<float>::lowest();
     int best = kNoVertex;
@@ -551,6 +654,7 @@ Node* Node::GetChild(int vertex) {
 }
 
 std::unique_ptr<Node> Node::PopChild(int vertex) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     for (auto it = children_.begin(); it != children_.end(); ++it) {
         if (it->GetVertex() == vertex) {
             Inflate(*it);
@@ -573,6 +677,7 @@ size_t Node::CountNodes() const {
 // ---------------------------------------------------------------------------------------------
 // Random move pickers.
 int Node::GetRandomMoveProportionally(float temp, float min_ratio, int min_visits, Rng& rng) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     // visit-proportional pick, ignoring children below a relative / absolute visit floor
     double norm = 0, accum = 0;
     std::vector<std::pair<double, int>> table;
@@ -597,6 +702,7 @@ int Node::GetRandomMoveProportionally(float temp, float min_ratio, int min_visit
 }
 
 int Node::GetRandomMoveWithLogitsQ(GameState& state, float temp, Rng& rng) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     const int n = state.GetNumIntersections();
     std::vector<float> prob(static_cast<size_t>(n + 1), 0.f);
     std::vector<int> vertices(static_cast<size_t>(n + 1), kNoVertex);
@@ -639,6 +745,7 @@ float Node::TransformCompletedQ(float completed_q, int max_visits) const {
 }
 
 std::vector<float> Node::GetProbLogitsCompletedQ(GameState& state) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     const int n = state.GetNumIntersections();
     std::vector<float> prob(static_cast<size_t>(n + 1), 0.f);
     float acc = 0.f;
@@ -652,6 +759,7 @@ std::vector<float> Node::GetProbLogitsCompletedQ(GameState& state) {
 }
 
 void Node::MixLogitsCompletedQ(GameState& state, std::vector<float>& prob) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     const int n = state.GetNumIntersections();
     const int color = state.GetToMove();
     if (n + 1 != static_cast<int>(prob.size())) return;
@@ -695,6 +803,7 @@ void Node::MixLogitsCompletedQ(GameState& state, std::vector<float>& prob) {
 bool Node::ShouldApplyGumbel() const { return param_->gumbel && param_->gumbel_playouts_threshold > GetChildrenVisits(); }
 
 bool Node::ProcessGumbelLogits(std::vector<float>& logits, int color, bool only_max_visits, Rng& rng) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     // Sequential-halving visit schedule over the top `considered` children; the child(ren) whose visit count
     // equals the schedule's current target get Gumbel(0,1) + log prior + transformed completed Q.
     const int size = static_cast<int>(children_.size());
@@ -768,6 +877,7 @@ bool Node::ProcessGumbelLogits(std::vector<float>& logits, int color, bool only_
 }
 
 Node* Node::GumbelSelectChild(int color, bool only_max_visits, bool allow_pass, Rng& rng) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     std::vector<float> logits;
     if (!ProcessGumbelLogits(logits, color, only_max_visits, rng)) return nullptr;
     Edge *best = nullptr, *best_no_pass = nullptr;
@@ -784,6 +894,7 @@ Node* Node::GumbelSelectChild(int color, bool only_max_visits, bool allow_pass, 
 }
 
 int Node::GetGumbelMove(bool allow_pass, Rng& rng) {
+    EnsureSorted();  // every child's place (tree.h: the order is finished on demand)
     int candidates = 0;
     for (auto& c : children_)
         if (c.GetVisits() > 0 && c.Get()->IsValid()) candidates += 1;

@@ -80,8 +80,8 @@ public:
     std::vector<float> GetProbLogitsCompletedQ(GameState& state); // node.cc:1487-1505
     bool ShouldApplyGumbel() const;
 
-    EdgeList& GetChildren() { return children_; }
-    const EdgeList& GetChildren() const { return children_; }
+    EdgeList& GetChildren() { EnsureSorted(); return children_; }
+    const EdgeList& GetChildren() const { EnsureSorted(); return children_; }
     bool HasChildren() const { return expanded_ && color_ != sayuri_go::kWall; }
     Node* GetChild(int vertex);
     std::unique_ptr<Node> PopChild(int vertex);
@@ -125,6 +125,7 @@ private:
     float GetWLVariance(float default_var, int visits) const;
     Node* Inflate(Edge& e);
     void InflateAllChildren();
+    void BuildRootIndex();  // search_params.h RootIndex
     float GetGumbelEval(int color) const;
     float TransformCompletedQ(float completed_q, int max_visits) const;
     bool ProcessGumbelLogits(std::vector<float>& logits, int color, bool only_max_visits, Rng& rng);
@@ -147,6 +148,18 @@ private:
     int visits_{0};
     std::int16_t vertex_;
     std::int16_t inflated_hi_{0};  // every child at an index >= this is still a bare edge (Inflate keeps it; selection stops there)
+    // The children's order (best policy first, ties: higher vertex first) is established LAZILY: an expansion puts the
+    // kSortedAtExpansion best in place and leaves the others behind them in no particular order -- a node has ~360 children, a
+    // search descends into a handful of them, and sorting all 360 keys was the largest single item of a self-play rank's host
+    // time.  children_[0 .. sorted_n_) are final; EnsureSorted(k) finishes the order when anything wants to look at index >= sorted_n_
+    // (the selection asks for inflated_hi_ + 1, everything else for all).  Bare edges only are ever moved (an inflated edge
+    // sits below inflated_hi_ <= sorted_n_), and the order reached is the same total order whichever way it is reached.
+    static constexpr int kSortedAtExpansion = 16;
+    mutable std::int16_t sorted_n_{0};
+    void EnsureSorted(int upto = 1 << 14) const {
+        if (upto > sorted_n_ && sorted_n_ < static_cast<int>(children_.size())) SortTail();
+    }
+    void SortTail() const;
     std::uint8_t color_{sayuri_go::kWall}; // side to move here; kWall while there are no children
     Status status_{kActive};
     bool expanded_{false};

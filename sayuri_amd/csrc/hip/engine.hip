@@ -150,7 +150,15 @@ static void enable_big_lds_glds() {
 //   SAYURI_HEADS_FUSED=0          conv1x1 x2 + head_tail instead of head_board_kernel
 //   SAYURI_NO_ARITH=1             board kernels read their index tables instead of computing the entries
 //   SAYURI_COMPUTE_STREAMS=2      the two tickets' forwards on two streams
-struct ConvOverride { bool v0 = false, no_board = false; int wnt = 0; };
+struct ConvOverride {
+    bool v0 = false, no_board = false;
+    int wnt = 0;
+    // The board kernel runs whenever the batch's boards fit its tiles, however empty the tiles are: which convolution kernel
+    // a sample meets must not depend on its batch mates (a lone 9x9 board fills a fifth of its tile; with the across-sample
+    // kernel it came out ~1e-4 away from the same position inside a larger batch).  SAYURI_BOARD_MIN_FILL=0.55 brings back the
+    // rule of rounds 2-4 (tiles less than 55 % full go to the across-sample kernel: half the latency of a lone small board).
+    double board_min_fill = 0.0;
+};
 struct EngineFlags {
     ConvOverride conv;
     bool tower = true, se_fused = true, heads_fused = true, arith = true;
@@ -171,6 +179,7 @@ struct EngineFlags {
             if (!strncmp(e, "v0", 2)) { f.conv.v0 = true; f.conv.no_board = true; }
             else if (!strncmp(e, "glds", 4)) { f.conv.no_board = true; (void)sscanf(e, "glds:%d", &f.conv.wnt); }
         }
+        if (const char* e = getenv("SAYURI_BOARD_MIN_FILL")) f.conv.board_min_fill = atof(e);
         f.tower = !off("SAYURI_TOWER");
         f.tower_chain = !off("SAYURI_TOWER_CHAIN");
         f.tower_gen_epi = !off("SAYURI_TOWER_GEN_EPI");
@@ -1358,7 +1367,7 @@ private:
     const BoardEntry* choose_board(const ConvLayerDev& L, int* kot_tiles) {
         if (sizeof(T) != 2 || L.k != 3) return nullptr;
         if (!board_plan_valid_) { board_plan_ = board_plan(geom_, flags_.conv); board_plan_valid_ = true; }
-        if (!board_plan_.ok || board_plan_.fill < 0.55) return nullptr;
+        if (!board_plan_.ok || board_plan_.fill < flags_.conv.board_min_fill) return nullptr;
         return pick_board(board_plan_, L.ko_pad, kot_tiles, flags_.board_kot);
     }
 
@@ -2149,9 +2158,10 @@ static int test_conv_impl(int device, int n, const int* board_sizes, int max_boa
         bool board_done = false;
         if (sizeof(T) == 2 && k == 3) {
             enable_big_lds_glds();
-            const BoardPlan plan = board_plan(hg, EngineFlags::from_env().conv);
+            const ConvOverride cov = EngineFlags::from_env().conv;
+            const BoardPlan plan = board_plan(hg, cov);
             int kot_tiles = 0;
-            const BoardEntry* be = plan.fill >= 0.55 ? pick_board(plan, ko_pad, &kot_tiles) : nullptr;
+            const BoardEntry* be = plan.fill >= cov.board_min_fill ? pick_board(plan, ko_pad, &kot_tiles) : nullptr;
             if (be) {
                 int* tsrc = (int*)dalloc(sizeof(int) * (size_t)plan.ntiles * plan.npos);
                 int2* tpix = (int2*)dalloc(sizeof(int2) * (size_t)plan.ntiles * kBoardPT);
