@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--net", default="40b384")
     ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--full", action="store_true", help="every group evaluates the WHOLE batch (G batches in flight on G streams: does a "
+                                                        "second batch hide the first one's launch boundaries and tails?) instead of 1/G of it")
+    ap.add_argument("--uniform", action="store_true", help="19x19 boards only (configs[1]'s batch) instead of the 9/13/19 mix")
     args = ap.parse_args()
     lib = _lib.hip()
     spec = {"40b384": W.spec_40b384, "20b256": W.spec_20b256}[args.net]()
@@ -44,6 +47,8 @@ def main():
     n = args.n
     rng = np.random.default_rng(5000)
     bsz = rng.choice([9, 13, 19], size=n).astype(np.int32)
+    if args.uniform:
+        bsz[:] = 19
     planes = W.synthetic_planes(n, [int(b) for b in bsz], seed=5100)
     grid = np.zeros((n, 43, 19, 19), np.float32)
     for i, (p, b) in enumerate(zip(planes, bsz)):
@@ -54,7 +59,7 @@ def main():
     for G in [int(x) for x in args.groups.split(",")]:
         pipes, ctxs, counts = [], [], []
         for g in range(G):
-            idx = order[g::G]
+            idx = order if args.full else order[g::G]
             pipe = HipForwardPipe(wpath, board_size=19, batch_size=len(idx), fp16=True)
             ctx = pipe.ctx(0)
             gg = np.ascontiguousarray(grid[idx])
@@ -82,13 +87,13 @@ def main():
                 lib.sayuri_hip_sync(c)
             el = time.perf_counter() - t0
         row = {"groups": G, "samples_per_group": counts, "ms_per_batch": round(el / args.steps * 1e3, 3),
-               "evals_per_sec": round(n * args.steps / el, 1), "device_ms_per_group_forward": [round(m.value / args.steps, 3) for m in ms]}
+               "evals_per_sec": round((G if args.full else 1) * n * args.steps / el, 1), "full_batch_per_group": bool(args.full), "device_ms_per_group_forward": [round(m.value / args.steps, 3) for m in ms]}
         print(json.dumps(row), flush=True)
         out.append(row)
         for p in pipes:
             p.Destroy()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"c5_streams_{args.net}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"c5_streams_{args.net}{'_full' if args.full else ''}.json"), "w") as f:
         json.dump(out, f, indent=1)
 
 
