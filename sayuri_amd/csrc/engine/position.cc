@@ -1,5 +1,7 @@
 #include "position.h"
 
+#include <array>
+
 #include <algorithm>
 #include <memory>
 #include <vector>
@@ -68,11 +70,31 @@ void Position::Reset(int board_size) {
 }
 
 std::uint64_t Position::SymmetryKoHash(int symm) const {
+    // = kEmptyBoard ^ XOR over the board's cells of state[cell][image of the cell].  A symmetry permutes the board's cells, so
+    // the empty cells' share is the whole board's XOR of state[kEmpty][.] (one constant per board size) with the stones' cells
+    // taken back out: the loop below only does work per STONE -- these hashes are asked for during the first board-size moves
+    // of a game (Network::ProbeCache, seven per leaf), when there are a handful.
+    static const auto empty_all = [] {
+        std::array<std::uint64_t, kMaxBoard + 1> e{};
+        const ZobristKeys& z = ZobristKeys::Get();
+        for (int bs = 1; bs <= kMaxBoard; ++bs)
+            for (int y = 0; y < bs; ++y)
+                for (int x = 0; x < bs; ++x) e[static_cast<size_t>(bs)] ^= z.state[kEmpty][(y + 1) * (bs + 2) + x + 1];
+        return e;
+    }();
     const ZobristKeys& z = ZobristKeys::Get();
     const SymmetryTables& t = SymmetryTables::Get();
-    std::uint64_t h = ZobristKeys::kEmptyBoard;
-    for (int v = 0; v < vertices_; ++v)
-        if (cell_[v] != kWall) h ^= z.state[cell_[v]][t.Vertex(size_, symm, v)];
+    std::uint64_t h = ZobristKeys::kEmptyBoard ^ empty_all[static_cast<size_t>(size_)];
+    const int w = size_ + 2;
+    for (int y = 1; y <= size_; ++y) {
+        const std::uint8_t* row = &cell_[y * w];
+        for (int x = 1; x <= size_; ++x) {
+            const int c = row[x];
+            if (c == kEmpty) continue;
+            const int sv = t.Vertex(size_, symm, y * w + x);
+            h ^= z.state[kEmpty][sv] ^ z.state[c][sv];
+        }
+    }
     return h;
 }
 
