@@ -123,15 +123,27 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
     if lib.sayuri_hip_upload(ctx, n, grid.ctypes.data_as(_lib.c_float_p), bsz.ctypes.data_as(_lib.c_int_p)):
         raise RuntimeError(lib.sayuri_hip_last_error().decode())
     ms = ctypes.c_float(0)
+    # the throughput: forwards as the engine runs them -- for this network a batch is cut into chains of per-layer launches over
+    # groups of board tiles, on streams of their own (Engine::forward: a layer of the whole batch is 450 workgroups = two rounds
+    # of the 256 CUs, the second 76 % full; chains let a group's next layer start on the CUs another group's round leaves free)
     lib.sayuri_hip_mark_kernel(ctx, b"")
     lib.sayuri_hip_time_runs(ctx, warmup, ctypes.byref(ms))
-    mark_dominant(lib, ctx)
     lib.sayuri_hip_sync(ctx)
     t0 = time.perf_counter()
     if lib.sayuri_hip_time_runs(ctx, steps, ctypes.byref(ms)):
         raise RuntimeError(lib.sayuri_hip_last_error().decode())
     lib.sayuri_hip_sync(ctx)
     el = time.perf_counter() - t0
+    chains = int(lib.sayuri_hip_last_chains(ctx))
+    # the dominant kernel's own duration: a second pass with event pairs around its launches, as ONE chain (a launch that shares
+    # the chip with another chain's has no duration of its own)
+    mark_dominant(lib, ctx)
+    lib.sayuri_hip_sync(ctx)
+    t1 = time.perf_counter()
+    if lib.sayuri_hip_time_runs(ctx, steps, ctypes.byref(ms)):
+        raise RuntimeError(lib.sayuri_hip_last_error().decode())
+    lib.sayuri_hip_sync(ctx)
+    el_one = time.perf_counter() - t1
     stat = _lib.KernelStat()
     lib.sayuri_hip_timed_stat(ctx, ctypes.byref(stat))
     pipe.Destroy()
@@ -140,6 +152,7 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
     tower_tf = (stat.flops / stat.launches) / (stat.total_ms / stat.launches * 1e-3) / 1e12 if stat.launches else None
     return {"workload": "configs[4]: 40-block x 384-filter net, fp16, batch 256 of mixed 9/13/19 boards (uniform draw, random order), "
                         "planes resident in HBM", "evals_per_sec": round(n * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+            "chains": chains, "ms_per_step_one_chain": round(el_one / steps * 1e3, 3), "evals_per_sec_one_chain": round(n * steps / el_one, 1),
             "real_pixel_fraction": round(px / (n * 361), 4), "gflop_per_batch": round(flops_batch / 1e9, 1),
             "whole_net_tflops": round(flops_batch * steps / el / 1e12, 1), "whole_net_mfma_frac": round(flops_batch * steps / el / 1e12 / 2500.0, 4),
             "tower_conv_avg_launch_us": round(stat.total_ms / max(stat.launches, 1) * 1e3, 2),

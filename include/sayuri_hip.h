@@ -170,6 +170,12 @@ void sayuri_hip_host_free(void* p);
 /* Bytes of device memory held by the ctx. */
 size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* ctx);
 
+/* How many chains the last forward of the ctx was run as (measurement / tests).  A batch whose layers are more than one
+ * round of workgroups on a network without the persistent launch (configs[4]: 40b x 384) is cut into groups of board tiles,
+ * each a chain of per-layer launches on a stream of its own -- the reference has one stream per GPU and one launch per
+ * kernel (cuda_forward_pipe.cc:713-981).  SAYURI_CHAINS=1 turns it off, =N forces N. */
+int sayuri_hip_last_chains(const sayuri_hip_ctx* ctx);
+
 /* Release everything (replaces NNGraph::DestroyGraph, cuda_forward_pipe.cc:1092-1130). */
 void sayuri_hip_destroy(sayuri_hip_ctx* ctx);
 

@@ -168,6 +168,7 @@ struct EngineFlags {
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
     int compute_streams = 1;
+    int chains = 0;                    // SAYURI_CHAINS: 0 = the engine decides, 1 = never, N = N chains whenever a batch qualifies (Engine::forward)
     bool io_inorder = true;            // each ticket's upload, forward and download on the ticket's own stream (submit()); SAYURI_IO_INORDER=0: three streams and events
     int board_kot = 0;                 // experiments: only this channel tile
     int act_override = -1;             // experiments: activation of every board convolution
@@ -192,6 +193,7 @@ struct EngineFlags {
         f.heads_fused = !off("SAYURI_HEADS_FUSED");
         f.arith = !getenv("SAYURI_NO_ARITH");
         if (const char* e = getenv("SAYURI_COMPUTE_STREAMS")) f.compute_streams = atoi(e) == 2 ? 2 : 1;
+        if (const char* e = getenv("SAYURI_CHAINS")) f.chains = std::max(0, std::min(atoi(e), 4));
         if (const char* e = getenv("SAYURI_IO_INORDER")) f.io_inorder = atoi(e) != 0;
 #ifdef SAYURI_EXPERIMENTS
         if (const char* e = getenv("SAYURI_BOARD_KOT")) f.board_kot = atoi(e);
@@ -291,13 +293,16 @@ struct BoardPlan {
     bool ok = false, single = false;  // single: one sample per tile
     int uniform_info = -1;            // every tile has this (column tiles | board size << 8), or -1
     double fill = 0;
+    std::vector<int> tile_first;      // first sample of every tile, then the number of samples (ntiles + 1 entries)
 };
 static BoardPlan board_plan(const HostGeom& geom, const ConvOverride& ov) {
     BoardPlan bp;
     if (ov.no_board || geom.n <= 0) return bp;
     BoardPack pk;
     int max_pos = 0, info0 = -2;
+    int tile_start = 0;
     auto close_tile = [&] {
+        bp.tile_first.push_back(tile_start);
         max_pos = std::max(max_pos, pk.pos);
         const int info = ((pk.px + 15) / 16) | (pk.bs0 << 8);
         info0 = info0 == -2 ? info : (info0 == info ? info0 : -1);
@@ -309,10 +314,12 @@ static BoardPlan board_plan(const HostGeom& geom, const ConvOverride& ov) {
         if (pk.cnt > 0 && !pk.fits(bs)) {
             close_tile();
             pk = BoardPack{};
+            tile_start = s;
         }
         pk.add(bs);
     }
     close_tile();
+    bp.tile_first.push_back(geom.n);
     bp.uniform_info = info0;
     bp.npos = round_up(max_pos, 64);
     bp.fill = (double)geom.total / ((double)bp.ntiles * kBoardPT);
@@ -473,6 +480,7 @@ public:
     virtual int mark_kernel(const char* name) = 0;
     virtual int timed_stat(sayuri_hip_kernel_stat* row) = 0;
     virtual size_t device_bytes() const = 0;
+    virtual int last_chains() const = 0;
 };
 
 template <typename T> class Engine : public EngineBase {
@@ -537,6 +545,50 @@ public:
         }
         const int c0 = round_up(desc_.residual_channels, 32);
         return n3 > 0 && (c0 == 256 || c0 == 128);
+    }
+
+    // -------------------------------------------------------------- chains (see forward())
+    static constexpr int kMaxChains = 4;
+    hipStream_t chain_stream_[kMaxChains] = {};
+    hipEvent_t chain_fork_ = nullptr, chain_join_[kMaxChains] = {};
+    int rg_tile0_ = 0, rg_ntiles_ = -1, rg_n0_ = 0, rg_ns_ = -1;  // the tiles / samples the launches of forward_graph() cover (-1: all)
+    int last_chains_ = 1;
+    int range_ntiles() const { return rg_ntiles_ >= 0 ? rg_ntiles_ : board_plan_.ntiles; }
+    int range_ns() const { return rg_ns_ >= 0 ? rg_ns_ : geom_.n; }
+    double range_px() const { return rg_ns_ >= 0 ? (double)(geom_.off[rg_n0_ + rg_ns_] - geom_.off[rg_n0_]) : (double)geom_.total; }
+    int chain_setup(int G) {
+        if (!chain_fork_) HIP_OK(hipEventCreateWithFlags(&chain_fork_, hipEventDisableTiming));
+        for (int g = 0; g < G; ++g) {
+            if (!chain_stream_[g]) HIP_OK(hipStreamCreateWithFlags(&chain_stream_[g], hipStreamNonBlocking));
+            if (!chain_join_[g]) HIP_OK(hipEventCreateWithFlags(&chain_join_[g], hipEventDisableTiming));
+        }
+        return 0;
+    }
+    // How many chains the current batch is run as.  A layer of a network the persistent launch does not cover is one launch of
+    // (tiles x channel tiles) workgroups of equal cost; at 450 of them (configs[4]: 150 tiles x three 128-channel tiles) the 256 CUs
+    // run two rounds, the second 76 % full, whatever the item size.  The boards of a batch are independent: cut into G groups of
+    // tiles, each a chain of per-layer launches on a stream of its own, a group's next layer starts on the CUs another group's
+    // round leaves free -- the cross-layer pipelining of a persistent (layer, tile, channel tile) run, done by the dispatcher
+    // instead of by dependency counters.  Measured from outside the engine (tools/gpu/c5_streams.py, G contexts): 24.4 k evals/s
+    // as one chain, 25.8 / 25.9 / 25.6 k as 2 / 3 / 4, 21.4 k as 6.
+    int chains_for_batch() {
+        if (sizeof(T) != 2 || flags_.chains == 1 || profiling_ || light_ || !head_img_ || !heads_fused_enabled()) return 1;
+        if (desc_.policy_head_type != 0 || tower_covers_net()) return 1;
+        for (const auto& b : blocks_)
+            if (b.type != SAYURI_BLOCK_RESIDUAL) return 1;  // every layer of the graph must be a board convolution or a per-sample kernel
+        const ConvLayerDev& L = cv(SAYURI_L_BLOCK(0, SAYURI_S_CONV1));
+        // (a network whose SE units could run inside the convolution keeps one chain: conv_se launches over the whole batch)
+        for (const auto& e : kBoardEntries)
+            if (e.fn_se && e.kot == L.ko_pad)
+                for (const auto& b : blocks_)
+                    if (b.apply_se) return 1;
+        int kts = 0;
+        if (!choose_board(L, &kts) || !board_plan_.ok) return 1;
+        const int wgs = board_plan_.ntiles * kts;
+        if (wgs <= kNumCU && flags_.chains == 0) return 1;  // one round already
+        int G = flags_.chains > 1 ? flags_.chains : std::min(kMaxChains, std::max(2, (wgs + 159) / 160));
+        G = std::min(G, board_plan_.ntiles / 8);
+        return std::max(G, 1);
     }
 
     // -------------------------------------------------------------- weights
@@ -942,6 +994,7 @@ public:
     }
 
     size_t device_bytes() const override { return dev_bytes_; }
+    int last_chains() const override { return last_chains_; }
 
 private:
     // -------------------------------------------------------------- construction helpers
@@ -1208,6 +1261,10 @@ private:
             }
         if (tower_mod_) (void)hipModuleUnload(tower_mod_);
         tower_mod_ = nullptr;
+        for (hipStream_t& cs : chain_stream_) { if (cs) (void)hipStreamDestroy(cs); cs = nullptr; }
+        for (hipEvent_t& e : chain_join_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (chain_fork_) (void)hipEventDestroy(chain_fork_);
+        chain_fork_ = nullptr;
         if (fwdstat_ && fs_cnt_[0] + fs_cnt_[1] + fs_cnt_[2] > 0) {
             const long all = fs_cnt_[0] + fs_cnt_[1] + fs_cnt_[2];
             std::fprintf(stderr, "[hip fwdstat] forwards by batch size (<= half | partial | full): %ld / %ld / %ld, mean device ms %.4f / %.4f / %.4f, tower table uploads %ld; "
@@ -1478,14 +1535,14 @@ private:
             p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
             p.g = dgeom();
             p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
-            p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = board_plan_.ntiles;
+            p.taps = 9; p.act = act; p.npos = rg_tile0_; p.num_pix_tiles = range_ntiles();  // (npos: the launch's first tile, conv_board_kernel)
 #ifdef SAYURI_EXPERIMENTS
             if (flags_.act_override >= 0) p.act = flags_.act_override;  // timing experiments only
 #endif
-            const double px = geom_.total;
+            const double px = range_px();
             const double flops = 2.0 * px * L.cin * L.cout * 9;
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
-            if (bkt == 1 && tower_ok(be->kot) && !bp.dbg) {
+            if (bkt == 1 && tower_ok(be->kot) && !bp.dbg && rg_ntiles_ < 0) {
                 if (board_row_order_ok(L, be, bp, p.act)) { p.w = L.w_board; p.bias = L.bias_board; bp.row_order = 1; }
                 BoardSeParams sp;
                 std::memset(&sp, 0, sizeof(sp));
@@ -1493,9 +1550,10 @@ private:
                 return tower_append(be->kot, sp, false, flops, bytes);
             }
             const size_t lds = be->lds(board_plan_.npos);
-            const int grid = board_plan_.ntiles * bkt;
+            const int grid = range_ntiles() * bkt;
             return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, bp); });
         }
+        if (rg_ntiles_ >= 0) return fail(std::string("chained forward: layer ") + name + " has no board kernel");
         if (const GldsChoice* gc = choose_glds(L)) {
             const TileTabs* tabs = nullptr;
             if (tile_tabs(*gc->e, &tabs)) return -1;
@@ -1546,10 +1604,10 @@ private:
     }
 
     // n0: the unit runs on the samples [n0, n) of the batch (conv_se's split of a mixed batch)
-    int se_unit(const FcLayerDev& sq, const FcLayerDev& ex, T* x, const T* res, int C, int cs, int act, int n0 = 0) {
+    int se_unit(const FcLayerDev& sq, const FcLayerDev& ex, T* x, const T* res, int C, int cs, int act, int n0 = 0, int count = -1) {
         const BatchGeom g = dgeom();
-        const int ns = geom_.n - n0;
-        const double px = geom_.total - geom_.off[n0];
+        const int ns = count >= 0 ? count : geom_.n - n0;
+        const double px = geom_.off[n0 + ns] - geom_.off[n0];
         constexpr int EPP = ElemTraits<T>::kPieceElems;
         if (cs / EPP > 256) return fail("SE unit: more than 256*8 channels is not supported");
         if (timed("se_pool", 2.0 * px * C, sizeof(T) * px * C, [&] {
@@ -1585,7 +1643,39 @@ private:
     const FcLayerDev& fc(int id) const { return fcs_.at(id); }
 
     // -------------------------------------------------------------- the graph
+    // One forward of the current batch: as ONE chain of launches on stream_, or -- chains_for_batch() -- as G chains over G
+    // ranges of tiles on G streams, forked from and joined to stream_ by events (the activations, tables and outputs of the
+    // ranges are disjoint: a tile is whole samples).
     int forward() {
+        const int G = chains_for_batch();
+        last_chains_ = G;
+        if (G <= 1) return forward_graph();
+        if (chain_setup(G)) return -1;
+        const BoardTabs* tabs = nullptr;
+        if (board_tabs(&tabs)) return -1;  // built on stream_, in front of the fork
+        hipStream_t main = stream_;
+        HIP_OK(hipEventRecord(chain_fork_, main));
+        int rc = 0;
+        const int nt = board_plan_.ntiles;
+        for (int g = 0; g < G && rc == 0; ++g) {
+            rg_tile0_ = (int)((long)nt * g / G);
+            rg_ntiles_ = (int)((long)nt * (g + 1) / G) - rg_tile0_;
+            rg_n0_ = board_plan_.tile_first[rg_tile0_];
+            rg_ns_ = board_plan_.tile_first[rg_tile0_ + rg_ntiles_] - rg_n0_;
+            stream_ = chain_stream_[g];
+            hipError_t e = hipStreamWaitEvent(stream_, chain_fork_, 0);
+            if (e == hipSuccess) rc = forward_graph();
+            if (e == hipSuccess && rc == 0) e = hipEventRecord(chain_join_[g], stream_);
+            if (e != hipSuccess) rc = fail(std::string("chained forward: ") + hipGetErrorString(e));
+        }
+        stream_ = main;
+        rg_tile0_ = 0; rg_ntiles_ = -1; rg_n0_ = 0; rg_ns_ = -1;
+        if (rc) return rc;
+        for (int g = 0; g < G; ++g) HIP_OK(hipStreamWaitEvent(main, chain_join_[g], 0));
+        return 0;
+    }
+
+    int forward_graph() {
         const auto& d = desc_;
         const int C = d.residual_channels, csC = round_up(C, 32), act = d.default_act;
         const BatchGeom g = dgeom();
@@ -1599,17 +1689,18 @@ private:
         {
             const ConvLayerDev& L = cv(SAYURI_L_INPUT_CONV);
             const int in = take();
-            const int grid = geom_.n * kPackSplit;  // kPackSplit workgroups per sample
-            const double px = geom_.total;
+            const int n0 = rg_n0_, ns = range_ns();
+            const int grid = ns * kPackSplit;  // kPackSplit workgroups per sample
+            const double px = range_px();
             T* dst = bufs_[in];
             const int cin = d.input_channels, cs = L.cin_s, board = board_;
             const IoSlot& io = io_[cur_slot_];
             if (io.packed_binary > 0) {
                 const unsigned* rec = io.packed;
                 const int nbin = io.packed_binary, words = nbin * 12 + 8;
-                if (timed("pack_input", 0, (double)geom_.n * words * 4 + px * cs * sizeof(T), [&] {
+                if (timed("pack_input", 0, (double)ns * words * 4 + px * cs * sizeof(T), [&] {
                         hipLaunchKernelGGL(pack_bits_kernel<T>, dim3(grid), dim3(256), 0, stream_, rec, words, nbin, dst, g, cin, cs,
-                                           (const int*)d_perm_);
+                                           (const int*)d_perm_, n0);
                     }))
                     return -1;
             } else {
@@ -1620,11 +1711,11 @@ private:
                 const bool flat = flat_lds <= 64 * 1024 && (size_t)cin * board * board < 65536;
                 if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
                         if (flat)
-                            hipLaunchKernelGGL(pack_input_flat_kernel<T>, dim3(geom_.n), dim3(kPackFlatThreads), flat_lds, stream_,
-                                               (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_);
+                            hipLaunchKernelGGL(pack_input_flat_kernel<T>, dim3(ns), dim3(kPackFlatThreads), flat_lds, stream_,
+                                               (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_, n0);
                         else
                             hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(kPackThreads), lds, stream_,
-                                               (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_, chunk);
+                                               (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_, chunk, n0);
                     }))
                     return -1;
             }
@@ -1681,7 +1772,7 @@ private:
             }
             if (se && !se_done) {
                 if (se_unit(fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)), fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[y],
-                            bufs_[skip], C, csC, act))
+                            bufs_[skip], C, csC, act, rg_n0_, range_ns()))
                     return -1;
             }
             give(x);
@@ -1714,14 +1805,17 @@ private:
             }
 #endif
             hp.trunk = bufs_[x]; hp.w = head_img_; hp.w2 = head_img2_; hp.bias = head_bias_; hp.g = g; hp.cs = csC; hp.PT = head_pt_; hp.VT = head_vt_; hp.h = h;
+            hp.n0 = rg_n0_;
             const auto fn = head_fn_;
             {
-                const double flops = 2.0 * geom_.total * C * (Cp + Cv);
-                return timed("heads_fused", flops, (double)geom_.total * csC * 2, [&] {
-                    hipLaunchKernelGGL(fn, dim3(geom_.n), dim3(512), kMaxLds, stream_, hp);
+                const int ns = range_ns();
+                const double flops = 2.0 * range_px() * C * (Cp + Cv);
+                return timed("heads_fused", flops, range_px() * csC * 2, [&] {
+                    hipLaunchKernelGGL(fn, dim3(ns), dim3(512), kMaxLds, stream_, hp);
                 });
             }
         }
+        if (rg_ns_ >= 0) return fail("chained forward reached the separate head kernels");
         int pb = take();
         const int vb = take();
         if (conv("conv1x1_head", cv(SAYURI_L_P_HD_CONV), bufs_[x], bufs_[pb], nullptr, act)) return -1;
@@ -2046,6 +2140,7 @@ void sayuri_hip_host_free(void* p) {
 }
 
 size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->device_bytes() : 0; }
+int sayuri_hip_last_chains(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->last_chains() : 0; }
 
 void sayuri_hip_destroy(sayuri_hip_ctx* ctx) { delete ctx; }
 

@@ -29,6 +29,7 @@ struct HeadBoardParams {
     int PT, VT;           // policy / value rows, each a multiple of 16 (>= Cp / Cv)
     HeadParams h;         // FCs, per-pixel weights, outputs, perm, act (small_ops.h)
     unsigned long long* dbg;  // SAYURI_HEADS_DBG: s_memtime stamps of workgroups 0-3, wave 0 ([wg][8])
+    int n0;                   // first sample of the launch (a chain of the batch, Engine::forward)
 };
 
 // floats of the small-vector area at the END of the LDS (outside the rings):
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(512) void head_board_kernel(const HeadBoardParams h
     constexpr int ROWS = RT * 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = blockIdx.x;
+    const int n = hp.n0 + blockIdx.x;
     const int bs = hp.g.bsz[n], npix = bs * bs;
     const int nchunks = hp.cs / kChunk;
 

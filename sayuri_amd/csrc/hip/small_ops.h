@@ -26,10 +26,10 @@ constexpr int kPackSplit = 4;  // workgroups per sample (pixel ranges): several 
 template <typename T>
 __global__ __launch_bounds__(kPackThreads) void pack_input_kernel(const float* __restrict__ planes, T* __restrict__ out,
                                                                   BatchGeom g, int cin, int cs, int board, const int* __restrict__ perm,
-                                                                  int chunk) {
+                                                                  int chunk, int n0 = 0) {  // n0: first sample of the launch
     constexpr int EPP = ElemTraits<T>::kPieceElems;
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
-    const int n = blockIdx.x / kPackSplit, part = blockIdx.x % kPackSplit, tid = threadIdx.x;
+    const int n = n0 + blockIdx.x / kPackSplit, part = blockIdx.x % kPackSplit, tid = threadIdx.x;
     const int bs = g.bsz[n], npix = bs * bs, ppr = cs / EPP, stride = cs * (int)sizeof(T) + 16;
     const int per = (npix + kPackSplit - 1) / kPackSplit, pbeg = part * per, pend = min(npix, pbeg + per);
     const size_t B2 = (size_t)board * board;
@@ -78,10 +78,10 @@ constexpr int kPackFlatLoads = 32;  // x 512 threads = 16 384 floats per pass (4
 template <typename T>
 __global__ __launch_bounds__(kPackFlatThreads) void pack_input_flat_kernel(const float* __restrict__ planes, T* __restrict__ out,
                                                                             BatchGeom g, int cin, int cs, int board,
-                                                                            const int* __restrict__ perm) {
+                                                                            const int* __restrict__ perm, int n0 = 0) {
     constexpr int EPP = ElemTraits<T>::kPieceElems;
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n = n0 + blockIdx.x, tid = threadIdx.x;
     const int bs = g.bsz[n], npix = bs * bs, ppr = cs / EPP, stride = cs * (int)sizeof(T) + 16;
     const int B2 = board * board, total = cin * B2;
     const float* src = planes + (size_t)(perm ? perm[n] : n) * total;  // perm: device sample -> caller's slot
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(256) void geom_stage_kernel(const int* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void pack_bits_kernel(const unsigned* __restrict__ records, int rec_words, int nbin,
                                                         T* __restrict__ out, BatchGeom g, int cin, int cs,
-                                                        const int* __restrict__ perm) {
+                                                        const int* __restrict__ perm, int n0 = 0) {
     constexpr int EPP = ElemTraits<T>::kPieceElems;
     __shared__ unsigned rec[40 * 13 + 8];  // 13 words per plane: the eight planes a wave reads at once fall on different banks
-    const int n = blockIdx.x / kPackSplit, part = blockIdx.x % kPackSplit, tid = threadIdx.x;
+    const int n = n0 + blockIdx.x / kPackSplit, part = blockIdx.x % kPackSplit, tid = threadIdx.x;
     const int bs = g.bsz[n], npix = bs * bs, ppr = cs / EPP;
     const int per = (npix + kPackSplit - 1) / kPackSplit, pbeg = part * per, pend = min(npix, pbeg + per);
     const unsigned* src = records + (size_t)(perm ? perm[n] : n) * rec_words;  // perm: device sample -> caller's slot

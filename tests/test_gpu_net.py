@@ -461,6 +461,46 @@ def test_config5_full_mixed_batch_40b384(fp16, tmp_weights_dir):
         pipe.Destroy()
 
 
+def test_chained_forward_gives_identical_outputs(tmp_weights_dir, monkeypatch):
+    """configs[4]: a batch whose layers are more than one round of workgroups (40b x 384: 150 board tiles x 3 channel tiles on
+    256 CUs) is run as chains of per-layer launches over groups of tiles on streams of their own (Engine::forward); the chains
+    cover disjoint tiles with the same kernels, so the outputs are BIT-identical to the one-chain forward -- for the default
+    choice, for two and for four chains, for a batch too small to be cut, and through submit / wait with two tickets in flight
+    (the queue's path)."""
+    from sayuri_amd import _lib
+    from sayuri_amd.pipe import hip_forward_raw
+    g = Golden("net_40b384", tmp_weights_dir)
+    rng = np.random.default_rng(56)
+    B = 19
+    outs, chains = {}, {}
+    for n in (256, 40):
+        bsz = [int(b) for b in rng.choice([9, 13, 19], size=n)]
+        planes = W.synthetic_planes(n, bsz, seed=5600 + n)
+        grid = np.zeros((n, 43, B * B), np.float32)
+        for i, (p, bs) in enumerate(zip(planes, bsz)):
+            grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+        for mode in ("1", "0", "2", "4"):
+            monkeypatch.setenv("SAYURI_CHAINS", mode)
+            pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=256, fp16=True)
+            try:
+                outs[(n, mode)] = hip_forward_raw(pipe.ctx(0), grid, bsz, B)
+                chains[(n, mode)] = _lib.hip().sayuri_hip_last_chains(pipe.ctx(0))
+                if mode == "0" and n == 256:
+                    q = pipe.BatchForward(planes, bsz)   # the same batch through the pump (submit / wait)
+                    raw = outs[(n, "1")]
+                    for i in (0, 100, 255):
+                        s = bsz[i] * bsz[i]
+                        assert np.array_equal(q[i][:s], raw[0][i, 0].reshape(B, B)[:bsz[i], :bsz[i]].ravel()), i
+            finally:
+                pipe.Destroy()
+        for mode in ("0", "2", "4"):
+            for a, b, what in zip(outs[(n, "1")], outs[(n, mode)], ("prob", "pass", "misc", "own")):
+                assert np.array_equal(a, b), (n, mode, what)
+        assert np.abs(outs[(n, "1")][0]).max() > 0
+    assert chains[(256, "1")] == 1 and chains[(256, "0")] == 3 and chains[(256, "2")] == 2 and chains[(256, "4")] == 4, chains
+    assert chains[(40, "0")] == 1, chains   # 24 tiles x 3 = 72 workgroups: one round, nothing to fill
+
+
 def test_fp16_error_is_measured_on_64_positions(tmp_weights_dir):
     """The fp16 gate is a measurement, not a guess: 64 positions of the 20b256 network against the reference's outputs
     (tests/golden/net_20b256_x64.npz).  Records max-abs error on the raw outputs and the reference's own SelfCheck L2
