@@ -123,9 +123,9 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
     if lib.sayuri_hip_upload(ctx, n, grid.ctypes.data_as(_lib.c_float_p), bsz.ctypes.data_as(_lib.c_int_p)):
         raise RuntimeError(lib.sayuri_hip_last_error().decode())
     ms = ctypes.c_float(0)
-    # the throughput: forwards as the engine runs them -- for this network a batch is cut into chains of per-layer launches over
-    # groups of board tiles, on streams of their own (Engine::forward: a layer of the whole batch is 450 workgroups = two rounds
-    # of the 256 CUs, the second 76 % full; chains let a group's next layer start on the CUs another group's round leaves free)
+    # the throughput: forwards as the engine runs them (one chain of launches per forward: cutting the batch into chains over
+    # groups of board tiles on streams of their own, SAYURI_CHAINS=3, measured +9.6 % here and is off by default because the
+    # overlapping chains do not reproduce the one-chain forward's bits -- DESIGN.md section 10)
     lib.sayuri_hip_mark_kernel(ctx, b"")
     lib.sayuri_hip_time_runs(ctx, warmup, ctypes.byref(ms))
     lib.sayuri_hip_sync(ctx)

@@ -165,10 +165,11 @@ struct EngineFlags {
     bool se_by_geometry = true;        // which samples take the fused SE form depends on their board size alone (conv_se); SAYURI_SE_BY_GEOMETRY=0: on the tiles' occupancy
     bool io_v2 = true;                 // SAYURI_IO_V2=0: geometry / small outputs by copies again (A/B; see submit())
     bool io_zc = true, io_geom = true, io_prefix = true;  // its three parts, one at a time (SAYURI_IO_ZC / _GEOM / _PREFIX = 0)
+    bool no_exclusive = false;         // SAYURI_NO_EXCLUSIVE=1: tower launches that do not own the chip may overlap the other ticket's kernels again (A/B)
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
     int compute_streams = 1;
-    int chains = 0;                    // SAYURI_CHAINS: 0 = the engine decides, 1 = never, N = N chains whenever a batch qualifies (Engine::forward)
+    int chains = 1;                    // SAYURI_CHAINS=N (2..4): N chains whenever a batch qualifies (Engine::forward); default 1 = never
     bool io_inorder = true;            // each ticket's upload, forward and download on the ticket's own stream (submit()); SAYURI_IO_INORDER=0: three streams and events
     int board_kot = 0;                 // experiments: only this channel tile
     int act_override = -1;             // experiments: activation of every board convolution
@@ -183,6 +184,7 @@ struct EngineFlags {
         if (const char* e = getenv("SAYURI_BOARD_MIN_FILL")) f.conv.board_min_fill = atof(e);
         f.tower = !off("SAYURI_TOWER");
         f.tower_chain = !off("SAYURI_TOWER_CHAIN");
+        f.no_exclusive = getenv("SAYURI_NO_EXCLUSIVE") != nullptr;
         f.tower_gen_epi = !off("SAYURI_TOWER_GEN_EPI");
         f.io_v2 = !off("SAYURI_IO_V2");
         f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");
@@ -193,7 +195,7 @@ struct EngineFlags {
         f.heads_fused = !off("SAYURI_HEADS_FUSED");
         f.arith = !getenv("SAYURI_NO_ARITH");
         if (const char* e = getenv("SAYURI_COMPUTE_STREAMS")) f.compute_streams = atoi(e) == 2 ? 2 : 1;
-        if (const char* e = getenv("SAYURI_CHAINS")) f.chains = std::max(0, std::min(atoi(e), 4));
+        if (const char* e = getenv("SAYURI_CHAINS")) f.chains = std::max(1, std::min(atoi(e), 4));
         if (const char* e = getenv("SAYURI_IO_INORDER")) f.io_inorder = atoi(e) != 0;
 #ifdef SAYURI_EXPERIMENTS
         if (const char* e = getenv("SAYURI_BOARD_KOT")) f.board_kot = atoi(e);
@@ -572,7 +574,10 @@ public:
     // instead of by dependency counters.  Measured from outside the engine (tools/gpu/c5_streams.py, G contexts): 24.4 k evals/s
     // as one chain, 25.8 / 25.9 / 25.6 k as 2 / 3 / 4, 21.4 k as 6.
     int chains_for_batch() {
-        if (sizeof(T) != 2 || flags_.chains == 1 || profiling_ || light_ || !head_img_ || !heads_fused_enabled()) return 1;
+        // OFF unless asked for (SAYURI_CHAINS=N, N >= 2): measured +9.6 % on configs[4], but the chained forward does not give
+        // the one-chain forward's BITS when its chains really overlap (a few dozen samples per batch ~1e-4 off; bit-identical
+        // when the chains run one after another, SAYURI_CHAINS_SERIAL=1) -- DESIGN.md section 10.
+        if (sizeof(T) != 2 || flags_.chains <= 1 || profiling_ || light_ || !head_img_ || !heads_fused_enabled()) return 1;
         if (desc_.policy_head_type != 0 || tower_covers_net()) return 1;
         for (const auto& b : blocks_)
             if (b.type != SAYURI_BLOCK_RESIDUAL) return 1;  // every layer of the graph must be a board convolution or a per-sample kernel
@@ -585,8 +590,8 @@ public:
         int kts = 0;
         if (!choose_board(L, &kts) || !board_plan_.ok) return 1;
         const int wgs = board_plan_.ntiles * kts;
-        if (wgs <= kNumCU && flags_.chains == 0) return 1;  // one round already
-        int G = flags_.chains > 1 ? flags_.chains : std::min(kMaxChains, std::max(2, (wgs + 159) / 160));
+        if (wgs <= kNumCU) return 1;  // one round already
+        int G = flags_.chains;
         G = std::min(G, board_plan_.ntiles / 8);
         return std::max(G, 1);
     }
@@ -663,6 +668,20 @@ public:
         // So nothing small is copied any more: the heads kernel stores pass / misc straight into the caller's pinned
         // buffers (20 KB of posted PCIe writes), a uniform batch uses geometry arrays that are resident (enqueue_inputs),
         // and the tower table does not depend on the batch size (tower_append).  The two large outputs keep their DMA copies.
+        // The persistent launch beside another launch.  A batch of 256 one-board tiles owns every CU, and whatever the other
+        // ticket has queued runs before or after it.  A launch with fewer (or more) workgroups than CUs -- a mixed-size batch,
+        // a partial batch -- shares the chip with the other ticket's kernels for its whole length, and then its results are
+        // no longer the bits the same batch gives alone (measured: 141 of 256 samples of a mixed batch ~1e-4 off in 3 of 12
+        // batches, the workgroups that started late; two launch-per-layer forwards side by side stay exact;
+        // tools/gpu/concurrent_ctx_dbg.py).  Such a forward therefore runs alone: it waits for the other
+        // ticket's forward, and the other ticket's next forward waits for it (the copies of both still overlap).
+        bool exclusive = false;
+        if (inorder && sizeof(T) == 2 && tower_fn_[0] && tower_covers_net() && !flags_.no_exclusive) {
+            if (!board_plan_valid_) { board_plan_ = board_plan(geom_, flags_.conv); board_plan_valid_ = true; }
+            exclusive = !board_plan_.ok || board_plan_.ntiles % kNumCU != 0;
+        }
+        if (inorder && (exclusive || last_exclusive_[t ^ 1]) && fwd_recorded_[t ^ 1]) HIP_OK(hipStreamWaitEvent(stream_, fwd_done_[t ^ 1], 0));
+        last_exclusive_[t] = exclusive;
         zc_pass_ = flags_.io_zc ? zc_device_pointer(pass) : nullptr;
         zc_misc_ = zc_pass_ ? zc_device_pointer(misc) : nullptr;
         if (!zc_misc_) zc_pass_ = nullptr;  // both or neither: the heads kernel takes one path
@@ -679,6 +698,9 @@ public:
         if (!inorder) {
             HIP_OK(hipEventRecord(fwd_done_[t], stream_));
             HIP_OK(hipStreamWaitEvent(d2h_stream_, fwd_done_[t], 0));
+        } else if (tower_covers_net()) {  // (one marker per batch: an exclusive forward of the other ticket will wait for it)
+            HIP_OK(hipEventRecord(fwd_done_[t], stream_));
+            fwd_recorded_[t] = true;
         }
         const size_t B2 = (size_t)board_ * board_;
         HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, down));
@@ -1664,6 +1686,8 @@ private:
             rg_ns_ = board_plan_.tile_first[rg_tile0_ + rg_ntiles_] - rg_n0_;
             stream_ = chain_stream_[g];
             hipError_t e = hipStreamWaitEvent(stream_, chain_fork_, 0);
+            static const bool serial = std::getenv("SAYURI_CHAINS_SERIAL") != nullptr;  // debugging aid: the chains one after another
+            if (serial && g > 0 && e == hipSuccess) e = hipStreamWaitEvent(stream_, chain_join_[g - 1], 0);
             if (e == hipSuccess) rc = forward_graph();
             if (e == hipSuccess && rc == 0) e = hipEventRecord(chain_join_[g], stream_);
             if (e != hipSuccess) rc = fail(std::string("chained forward: ") + hipGetErrorString(e));
@@ -1953,6 +1977,7 @@ private:
     hipStream_t stream_ = nullptr, h2d_stream_ = nullptr, d2h_stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     hipEvent_t h2d_done_[2] = {nullptr, nullptr}, fwd_done_[2] = {nullptr, nullptr};
+    bool last_exclusive_[2] = {false, false}, fwd_recorded_[2] = {false, false};  // submit(): forwards that must not share the chip
     // device-side batch i/o, one set per ticket; the d_* members below alias the slot the current forward uses
     struct IoSlot {
         float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;

@@ -461,44 +461,51 @@ def test_config5_full_mixed_batch_40b384(fp16, tmp_weights_dir):
         pipe.Destroy()
 
 
-def test_chained_forward_gives_identical_outputs(tmp_weights_dir, monkeypatch):
+def test_chained_forward(tmp_weights_dir, monkeypatch):
     """configs[4]: a batch whose layers are more than one round of workgroups (40b x 384: 150 board tiles x 3 channel tiles on
-    256 CUs) is run as chains of per-layer launches over groups of tiles on streams of their own (Engine::forward); the chains
-    cover disjoint tiles with the same kernels, so the outputs are BIT-identical to the one-chain forward -- for the default
-    choice, for two and for four chains, for a batch too small to be cut, and through submit / wait with two tickets in flight
-    (the queue's path)."""
+    256 CUs) CAN be run as chains of per-layer launches over groups of tiles on streams of their own (Engine::forward,
+    SAYURI_CHAINS=N; +9.6 % on the bench's configs[4] batch).  It is OFF by default, and this test pins why: the chains cover
+    disjoint tiles with the same kernels and give the one-chain forward's bits when they run one after another
+    (SAYURI_CHAINS_SERIAL=1), but NOT always when they overlap on the chip -- then a few dozen samples of a batch come out
+    ~1e-4 away (inside the fp16 gate, outside bit-identity)."""
     from sayuri_amd import _lib
     from sayuri_amd.pipe import hip_forward_raw
     g = Golden("net_40b384", tmp_weights_dir)
     rng = np.random.default_rng(56)
-    B = 19
-    outs, chains = {}, {}
-    for n in (256, 40):
-        bsz = [int(b) for b in rng.choice([9, 13, 19], size=n)]
-        planes = W.synthetic_planes(n, bsz, seed=5600 + n)
-        grid = np.zeros((n, 43, B * B), np.float32)
-        for i, (p, bs) in enumerate(zip(planes, bsz)):
-            grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
-        for mode in ("1", "0", "2", "4"):
-            monkeypatch.setenv("SAYURI_CHAINS", mode)
-            pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=256, fp16=True)
-            try:
-                outs[(n, mode)] = hip_forward_raw(pipe.ctx(0), grid, bsz, B)
-                chains[(n, mode)] = _lib.hip().sayuri_hip_last_chains(pipe.ctx(0))
-                if mode == "0" and n == 256:
-                    q = pipe.BatchForward(planes, bsz)   # the same batch through the pump (submit / wait)
-                    raw = outs[(n, "1")]
-                    for i in (0, 100, 255):
-                        s = bsz[i] * bsz[i]
-                        assert np.array_equal(q[i][:s], raw[0][i, 0].reshape(B, B)[:bsz[i], :bsz[i]].ravel()), i
-            finally:
-                pipe.Destroy()
-        for mode in ("0", "2", "4"):
-            for a, b, what in zip(outs[(n, "1")], outs[(n, mode)], ("prob", "pass", "misc", "own")):
-                assert np.array_equal(a, b), (n, mode, what)
-        assert np.abs(outs[(n, "1")][0]).max() > 0
-    assert chains[(256, "1")] == 1 and chains[(256, "0")] == 3 and chains[(256, "2")] == 2 and chains[(256, "4")] == 4, chains
-    assert chains[(40, "0")] == 1, chains   # 24 tiles x 3 = 72 workgroups: one round, nothing to fill
+    B, n = 19, 256
+    bsz = [int(b) for b in rng.choice([9, 13, 19], size=n)]
+    planes = W.synthetic_planes(n, bsz, seed=5600 + n)
+    grid = np.zeros((n, 43, B * B), np.float32)
+    for i, (p, bs) in enumerate(zip(planes, bsz)):
+        grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+
+    def run(env, reps=2):
+        for k in ("SAYURI_CHAINS", "SAYURI_CHAINS_SERIAL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=256, fp16=True)
+        try:
+            outs = [hip_forward_raw(pipe.ctx(0), grid, bsz, B) for _ in range(reps)]
+            return outs, _lib.hip().sayuri_hip_last_chains(pipe.ctx(0))
+        finally:
+            pipe.Destroy()
+
+    ref, chains = run({})
+    assert chains == 1, "chains must be off unless asked for"
+    assert all(np.array_equal(a, b) for a, b in zip(ref[0], ref[1]))
+    for G in ("2", "3"):
+        serial, chains = run({"SAYURI_CHAINS": G, "SAYURI_CHAINS_SERIAL": "1"}, reps=3)
+        assert chains == int(G)
+        for o in serial:
+            for a, b, what in zip(ref[0], o, ("prob", "pass", "misc", "own")):
+                assert np.array_equal(a, b), (G, "serial", what)
+        overlapped, chains = run({"SAYURI_CHAINS": G}, reps=3)
+        assert chains == int(G)
+        scale = max(1.0, float(np.abs(ref[0][0]).max()))
+        for o in overlapped:
+            for a, b, what in zip(ref[0], o, ("prob", "pass", "misc", "own")):
+                assert np.isfinite(b).all() and float(np.abs(a - b).max()) <= FP16_ATOL * scale, (G, "overlapped", what)
 
 
 def test_fp16_error_is_measured_on_64_positions(tmp_weights_dir):
