@@ -65,7 +65,9 @@ def hbm_traffic(fp16: bool, dominant: str) -> dict:
     (counters cannot be read from inside this process; MI355X_MICROARCH.md HBM section: separate --pmc passes, requests x
     calibrated bytes per request).  Round 4: the passes run on the persistent tower launch itself (conv_tower_kernel<4>;
     rounds 2-3 had to sum per-layer launches).  `traffic_source` names the file, its age and the commit it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))
+    path = found[-1] if found else os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")  # the latest round's passes
     layer_algo = 2 * 256 * 361 * 256 * 2 + 256 * 256 * 9 * 2  # in + out + weights of one 256->256 layer, fp16, batch 256
     if not fp16 or dominant != "tower_run" or not os.path.exists(path):
         return {"traffic": None, "algorithmic_bytes": layer_algo}
@@ -123,9 +125,10 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
     if lib.sayuri_hip_upload(ctx, n, grid.ctypes.data_as(_lib.c_float_p), bsz.ctypes.data_as(_lib.c_int_p)):
         raise RuntimeError(lib.sayuri_hip_last_error().decode())
     ms = ctypes.c_float(0)
-    # the throughput: forwards as the engine runs them (one chain of launches per forward: cutting the batch into chains over
-    # groups of board tiles on streams of their own, SAYURI_CHAINS=3, measured +9.6 % here and is off by default because the
-    # overlapping chains do not reproduce the one-chain forward's bits -- DESIGN.md section 10)
+    # the throughput: forwards as the engine runs them -- for this network a batch is cut into chains of per-layer launches over
+    # groups of board tiles, on streams and in activation buffers of their own (Engine::forward: a layer of the whole batch is 450
+    # workgroups = two rounds of the 256 CUs, the second 76 % full; chains let a group's next layer start on the CUs another
+    # group's round leaves free; bit-identical to the one-chain forward, tests/test_gpu_net.py::test_chained_forward)
     lib.sayuri_hip_mark_kernel(ctx, b"")
     lib.sayuri_hip_time_runs(ctx, warmup, ctypes.byref(ms))
     lib.sayuri_hip_sync(ctx)

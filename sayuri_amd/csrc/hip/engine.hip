@@ -169,7 +169,7 @@ struct EngineFlags {
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
     int compute_streams = 1;
-    int chains = 1;                    // SAYURI_CHAINS=N (2..4): N chains whenever a batch qualifies (Engine::forward); default 1 = never
+    int chains = 0;                    // SAYURI_CHAINS: 0 = the engine decides, 1 = never, N = N chains whenever a batch qualifies (Engine::forward)
     bool io_inorder = true;            // each ticket's upload, forward and download on the ticket's own stream (submit()); SAYURI_IO_INORDER=0: three streams and events
     int board_kot = 0;                 // experiments: only this channel tile
     int act_override = -1;             // experiments: activation of every board convolution
@@ -195,7 +195,7 @@ struct EngineFlags {
         f.heads_fused = !off("SAYURI_HEADS_FUSED");
         f.arith = !getenv("SAYURI_NO_ARITH");
         if (const char* e = getenv("SAYURI_COMPUTE_STREAMS")) f.compute_streams = atoi(e) == 2 ? 2 : 1;
-        if (const char* e = getenv("SAYURI_CHAINS")) f.chains = std::max(1, std::min(atoi(e), 4));
+        if (const char* e = getenv("SAYURI_CHAINS")) f.chains = std::max(0, std::min(atoi(e), 4));
         if (const char* e = getenv("SAYURI_IO_INORDER")) f.io_inorder = atoi(e) != 0;
 #ifdef SAYURI_EXPERIMENTS
         if (const char* e = getenv("SAYURI_BOARD_KOT")) f.board_kot = atoi(e);
@@ -531,7 +531,11 @@ public:
         // must have a channel tile that covers the layer (tower_ok: 256 or 128 padded output channels).  A 384- or
         // 192-channel network has the code object loaded and still runs one launch per layer.
         if (describe_layers()) return -1;
-        inorder_ = flags_.io_inorder && tower_fn_[0] != nullptr && tower_covers_net();
+        // (round 5, networks the launch does not cover: 40b x 384 through submit / wait, two tickets in flight -- a stream per ticket
+        // 26.3 k evals/s, one compute stream 23.7 k: a layer is 450 workgroups, two rounds of the CUs, and the other ticket's
+        // launches fill the second; 200 batches bit-identical to the solo result, tools/gpu/c5_pump.py, concurrent_ctx_dbg.py.
+        // The 48.0 k vs 54.0 k above was round 1's 482-workgroup kernel on the 256-channel network.)
+        inorder_ = flags_.io_inorder && tower_fn_[0] != nullptr;
         if (flags_.compute_streams == 2 || inorder_) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
         return 0;
     }
@@ -553,6 +557,7 @@ public:
     static constexpr int kMaxChains = 4;
     hipStream_t chain_stream_[kMaxChains] = {};
     hipEvent_t chain_fork_ = nullptr, chain_join_[kMaxChains] = {};
+    T* chain_bufs_[kMaxChains][6] = {};  // chains g >= 1 keep their activations in buffers of their own (SAYURI_CHAINS_OWN_BUFS=0: shared)
     int rg_tile0_ = 0, rg_ntiles_ = -1, rg_n0_ = 0, rg_ns_ = -1;  // the tiles / samples the launches of forward_graph() cover (-1: all)
     int last_chains_ = 1;
     int range_ntiles() const { return rg_ntiles_ >= 0 ? rg_ntiles_ : board_plan_.ntiles; }
@@ -574,10 +579,11 @@ public:
     // instead of by dependency counters.  Measured from outside the engine (tools/gpu/c5_streams.py, G contexts): 24.4 k evals/s
     // as one chain, 25.8 / 25.9 / 25.6 k as 2 / 3 / 4, 21.4 k as 6.
     int chains_for_batch() {
-        // OFF unless asked for (SAYURI_CHAINS=N, N >= 2): measured +9.6 % on configs[4], but the chained forward does not give
-        // the one-chain forward's BITS when its chains really overlap (a few dozen samples per batch ~1e-4 off; bit-identical
-        // when the chains run one after another, SAYURI_CHAINS_SERIAL=1) -- DESIGN.md section 10.
-        if (sizeof(T) != 2 || flags_.chains <= 1 || profiling_ || light_ || !head_img_ || !heads_fused_enabled()) return 1;
+        // Every chain but the first keeps its activations in buffers of its own.  With the chains in ONE set of buffers (disjoint
+        // rows of them: a tile is whole samples) the overlapping chains did not reproduce the one-chain forward's bits -- a few
+        // dozen samples per batch ~1e-4 off in two runs of three, bit-identical when the chains ran one after another
+        // (SAYURI_CHAINS_SERIAL=1) -- with their own buffers they do (tools/gpu/chains_dbg.py).
+        if (sizeof(T) != 2 || flags_.chains == 1 || profiling_ || light_ || !head_img_ || !heads_fused_enabled()) return 1;
         if (desc_.policy_head_type != 0 || tower_covers_net()) return 1;
         for (const auto& b : blocks_)
             if (b.type != SAYURI_BLOCK_RESIDUAL) return 1;  // every layer of the graph must be a board convolution or a per-sample kernel
@@ -591,7 +597,7 @@ public:
         if (!choose_board(L, &kts) || !board_plan_.ok) return 1;
         const int wgs = board_plan_.ntiles * kts;
         if (wgs <= kNumCU) return 1;  // one round already
-        int G = flags_.chains;
+        int G = flags_.chains > 1 ? flags_.chains : std::min(kMaxChains, std::max(2, (wgs + 159) / 160));
         G = std::min(G, board_plan_.ntiles / 8);
         return std::max(G, 1);
     }
@@ -1685,12 +1691,27 @@ private:
             rg_n0_ = board_plan_.tile_first[rg_tile0_];
             rg_ns_ = board_plan_.tile_first[rg_tile0_ + rg_ntiles_] - rg_n0_;
             stream_ = chain_stream_[g];
+            static const bool own_bufs = !EngineFlags::off("SAYURI_CHAINS_OWN_BUFS");
+            T* saved[kNumBufs];
+            for (int i = 0; i < kNumBufs; ++i) saved[i] = bufs_[i];
+            if (own_bufs && g > 0) {
+                const size_t act_elems = (size_t)max_batch_ * slot_pix_ * cs_max_;
+                for (int i = 0; i < kNumBufs; ++i) {
+                    if (!chain_bufs_[g][i]) {
+                        if (dev_alloc(&chain_bufs_[g][i], act_elems + kZeroPrefix / sizeof(T))) { rc = -1; break; }
+                        chain_bufs_[g][i] += kZeroPrefix / sizeof(T);
+                    }
+                    bufs_[i] = chain_bufs_[g][i];
+                }
+                if (rc) break;
+            }
             hipError_t e = hipStreamWaitEvent(stream_, chain_fork_, 0);
             static const bool serial = std::getenv("SAYURI_CHAINS_SERIAL") != nullptr;  // debugging aid: the chains one after another
             if (serial && g > 0 && e == hipSuccess) e = hipStreamWaitEvent(stream_, chain_join_[g - 1], 0);
             if (e == hipSuccess) rc = forward_graph();
             if (e == hipSuccess && rc == 0) e = hipEventRecord(chain_join_[g], stream_);
             if (e != hipSuccess) rc = fail(std::string("chained forward: ") + hipGetErrorString(e));
+            for (int i = 0; i < kNumBufs; ++i) bufs_[i] = saved[i];
         }
         stream_ = main;
         rg_tile0_ = 0; rg_ntiles_ = -1; rg_n0_ = 0; rg_ns_ = -1;

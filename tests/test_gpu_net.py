@@ -463,11 +463,13 @@ def test_config5_full_mixed_batch_40b384(fp16, tmp_weights_dir):
 
 def test_chained_forward(tmp_weights_dir, monkeypatch):
     """configs[4]: a batch whose layers are more than one round of workgroups (40b x 384: 150 board tiles x 3 channel tiles on
-    256 CUs) CAN be run as chains of per-layer launches over groups of tiles on streams of their own (Engine::forward,
-    SAYURI_CHAINS=N; +9.6 % on the bench's configs[4] batch).  It is OFF by default, and this test pins why: the chains cover
-    disjoint tiles with the same kernels and give the one-chain forward's bits when they run one after another
-    (SAYURI_CHAINS_SERIAL=1), but NOT always when they overlap on the chip -- then a few dozen samples of a batch come out
-    ~1e-4 away (inside the fp16 gate, outside bit-identity)."""
+    256 CUs) is run as chains of per-layer launches over groups of tiles, each on a stream of its own and -- all but the first --
+    in activation buffers of its own (Engine::forward; +9.6 % on the bench's configs[4] batch).  The chains cover disjoint tiles
+    with the same kernels: the outputs must be the one-chain forward's BITS, for the engine's own choice (three chains here),
+    for two and four, run after run, and through the queue.  What this test also pins is why the buffers are per chain: with
+    the chains in ONE set of buffers (SAYURI_CHAINS_OWN_BUFS=0) overlapping chains came out ~1e-4 off for a few dozen samples in
+    two runs of three -- there only the fp16 gate is asserted -- and bit-identical again when run one after another
+    (SAYURI_CHAINS_SERIAL=1)."""
     from sayuri_amd import _lib
     from sayuri_amd.pipe import hip_forward_raw
     g = Golden("net_40b384", tmp_weights_dir)
@@ -478,34 +480,50 @@ def test_chained_forward(tmp_weights_dir, monkeypatch):
     grid = np.zeros((n, 43, B * B), np.float32)
     for i, (p, bs) in enumerate(zip(planes, bsz)):
         grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+    switches = ("SAYURI_CHAINS", "SAYURI_CHAINS_SERIAL", "SAYURI_CHAINS_OWN_BUFS")
 
-    def run(env, reps=2):
-        for k in ("SAYURI_CHAINS", "SAYURI_CHAINS_SERIAL"):
+    def run(env, reps=2, queue=False):
+        for k in switches:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=256, fp16=True)
         try:
             outs = [hip_forward_raw(pipe.ctx(0), grid, bsz, B) for _ in range(reps)]
-            return outs, _lib.hip().sayuri_hip_last_chains(pipe.ctx(0))
+            chains = _lib.hip().sayuri_hip_last_chains(pipe.ctx(0))
+            q = pipe.BatchForward(planes, bsz) if queue else None
+            return outs, chains, q
         finally:
             pipe.Destroy()
 
-    ref, chains = run({})
-    assert chains == 1, "chains must be off unless asked for"
-    assert all(np.array_equal(a, b) for a, b in zip(ref[0], ref[1]))
-    for G in ("2", "3"):
-        serial, chains = run({"SAYURI_CHAINS": G, "SAYURI_CHAINS_SERIAL": "1"}, reps=3)
-        assert chains == int(G)
-        for o in serial:
+    ref, chains, q1 = run({"SAYURI_CHAINS": "1"}, queue=True)
+    assert chains == 1 and all(np.array_equal(a, b) for a, b in zip(ref[0], ref[1]))
+    for env, want in (({}, 3), ({"SAYURI_CHAINS": "2"}, 2), ({"SAYURI_CHAINS": "4"}, 4), ({"SAYURI_CHAINS": "3", "SAYURI_CHAINS_OWN_BUFS": "0", "SAYURI_CHAINS_SERIAL": "1"}, 3)):
+        outs, chains, q = run(env, reps=6, queue=not env)
+        assert chains == want, (env, chains)
+        for o in outs:
             for a, b, what in zip(ref[0], o, ("prob", "pass", "misc", "own")):
-                assert np.array_equal(a, b), (G, "serial", what)
-        overlapped, chains = run({"SAYURI_CHAINS": G}, reps=3)
-        assert chains == int(G)
-        scale = max(1.0, float(np.abs(ref[0][0]).max()))
-        for o in overlapped:
-            for a, b, what in zip(ref[0], o, ("prob", "pass", "misc", "own")):
-                assert np.isfinite(b).all() and float(np.abs(a - b).max()) <= FP16_ATOL * scale, (G, "overlapped", what)
+                assert np.array_equal(a, b), (env, what, float(np.abs(a - b).max()))
+        if q is not None:   # the same batch through the pump (submit / wait)
+            assert all(np.array_equal(x, y) for x, y in zip(q1, q))
+    shared, chains, _ = run({"SAYURI_CHAINS": "3", "SAYURI_CHAINS_OWN_BUFS": "0"}, reps=3)
+    scale = max(1.0, float(np.abs(ref[0][0]).max()))
+    for o in shared:
+        for a, b in zip(ref[0], o):
+            assert np.isfinite(b).all() and float(np.abs(a - b).max()) <= FP16_ATOL * scale
+    small = [int(b) for b in rng.choice([9, 13, 19], size=40)]   # 24 tiles x 3 = 72 workgroups: one round, nothing to fill
+    pl = W.synthetic_planes(40, small, seed=77)
+    gr = np.zeros((40, 43, B * B), np.float32)
+    for i, (p, bs) in enumerate(zip(pl, small)):
+        gr[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+    for k in switches:
+        monkeypatch.delenv(k, raising=False)
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=256, fp16=True)
+    try:
+        hip_forward_raw(pipe.ctx(0), gr, small, B)
+        assert _lib.hip().sayuri_hip_last_chains(pipe.ctx(0)) == 1
+    finally:
+        pipe.Destroy()
 
 
 def test_fp16_error_is_measured_on_64_positions(tmp_weights_dir):

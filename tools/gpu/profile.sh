@@ -2,7 +2,7 @@
 # Evidence pass of a round on one box (TAG=r03 ...): GPU suite, kernel-trace stats, PMC passes (one counter set per run,
 # --kernel-trace only), HBM-side traffic with calibration streams, the default bench line, configs[4], fp32.
 cd "$GRAFT_REPO_ROOT" || exit 1
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 O=gpurun_out/$TAG
 mkdir -p $O/prof
 export TMPDIR=/tmp
