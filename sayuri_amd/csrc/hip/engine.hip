@@ -686,7 +686,9 @@ public:
             if (!board_plan_valid_) { board_plan_ = board_plan(geom_, flags_.conv); board_plan_valid_ = true; }
             exclusive = !board_plan_.ok || board_plan_.ntiles % kNumCU != 0;
         }
-        if (inorder && (exclusive || last_exclusive_[t ^ 1]) && fwd_recorded_[t ^ 1]) HIP_OK(hipStreamWaitEvent(stream_, fwd_done_[t ^ 1], 0));
+        // (the other ticket's completion event: recorded by every submit behind its downloads, so the common case -- two full
+        // batches of one-board tiles -- pays no extra marker; the ~30 us of its output copies that the wait includes do not show)
+        if (inorder && (exclusive || last_exclusive_[t ^ 1]) && tick_ev_[t ^ 1]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t ^ 1], 0));
         last_exclusive_[t] = exclusive;
         zc_pass_ = flags_.io_zc ? zc_device_pointer(pass) : nullptr;
         zc_misc_ = zc_pass_ ? zc_device_pointer(misc) : nullptr;
@@ -704,9 +706,6 @@ public:
         if (!inorder) {
             HIP_OK(hipEventRecord(fwd_done_[t], stream_));
             HIP_OK(hipStreamWaitEvent(d2h_stream_, fwd_done_[t], 0));
-        } else if (tower_covers_net()) {  // (one marker per batch: an exclusive forward of the other ticket will wait for it)
-            HIP_OK(hipEventRecord(fwd_done_[t], stream_));
-            fwd_recorded_[t] = true;
         }
         const size_t B2 = (size_t)board_ * board_;
         HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, down));
@@ -1998,7 +1997,7 @@ private:
     hipStream_t stream_ = nullptr, h2d_stream_ = nullptr, d2h_stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     hipEvent_t h2d_done_[2] = {nullptr, nullptr}, fwd_done_[2] = {nullptr, nullptr};
-    bool last_exclusive_[2] = {false, false}, fwd_recorded_[2] = {false, false};  // submit(): forwards that must not share the chip
+    bool last_exclusive_[2] = {false, false};  // submit(): forwards that must not share the chip
     // device-side batch i/o, one set per ticket; the d_* members below alias the slot the current forward uses
     struct IoSlot {
         float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;
