@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/sp
 if [ -z "$SKIP_LONG" ]; then
-SAYURI_MEMSTAT=1 timeout 1800 python tools/selfplay_bench.py --seconds 1620 --games 512 --num-games 100000 2> gpurun_out/sp/long.err | tail -1 > gpurun_out/sp/${TAG:-r05}_selfplay_27min_512games.json
+SAYURI_MEMSTAT=1 timeout 2100 python tools/selfplay_bench.py --seconds 1620 --games 512 --num-games 100000 2> gpurun_out/sp/long.err | tail -1 > gpurun_out/sp/${TAG:-r05}_selfplay_27min_512games.json
 python -c "
 import json
 d=json.load(open('gpurun_out/sp/${TAG:-r05}_selfplay_27min_512games.json'))
