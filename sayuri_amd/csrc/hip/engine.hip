@@ -483,6 +483,7 @@ public:
     virtual int timed_stat(sayuri_hip_kernel_stat* row) = 0;
     virtual size_t device_bytes() const = 0;
     virtual int last_chains() const = 0;
+    virtual int debug_read(int buf, void* host, size_t bytes) = 0;  // debugging tap: activation buffer `buf` of ticket 0
 };
 
 template <typename T> class Engine : public EngineBase {
@@ -1022,6 +1023,14 @@ public:
 
     size_t device_bytes() const override { return dev_bytes_; }
     int last_chains() const override { return last_chains_; }
+    int debug_read(int buf, void* host, size_t bytes) override {
+        if (buf < 0 || buf >= kNumBufs || !io_[0].bufs[buf]) return fail("debug_read: no such buffer");
+        HIP_OK(hipSetDevice(device_));
+        HIP_OK(hipDeviceSynchronize());
+        const size_t have = (size_t)max_batch_ * slot_pix_ * cs_max_ * sizeof(T);
+        HIP_OK(hipMemcpy(host, io_[0].bufs[buf], std::min(bytes, have), hipMemcpyDeviceToHost));
+        return 0;
+    }
 
 private:
     // -------------------------------------------------------------- construction helpers
@@ -2186,6 +2195,10 @@ void sayuri_hip_host_free(void* p) {
 
 size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->device_bytes() : 0; }
 int sayuri_hip_last_chains(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->last_chains() : 0; }
+// debugging tap (not part of the ABI, not in the header): activation buffer `buf` (0..5) of ticket 0 as it stands after the last forward
+extern "C" int sayuri_hip_debug_read_activations(sayuri_hip_ctx* ctx, int buf, void* host, size_t bytes) {
+    return ctx ? ctx->eng->debug_read(buf, host, bytes) : -1;
+}
 
 void sayuri_hip_destroy(sayuri_hip_ctx* ctx) { delete ctx; }
 
