@@ -76,5 +76,15 @@ def run(env, reps):
 REF = run({"SAYURI_CHAINS": "1"}, 1)
 REFB = REF[0][1]
 print("reference buffers in use:", [int((b != 0).any()) for b in REFB])
-run({"SAYURI_CHAINS": "3", "SAYURI_CHAINS_OWN_BUFS": "0"}, reps)
+if "own" in sys.argv:   # every chain but the first in buffers of its own: outputs only (ticket 0's buffers hold chain 0's rows)
+    os.environ.pop("SAYURI_CHAINS_OWN_BUFS", None); os.environ["SAYURI_CHAINS"] = "3"
+    pipe = HipForwardPipe(wpath, board_size=B, batch_size=256, fp16=True)
+    bad = 0
+    for r in range(reps):
+        o = hip_forward_raw(pipe.ctx(0), grid, bsz, B)
+        bad += not all(np.array_equal(a, b) for a, b in zip(REF[0][0], o))
+    print(f"own buffers: {bad} of {reps} forwards differ from the one-chain outputs ({lib.sayuri_hip_last_chains(pipe.ctx(0))} chains)")
+    pipe.Destroy()
+else:
+    run({"SAYURI_CHAINS": "3", "SAYURI_CHAINS_OWN_BUFS": "0"}, reps)
 print("done")
