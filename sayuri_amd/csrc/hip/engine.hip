@@ -561,6 +561,7 @@ public:
     T* chain_bufs_[kMaxChains][6] = {};  // chains g >= 1 keep their activations in buffers of their own (SAYURI_CHAINS_OWN_BUFS=0: shared)
     int rg_tile0_ = 0, rg_ntiles_ = -1, rg_n0_ = 0, rg_ns_ = -1;  // the tiles / samples the launches of forward_graph() cover (-1: all)
     int last_chains_ = 1;
+    bool solo_forward_ = true;  // submit(): false while the other ticket's batch is still in flight
     int range_ntiles() const { return rg_ntiles_ >= 0 ? rg_ntiles_ : board_plan_.ntiles; }
     int range_ns() const { return rg_ns_ >= 0 ? rg_ns_ : geom_.n; }
     double range_px() const { return rg_ns_ >= 0 ? (double)(geom_.off[rg_n0_ + rg_ns_] - geom_.off[rg_n0_]) : (double)geom_.total; }
@@ -584,6 +585,10 @@ public:
         // rows of them: a tile is whole samples) the overlapping chains did not reproduce the one-chain forward's bits -- a few
         // dozen samples per batch ~1e-4 off in two runs of three, bit-identical when the chains ran one after another
         // (SAYURI_CHAINS_SERIAL=1) -- with their own buffers they do (tools/gpu/chains_dbg.py).
+        // Only for a forward that runs alone: with the other ticket's batch in flight the stream per ticket already fills the
+        // rounds (26.3 k evals/s against 25.9 k with chains on top, tools/gpu/c5_pump.py), and the chains' own activation buffers
+        // belong to one forward at a time.
+        if (!solo_forward_) return 1;
         if (sizeof(T) != 2 || flags_.chains == 1 || profiling_ || light_ || !head_img_ || !heads_fused_enabled()) return 1;
         if (desc_.policy_head_type != 0 || tower_covers_net()) return 1;
         for (const auto& b : blocks_)
@@ -691,10 +696,12 @@ public:
         // batches of one-board tiles -- pays no extra marker; the ~30 us of its output copies that the wait includes do not show)
         if (inorder && (exclusive || last_exclusive_[t ^ 1]) && tick_ev_[t ^ 1]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t ^ 1], 0));
         last_exclusive_[t] = exclusive;
+        solo_forward_ = !tick_ev_[t ^ 1] || hipEventQuery(tick_ev_[t ^ 1]) == hipSuccess;
         zc_pass_ = flags_.io_zc ? zc_device_pointer(pass) : nullptr;
         zc_misc_ = zc_pass_ ? zc_device_pointer(misc) : nullptr;
         if (!zc_misc_) zc_pass_ = nullptr;  // both or neither: the heads kernel takes one path
         const int frc = forward();
+        solo_forward_ = true;
         const bool small_direct = zc_pass_ != nullptr;
         zc_pass_ = zc_misc_ = nullptr;
         if (frc) return -1;
