@@ -175,3 +175,46 @@ def test_bench_two_ranks_on_the_fake_device(tmp_path):
     sp = d["selfplay"]
     assert sp["exchange_rounds"] > 0 and sp["nn_evals_per_sec"] > 0 and sp["moves_per_sec"] > 0 and not sp["halt_seen"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_exchange_round_that_misses_its_deadline_gloo_world2(tmp_path):
+    """PeriodicGather never blocks its caller for longer than its deadline: a round whose peer is late stays in flight, the
+    caller goes on with the last completed totals, the next tick collects it first (no new round beside a pending one, so the
+    two ranks' sequences of collectives stay identical), and drain() ends with every round landed on both ranks.  Rank 1 is
+    0.6 s late to every tick, the deadline is 0.15 s: every round of rank 0 is a late one."""
+    script = tmp_path / "late.py"
+    script.write_text(
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from sayuri_amd.shard import PeriodicGather\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "pg = PeriodicGather(timeout=0.15)\n"
+        "blocked = []\n"
+        "for k in range(5):\n"
+        "    if r == 1: time.sleep(0.6)\n"
+        "    t0 = time.perf_counter()\n"
+        "    pg.tick({'games_done': k + 1, 'nn_queries': 100 * (k + 1) * (r + 1), 'elapsed': float(k)}, halt=(r == 1 and k == 3))\n"
+        "    blocked.append(time.perf_counter() - t0)\n"
+        "    if r == 0: time.sleep(0.6)\n"
+        "tot = pg.drain({'games_done': 6, 'nn_queries': 600 * (r + 1), 'elapsed': 9.0})\n"
+        "assert pg._inflight is None and pg.all_done\n"
+        "assert tot['games_done'] == 12 and tot['nn_queries'] == 1800 and tot['done'] == 2, tot\n"
+        "assert pg.any_halt, 'rank 1 raised its wish in round 3: both ranks must have seen it'\n"
+        "if r == 0:\n"
+        "    assert max(blocked) < 0.5, blocked            # never the peer's 0.6 s\n"
+        "    assert pg.late_rounds >= 3, (pg.late_rounds, pg.latencies_ms)\n"
+        "    assert max(pg.latencies_ms) > 300.0           # issue -> landed of a late round is the peer's delay\n"
+        "s = pg.latency_summary()\n"
+        "assert s['rounds'] == pg.rounds == len(pg.latencies_ms) and s['backend'] == 'gloo' and s['world'] == 2\n"
+        "rounds = torch.tensor([pg.rounds]); both = [torch.zeros_like(rounds) for _ in range(w)]\n"
+        "dist.all_gather(both, rounds)\n"
+        "assert int(both[0]) == int(both[1]), both          # the same number of collectives on both ranks\n"
+        "if r == 0: print('OK', pg.rounds, pg.late_rounds, pg.skipped_ticks)\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
