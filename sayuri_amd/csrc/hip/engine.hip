@@ -165,7 +165,6 @@ struct EngineFlags {
     bool se_by_geometry = true;        // which samples take the fused SE form depends on their board size alone (conv_se); SAYURI_SE_BY_GEOMETRY=0: on the tiles' occupancy
     bool io_v2 = true;                 // SAYURI_IO_V2=0: geometry / small outputs by copies again (A/B; see submit())
     bool io_zc = true, io_geom = true, io_prefix = true;  // its three parts, one at a time (SAYURI_IO_ZC / _GEOM / _PREFIX = 0)
-    bool no_exclusive = false;         // SAYURI_NO_EXCLUSIVE=1: tower launches that do not own the chip may overlap the other ticket's kernels again (A/B)
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
     int compute_streams = 1;
@@ -184,7 +183,6 @@ struct EngineFlags {
         if (const char* e = getenv("SAYURI_BOARD_MIN_FILL")) f.conv.board_min_fill = atof(e);
         f.tower = !off("SAYURI_TOWER");
         f.tower_chain = !off("SAYURI_TOWER_CHAIN");
-        f.no_exclusive = getenv("SAYURI_NO_EXCLUSIVE") != nullptr;
         f.tower_gen_epi = !off("SAYURI_TOWER_GEN_EPI");
         f.io_v2 = !off("SAYURI_IO_V2");
         f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");
@@ -558,7 +556,6 @@ public:
     static constexpr int kMaxChains = 4;
     hipStream_t chain_stream_[kMaxChains] = {};
     hipEvent_t chain_fork_ = nullptr, chain_join_[kMaxChains] = {};
-    T* chain_bufs_[kMaxChains][6] = {};  // chains g >= 1 keep their activations in buffers of their own (SAYURI_CHAINS_OWN_BUFS=0: shared)
     int rg_tile0_ = 0, rg_ntiles_ = -1, rg_n0_ = 0, rg_ns_ = -1;  // the tiles / samples the launches of forward_graph() cover (-1: all)
     int last_chains_ = 1;
     bool solo_forward_ = true;  // submit(): false while the other ticket's batch is still in flight
@@ -581,14 +578,10 @@ public:
     // instead of by dependency counters.  Measured from outside the engine (tools/gpu/c5_streams.py, G contexts): 24.4 k evals/s
     // as one chain, 25.8 / 25.9 / 25.6 k as 2 / 3 / 4, 21.4 k as 6.
     int chains_for_batch() {
-        // Every chain but the first keeps its activations in buffers of its own.  With the chains in ONE set of buffers (disjoint
-        // rows of them: a tile is whole samples) the overlapping chains did not reproduce the one-chain forward's bits -- a few
-        // dozen samples per batch ~1e-4 off in two runs of three, bit-identical when the chains ran one after another
-        // (SAYURI_CHAINS_SERIAL=1) -- with their own buffers they do (tools/gpu/chains_dbg.py).
-        // Only for a forward that runs alone: with the other ticket's batch in flight the stream per ticket already fills the
-        // rounds (26.3 k evals/s against 25.9 k with chains on top, tools/gpu/c5_pump.py), and the chains' own activation buffers
-        // belong to one forward at a time.
-        if (!solo_forward_) return 1;
+        // The chains share the forward's activation buffers: a tile is whole samples, every layer of a network that qualifies has
+        // ONE channel stride, and the packed input keeps a buffer of its own (forward_graph), so the chains' rows are disjoint
+        // bytes in every buffer.  (The first version recycled the packed input's buffer, whose rows have another stride: a chain
+        // that ran ahead overwrote a later chain's input -- a few dozen samples per batch off in two runs of three.)
         if (sizeof(T) != 2 || flags_.chains == 1 || profiling_ || light_ || !head_img_ || !heads_fused_enabled()) return 1;
         if (desc_.policy_head_type != 0 || tower_covers_net()) return 1;
         for (const auto& b : blocks_)
@@ -680,22 +673,6 @@ public:
         // So nothing small is copied any more: the heads kernel stores pass / misc straight into the caller's pinned
         // buffers (20 KB of posted PCIe writes), a uniform batch uses geometry arrays that are resident (enqueue_inputs),
         // and the tower table does not depend on the batch size (tower_append).  The two large outputs keep their DMA copies.
-        // The persistent launch beside another launch.  A batch of 256 one-board tiles owns every CU, and whatever the other
-        // ticket has queued runs before or after it.  A launch with fewer (or more) workgroups than CUs -- a mixed-size batch,
-        // a partial batch -- shares the chip with the other ticket's kernels for its whole length, and then its results are
-        // no longer the bits the same batch gives alone (measured: 141 of 256 samples of a mixed batch ~1e-4 off in 3 of 12
-        // batches, the workgroups that started late; two launch-per-layer forwards side by side stay exact;
-        // tools/gpu/concurrent_ctx_dbg.py).  Such a forward therefore runs alone: it waits for the other
-        // ticket's forward, and the other ticket's next forward waits for it (the copies of both still overlap).
-        bool exclusive = false;
-        if (inorder && sizeof(T) == 2 && tower_fn_[0] && tower_covers_net() && !flags_.no_exclusive) {
-            if (!board_plan_valid_) { board_plan_ = board_plan(geom_, flags_.conv); board_plan_valid_ = true; }
-            exclusive = !board_plan_.ok || board_plan_.ntiles % kNumCU != 0;
-        }
-        // (the other ticket's completion event: recorded by every submit behind its downloads, so the common case -- two full
-        // batches of one-board tiles -- pays no extra marker; the ~30 us of its output copies that the wait includes do not show)
-        if (inorder && (exclusive || last_exclusive_[t ^ 1]) && tick_ev_[t ^ 1]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t ^ 1], 0));
-        last_exclusive_[t] = exclusive;
         solo_forward_ = !tick_ev_[t ^ 1] || hipEventQuery(tick_ev_[t ^ 1]) == hipSuccess;
         zc_pass_ = flags_.io_zc ? zc_device_pointer(pass) : nullptr;
         zc_misc_ = zc_pass_ ? zc_device_pointer(misc) : nullptr;
@@ -1706,27 +1683,12 @@ private:
             rg_n0_ = board_plan_.tile_first[rg_tile0_];
             rg_ns_ = board_plan_.tile_first[rg_tile0_ + rg_ntiles_] - rg_n0_;
             stream_ = chain_stream_[g];
-            static const bool own_bufs = !EngineFlags::off("SAYURI_CHAINS_OWN_BUFS");
-            T* saved[kNumBufs];
-            for (int i = 0; i < kNumBufs; ++i) saved[i] = bufs_[i];
-            if (own_bufs && g > 0) {
-                const size_t act_elems = (size_t)max_batch_ * slot_pix_ * cs_max_;
-                for (int i = 0; i < kNumBufs; ++i) {
-                    if (!chain_bufs_[g][i]) {
-                        if (dev_alloc(&chain_bufs_[g][i], act_elems + kZeroPrefix / sizeof(T))) { rc = -1; break; }
-                        chain_bufs_[g][i] += kZeroPrefix / sizeof(T);
-                    }
-                    bufs_[i] = chain_bufs_[g][i];
-                }
-                if (rc) break;
-            }
             hipError_t e = hipStreamWaitEvent(stream_, chain_fork_, 0);
             static const bool serial = std::getenv("SAYURI_CHAINS_SERIAL") != nullptr;  // debugging aid: the chains one after another
             if (serial && g > 0 && e == hipSuccess) e = hipStreamWaitEvent(stream_, chain_join_[g - 1], 0);
             if (e == hipSuccess) rc = forward_graph();
             if (e == hipSuccess && rc == 0) e = hipEventRecord(chain_join_[g], stream_);
             if (e != hipSuccess) rc = fail(std::string("chained forward: ") + hipGetErrorString(e));
-            for (int i = 0; i < kNumBufs; ++i) bufs_[i] = saved[i];
         }
         stream_ = main;
         rg_tile0_ = 0; rg_ntiles_ = -1; rg_n0_ = 0; rg_ns_ = -1;
@@ -1780,7 +1742,15 @@ private:
                     return -1;
             }
             if (conv("conv3x3_input", L, bufs_[in], bufs_[x], nullptr, act)) return -1;
-            give(in);
+            // `in` is NOT handed back: it stays the packed input's buffer for the whole forward.  Its rows have the input
+            // convolution's channel stride (64), every later buffer the tower's (256 / 384): recycled as a block's output, sample
+            // m's rows would lie on top of sample n's packed input.  With a kernel boundary between every two layers and one
+            // stream that is harmless.  Inside the persistent launch it is not -- a workgroup's layers follow one another with no
+            // grid-wide order, and a workgroup that STARTS LATE (more tiles than CUs, or the chip shared with another ticket's
+            // kernels) found its packed input overwritten by an early workgroup's third layer -- and across the chains of one
+            // forward neither.  Rounds 3-4 recycled it: every full-chip launch won that race by a wide margin (all 256 workgroups
+            // start together, the input is read within the first ~80 us and overwritten after ~170), which is why it took round
+            // 5's bit-level harness to see it (tools/gpu/concurrent_ctx_dbg.py, chains_layers_dbg.py).
         }
 
         for (int b = 0; b < d.residual_blocks; ++b) {
@@ -2013,7 +1983,6 @@ private:
     hipStream_t stream_ = nullptr, h2d_stream_ = nullptr, d2h_stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     hipEvent_t h2d_done_[2] = {nullptr, nullptr}, fwd_done_[2] = {nullptr, nullptr};
-    bool last_exclusive_[2] = {false, false};  // submit(): forwards that must not share the chip
     // device-side batch i/o, one set per ticket; the d_* members below alias the slot the current forward uses
     struct IoSlot {
         float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;

@@ -463,13 +463,12 @@ def test_config5_full_mixed_batch_40b384(fp16, tmp_weights_dir):
 
 def test_chained_forward(tmp_weights_dir, monkeypatch):
     """configs[4]: a batch whose layers are more than one round of workgroups (40b x 384: 150 board tiles x 3 channel tiles on
-    256 CUs) is run as chains of per-layer launches over groups of tiles, each on a stream of its own and -- all but the first --
-    in activation buffers of its own (Engine::forward; +9.6 % on the bench's configs[4] batch).  The chains cover disjoint tiles
-    with the same kernels: the outputs must be the one-chain forward's BITS, for the engine's own choice (three chains here),
-    for two and four, run after run, and through the queue.  What this test also pins is why the buffers are per chain: with
-    the chains in ONE set of buffers (SAYURI_CHAINS_OWN_BUFS=0) overlapping chains came out ~1e-4 off for a few dozen samples in
-    two runs of three -- there only the fp16 gate is asserted -- and bit-identical again when run one after another
-    (SAYURI_CHAINS_SERIAL=1)."""
+    256 CUs) is run as chains of per-layer launches over groups of tiles, each on a stream of its own (Engine::forward; +6...10 %
+    on the bench's configs[4] batch).  The chains cover disjoint tiles with the same kernels in the same buffers: the outputs must
+    be the one-chain forward's BITS, for the engine's own choice (three chains here), for two and four, run after run, and through
+    the queue.  (Round 5's first version failed exactly this -- a few dozen samples ~1e-4 off in two runs of three: the packed
+    input's buffer, whose rows have the input convolution's channel stride, was recycled as a tower buffer, and a chain that ran
+    ahead overwrote a later chain's input.  It now keeps a buffer of its own for the whole forward.)"""
     from sayuri_amd import _lib
     from sayuri_amd.pipe import hip_forward_raw
     g = Golden("net_40b384", tmp_weights_dir)
@@ -480,7 +479,7 @@ def test_chained_forward(tmp_weights_dir, monkeypatch):
     grid = np.zeros((n, 43, B * B), np.float32)
     for i, (p, bs) in enumerate(zip(planes, bsz)):
         grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
-    switches = ("SAYURI_CHAINS", "SAYURI_CHAINS_SERIAL", "SAYURI_CHAINS_OWN_BUFS")
+    switches = ("SAYURI_CHAINS", "SAYURI_CHAINS_SERIAL")
 
     def run(env, reps=2, queue=False):
         for k in switches:
@@ -498,19 +497,15 @@ def test_chained_forward(tmp_weights_dir, monkeypatch):
 
     ref, chains, q1 = run({"SAYURI_CHAINS": "1"}, queue=True)
     assert chains == 1 and all(np.array_equal(a, b) for a, b in zip(ref[0], ref[1]))
-    for env, want in (({}, 3), ({"SAYURI_CHAINS": "2"}, 2), ({"SAYURI_CHAINS": "4"}, 4), ({"SAYURI_CHAINS": "3", "SAYURI_CHAINS_OWN_BUFS": "0", "SAYURI_CHAINS_SERIAL": "1"}, 3)):
-        outs, chains, q = run(env, reps=6, queue=not env)
+    assert np.abs(ref[0][0]).max() > 0
+    for env, want in (({}, 3), ({"SAYURI_CHAINS": "2"}, 2), ({"SAYURI_CHAINS": "4"}, 4), ({"SAYURI_CHAINS": "3", "SAYURI_CHAINS_SERIAL": "1"}, 3)):
+        outs, chains, q = run(env, reps=8, queue=not env)
         assert chains == want, (env, chains)
         for o in outs:
             for a, b, what in zip(ref[0], o, ("prob", "pass", "misc", "own")):
                 assert np.array_equal(a, b), (env, what, float(np.abs(a - b).max()))
         if q is not None:   # the same batch through the pump (submit / wait)
             assert all(np.array_equal(x, y) for x, y in zip(q1, q))
-    shared, chains, _ = run({"SAYURI_CHAINS": "3", "SAYURI_CHAINS_OWN_BUFS": "0"}, reps=3)
-    scale = max(1.0, float(np.abs(ref[0][0]).max()))
-    for o in shared:
-        for a, b in zip(ref[0], o):
-            assert np.isfinite(b).all() and float(np.abs(a - b).max()) <= FP16_ATOL * scale
     small = [int(b) for b in rng.choice([9, 13, 19], size=40)]   # 24 tiles x 3 = 72 workgroups: one round, nothing to fill
     pl = W.synthetic_planes(40, small, seed=77)
     gr = np.zeros((40, 43, B * B), np.float32)
@@ -523,6 +518,96 @@ def test_chained_forward(tmp_weights_dir, monkeypatch):
         hip_forward_raw(pipe.ctx(0), gr, small, B)
         assert _lib.hip().sayuri_hip_last_chains(pipe.ctx(0)) == 1
     finally:
+        pipe.Destroy()
+
+
+def test_persistent_launch_with_more_tiles_than_cus(tmp_weights_dir):
+    """The persistent tower launch has no grid-wide order between its workgroups' layers: a workgroup of the SECOND round starts
+    when one of the first has walked the whole tower.  That is only sound if no workgroup ever writes bytes another one still has
+    to read -- and rounds 3-4 broke it: the packed input's buffer (channel stride 64) was recycled as a tower buffer (stride
+    256), so an early workgroup's third layer lay on top of a late workgroup's packed input.  Full-chip launches (256 tiles,
+    all started together) won that race every time; 320 boards = 320 workgroups on 256 CUs lose it deterministically.  Every
+    sample of the 320-batch must be bit-equal to the same position in a batch of 160."""
+    from sayuri_amd.pipe import hip_forward_raw
+    g = Golden("net_20b256", tmp_weights_dir)
+    B, n = 19, 320
+    planes = W.synthetic_planes(n, B, seed=3200)
+    grid = np.ascontiguousarray(np.stack(planes), np.float32)
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=n, fp16=True)
+    try:
+        ctx = pipe.ctx(0)
+        big = hip_forward_raw(ctx, grid, [B] * n, B)
+        assert all(np.isfinite(x).all() for x in big) and np.abs(big[0]).max() > 0
+        for lo in (0, 160):
+            part = hip_forward_raw(ctx, grid[lo:lo + 160], [B] * 160, B)
+            for a, b, what in zip(big, part, ("prob", "pass", "misc", "own")):
+                bad = [i for i in range(160) if not np.array_equal(a[lo + i], b[i])]
+                assert not bad, (what, lo, len(bad), bad[:8])
+    finally:
+        pipe.Destroy()
+
+
+def test_two_tickets_in_flight_give_the_solo_bits(tmp_weights_dir):
+    """submit / wait with two batches in flight (what the pump does), a MIXED-size batch on the 20b x 256 network: its
+    persistent launches have 150 workgroups, so the other ticket's kernels run beside them and workgroups start late.  Every
+    batch must come back with the bits the same batch gives alone (round 4's engine: 3 batches of 100 off, the 141 samples of the
+    late workgroups -- the recycled input buffer of the test above)."""
+    import ctypes
+    from sayuri_amd import _lib
+    from sayuri_amd.pipe import hip_forward_raw
+    g = Golden("net_20b256", tmp_weights_dir)
+    rng = np.random.default_rng(56)
+    B, n = 19, 256
+    bsz = [int(b) for b in rng.choice([9, 13, 19], size=n)]
+    planes = W.synthetic_planes(n, bsz, seed=5856)
+    grid = np.zeros((n, 43, B * B), np.float32)
+    for i, (p, bs) in enumerate(zip(planes, bsz)):
+        grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+    lib = _lib.hip()
+    FP = ctypes.POINTER(ctypes.c_float)
+    lib.sayuri_hip_host_alloc.restype = ctypes.c_void_p
+    lib.sayuri_hip_host_alloc.argtypes = [ctypes.c_size_t]
+    lib.sayuri_hip_host_free.argtypes = [ctypes.c_void_p]
+    lib.sayuri_hip_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, FP, ctypes.POINTER(ctypes.c_int), FP, FP, FP, FP, ctypes.POINTER(ctypes.c_int)]
+    lib.sayuri_hip_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=n, fp16=True)
+    raw = []
+    try:
+        ctx = pipe.ctx(0)
+        ref = hip_forward_raw(ctx, grid, bsz, B)
+        sizes = (grid.size, n * 5 * B * B, n * 5, n * 15, n * B * B)
+        bufs = []
+        for _ in range(2):
+            ptrs = [lib.sayuri_hip_host_alloc(k * 4) for k in sizes]
+            raw += ptrs
+            np.ctypeslib.as_array(ctypes.cast(ptrs[0], FP), (grid.size,))[:] = grid.ravel()
+            bufs.append(ptrs)
+        hb = lib.sayuri_hip_host_alloc(n * 4)
+        raw.append(hb)
+        np.ctypeslib.as_array(ctypes.cast(hb, ctypes.POINTER(ctypes.c_int32)), (n,))[:] = np.asarray(bsz, np.int32)
+        bp = ctypes.cast(hb, ctypes.POINTER(ctypes.c_int))
+        tick = [ctypes.c_int(-1), ctypes.c_int(-1)]
+
+        def submit(i):
+            pl, pr, pa, mi, ow = bufs[i]
+            assert lib.sayuri_hip_submit(ctx, n, ctypes.cast(pl, FP), bp, ctypes.cast(pr, FP), ctypes.cast(pa, FP), ctypes.cast(mi, FP),
+                                         ctypes.cast(ow, FP), ctypes.byref(tick[i])) == 0, lib.sayuri_hip_last_error()
+
+        def check(i, k):
+            assert lib.sayuri_hip_wait(ctx, tick[i].value) == 0
+            pl, pr, pa, mi, ow = bufs[i]
+            got = (np.ctypeslib.as_array(ctypes.cast(pr, FP), (n, 5, B * B)), np.ctypeslib.as_array(ctypes.cast(pa, FP), (n, 5)),
+                   np.ctypeslib.as_array(ctypes.cast(mi, FP), (n, 15)), np.ctypeslib.as_array(ctypes.cast(ow, FP), (n, B * B)))
+            bad = sum(1 for s_ in range(n) if not all(np.array_equal(a[s_], b[s_]) for a, b in zip(ref, got)))
+            assert bad == 0, (k, bad)
+
+        submit(0); submit(1)
+        for k in range(120):
+            check(k & 1, k); submit(k & 1)
+        check(0, 120); check(1, 121)
+    finally:
+        for q in raw:
+            lib.sayuri_hip_host_free(ctypes.c_void_p(q))
         pipe.Destroy()
 
 
