@@ -8,6 +8,8 @@ Tolerances (raw, pre-softmax outputs; magnitudes are O(1)):
                 test_fp16_error_is_measured_on_64_positions) -- and the reference's own GPU-vs-CPU SelfCheck
                 criterion L2(softmax policy ++ pass ++ wdl_winrate) <= 0.2 (network.cc:333-359) as the hard floor.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -526,22 +528,33 @@ def test_persistent_launch_with_more_tiles_than_cus(tmp_weights_dir):
     when one of the first has walked the whole tower.  That is only sound if no workgroup ever writes bytes another one still has
     to read -- and rounds 3-4 broke it: the packed input's buffer (channel stride 64) was recycled as a tower buffer (stride
     256), so an early workgroup's third layer lay on top of a late workgroup's packed input.  Full-chip launches (256 tiles,
-    all started together) won that race every time; 320 boards = 320 workgroups on 256 CUs lose it deterministically.  Every
-    sample of the 320-batch must be bit-equal to the same position in a batch of 160."""
+    all started together) won that race every time; 512 boards = 512 workgroups on 256 CUs (the batch size at which the
+    full-width channel tile, and with it the persistent launch, is chosen again) lose it deterministically.  Every sample of the
+    512-batch must be bit-equal to the same position in a batch of 256."""
+    from sayuri_amd import _lib
     from sayuri_amd.pipe import hip_forward_raw
     g = Golden("net_20b256", tmp_weights_dir)
-    B, n = 19, 320
+    B, n = 19, 512
     planes = W.synthetic_planes(n, B, seed=3200)
     grid = np.ascontiguousarray(np.stack(planes), np.float32)
     pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=n, fp16=True)
     try:
         ctx = pipe.ctx(0)
         big = hip_forward_raw(ctx, grid, [B] * n, B)
+        # the persistent launch really ran (a launch per layer would pass this test whatever the buffers do)
+        stat = _lib.KernelStat()
+        lib = _lib.hip()
+        ms = ctypes.c_float(0)
+        lib.sayuri_hip_mark_kernel(ctx, b"tower_run")
+        assert lib.sayuri_hip_time_runs(ctx, 1, ctypes.byref(ms)) == 0
+        lib.sayuri_hip_timed_stat(ctx, ctypes.byref(stat))
+        lib.sayuri_hip_mark_kernel(ctx, b"")
+        assert stat.launches >= 1, "the 512-board batch did not take the persistent launch"
         assert all(np.isfinite(x).all() for x in big) and np.abs(big[0]).max() > 0
-        for lo in (0, 160):
-            part = hip_forward_raw(ctx, grid[lo:lo + 160], [B] * 160, B)
+        for lo in (0, 256):
+            part = hip_forward_raw(ctx, grid[lo:lo + 256], [B] * 256, B)
             for a, b, what in zip(big, part, ("prob", "pass", "misc", "own")):
-                bad = [i for i in range(160) if not np.array_equal(a[lo + i], b[i])]
+                bad = [i for i in range(256) if not np.array_equal(a[lo + i], b[i])]
                 assert not bad, (what, lo, len(bad), bad[:8])
     finally:
         pipe.Destroy()
