@@ -126,7 +126,7 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
         raise RuntimeError(lib.sayuri_hip_last_error().decode())
     ms = ctypes.c_float(0)
     # the throughput: forwards as the engine runs them -- for this network a batch is cut into chains of per-layer launches over
-    # groups of board tiles, on streams and in activation buffers of their own (Engine::forward: a layer of the whole batch is 450
+    # groups of board tiles, on streams of their own (Engine::forward: a layer of the whole batch is 450
     # workgroups = two rounds of the 256 CUs, the second 76 % full; chains let a group's next layer start on the CUs another
     # group's round leaves free; bit-identical to the one-chain forward, tests/test_gpu_net.py::test_chained_forward)
     lib.sayuri_hip_mark_kernel(ctx, b"")
