@@ -121,7 +121,8 @@ int sayuri_hip_download(sayuri_hip_ctx* ctx, float* prob, float* pass, float* mi
  * All host buffers must be page-locked and stay valid until the wait.  `pass` and `misc` are written by the heads kernel
  * itself when the device can address them -- memory from sayuri_hip_host_alloc (or any other page-locked memory that is
  * MAPPED into the device's address space); a buffer that is page-locked but not mapped is detected once per pointer
- * (hipHostGetDevicePointer) and served through copies. */
+ * (hipHostGetDevicePointer) and served through copies.  Packed records (sayuri_hip_submit_packed) in such memory are likewise
+ * read by the first kernel where they lie, with no copy: they must stay UNCHANGED until the wait, not merely valid. */
 int sayuri_hip_submit(sayuri_hip_ctx* ctx, int n, const float* planes, const int* board_sizes, float* prob,
                       float* pass, float* misc, float* own, int* ticket);
 /* The same two entry points for PACKED planes (sayuri_amd/csrc/host/packed_planes.h; SURVEY.md section 8 row f1, the

@@ -165,6 +165,7 @@ struct EngineFlags {
     bool se_by_geometry = true;        // which samples take the fused SE form depends on their board size alone (conv_se); SAYURI_SE_BY_GEOMETRY=0: on the tiles' occupancy
     bool io_v2 = true;                 // SAYURI_IO_V2=0: geometry / small outputs by copies again (A/B; see submit())
     bool io_zc = true, io_geom = true, io_prefix = true;  // its three parts, one at a time (SAYURI_IO_ZC / _GEOM / _PREFIX = 0)
+    bool io_zc_in = true;  // packed records read where the caller has them (SAYURI_IO_ZC_IN=0: copied first, rounds 2-4)
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
     int compute_streams = 1;
@@ -186,6 +187,7 @@ struct EngineFlags {
         f.tower_gen_epi = !off("SAYURI_TOWER_GEN_EPI");
         f.io_v2 = !off("SAYURI_IO_V2");
         f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");
+        f.io_zc_in = f.io_zc && !off("SAYURI_IO_ZC_IN");
         f.io_geom = f.io_v2 && !off("SAYURI_IO_GEOM");
         f.io_prefix = f.io_v2 && !off("SAYURI_IO_PREFIX");
         f.se_fused = !off("SAYURI_SE_FUSED");
@@ -651,7 +653,7 @@ public:
         hipStream_t up = inorder && !big_upload ? stream_ : h2d_stream_, down = inorder ? stream_ : d2h_stream_;
         if (!inorder) HIP_OK(hipStreamWaitEvent(h2d_stream_, fwd_done_[t], 0));  // the forward that last read this slot's inputs
         else if (big_upload && tick_ev_[t]) HIP_OK(hipStreamWaitEvent(h2d_stream_, tick_ev_[t], 0));
-        if (enqueue_inputs(n, planes, board_sizes, up, packed, binary)) return -1;
+        if (enqueue_inputs(n, planes, board_sizes, up, packed, binary, /*in_place=*/inorder)) return -1;
         if (!inorder || big_upload) {
             HIP_OK(hipEventRecord(h2d_done_[t], h2d_stream_));
             HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
@@ -787,7 +789,7 @@ public:
     // geometry + planes H2D on the stream (no sync).  The geometry arrays are staged in a
     // 2-deep pinned ring so a second batch can be enqueued while the first is still copying.
     int enqueue_inputs(int n, const float* planes, const int* board_sizes, hipStream_t copy_stream, const unsigned* packed = nullptr,
-                       int binary = 0) {
+                       int binary = 0, bool in_place = false) {
         HIP_OK(hipSetDevice(device_));
         if (n <= 0 || n > max_batch_) return fail("batch size out of range");
         if (packed && (binary <= 0 || binary > desc_.input_channels || desc_.input_channels - binary > 8 || board_ * board_ > 12 * 32))
@@ -874,6 +876,16 @@ public:
         io.packed_binary = packed ? binary : 0;
         if (packed) {
             const size_t words = (size_t)binary * 12 + 8;
+            // Packed records in device-addressable host memory (sayuri_hip_host_alloc: the pump's buffers) are not copied at all:
+            // pack_bits_kernel reads the 1.8 KB per sample across PCIe itself.  The copy was 14 us of DMA -- but the copy engine
+            // takes its packets in the order they were submitted, and the OTHER ticket's two downloads, submitted earlier and
+            // waiting for that ticket's heads kernel, were ahead of it: batch k+1's upload, and with it pack_bits and the tower
+            // launch, started only after batch k's results had gone out (135 us between two tower launches against 54 us for
+            // one forward after another on one stream; tools/pump_gaps.py, profiles/r05_pump_gaps.txt).  The caller keeps the
+            // records untouched until wait(), as it must for the asynchronous copy.
+            io.packed_src = nullptr;
+            if (in_place && flags_.io_zc_in) io.packed_src = (const unsigned*)zc_device_pointer((float*)const_cast<unsigned*>(packed));
+            if (io.packed_src) return 0;
             if (!io.packed && dev_alloc(&io.packed, (size_t)max_batch_ * (40 * 12 + 8))) return -1;
             HIP_OK(hipMemcpyAsync(io.packed, packed, sizeof(unsigned) * n * words, hipMemcpyHostToDevice, copy_stream));
             return 0;
@@ -1718,11 +1730,13 @@ private:
             const int cin = d.input_channels, cs = L.cin_s, board = board_;
             const IoSlot& io = io_[cur_slot_];
             if (io.packed_binary > 0) {
-                const unsigned* rec = io.packed;
+                // (records read across PCIe: one workgroup per sample, so that a record crosses once)
+                const unsigned* rec = io.packed_src ? io.packed_src : io.packed;
+                const int split = io.packed_src ? 1 : kPackSplit;
                 const int nbin = io.packed_binary, words = nbin * 12 + 8;
                 if (timed("pack_input", 0, (double)ns * words * 4 + px * cs * sizeof(T), [&] {
-                        hipLaunchKernelGGL(pack_bits_kernel<T>, dim3(grid), dim3(256), 0, stream_, rec, words, nbin, dst, g, cin, cs,
-                                           (const int*)d_perm_, n0);
+                        hipLaunchKernelGGL(pack_bits_kernel<T>, dim3(ns * split), dim3(256), 0, stream_, rec, words, nbin, dst, g, cin, cs,
+                                           (const int*)d_perm_, n0, split);
                     }))
                     return -1;
             } else {
@@ -1987,6 +2001,7 @@ private:
     struct IoSlot {
         float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;
         unsigned* packed = nullptr;  // packed records of the batch (allocated on first use)
+        const unsigned* packed_src = nullptr;  // non-null: the batch's records are read where the caller has them (pinned host memory)
         int packed_binary = 0;       // > 0: the slot's current batch came as packed records with this many bit planes
         int *off = nullptr, *bsz = nullptr, *perm = nullptr;
         T* bufs[kNumBufs] = {};

@@ -142,12 +142,12 @@ __global__ __launch_bounds__(256) void geom_stage_kernel(const int* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void pack_bits_kernel(const unsigned* __restrict__ records, int rec_words, int nbin,
                                                         T* __restrict__ out, BatchGeom g, int cin, int cs,
-                                                        const int* __restrict__ perm, int n0 = 0) {
+                                                        const int* __restrict__ perm, int n0 = 0, int split = kPackSplit) {
     constexpr int EPP = ElemTraits<T>::kPieceElems;
     __shared__ unsigned rec[40 * 13 + 8];  // 13 words per plane: the eight planes a wave reads at once fall on different banks
-    const int n = n0 + blockIdx.x / kPackSplit, part = blockIdx.x % kPackSplit, tid = threadIdx.x;
+    const int n = n0 + blockIdx.x / split, part = blockIdx.x % split, tid = threadIdx.x;  // split: workgroups per sample
     const int bs = g.bsz[n], npix = bs * bs, ppr = cs / EPP;
-    const int per = (npix + kPackSplit - 1) / kPackSplit, pbeg = part * per, pend = min(npix, pbeg + per);
+    const int per = (npix + split - 1) / split, pbeg = part * per, pend = min(npix, pbeg + per);
     const unsigned* src = records + (size_t)(perm ? perm[n] : n) * rec_words;  // perm: device sample -> caller's slot
     for (int i = tid; i < rec_words; i += 256) rec[i < nbin * 12 ? (i / 12) * 13 + i % 12 : nbin * 13 + (i - nbin * 12)] = src[i];
     __syncthreads();

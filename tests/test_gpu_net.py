@@ -624,6 +624,79 @@ def test_two_tickets_in_flight_give_the_solo_bits(tmp_weights_dir):
         pipe.Destroy()
 
 
+def test_packed_records_are_read_where_the_pump_has_them(tmp_weights_dir):
+    """Round 5: the packed records of sayuri_hip_submit_packed are not copied when they lie in device-addressable pinned
+    memory (sayuri_hip_host_alloc, the pump's buffers): pack_bits_kernel reads them across PCIe, so that batch k+1's first
+    kernel does not queue behind batch k's downloads on the copy engine (profiles/r05_pump_gaps.txt).  Two tickets in flight
+    with DIFFERENT records in their two buffers, refilled between rounds: every batch must come back with the bits the
+    blocking, copying entry point (sayuri_hip_forward_packed) gives for the same records; records in pageable memory take the
+    copy and give the same bits again."""
+    from sayuri_amd import _lib
+    from sayuri_amd.engine import pack_planes
+    from sayuri_amd.pipe import hip_forward_packed_raw
+    g = Golden("net_20b256", tmp_weights_dir)
+    B, n, words = 19, 64, 37 * 12 + 8
+    sets = []
+    for k in range(3):
+        bsz = [19] * n if k < 2 else [int(b) for b in np.random.default_rng(77).choice([9, 13, 19], size=n)]
+        planes = W.synthetic_planes(n, bsz, seed=9100 + k)
+        sets.append((np.stack([pack_planes(p, 37) for p in planes]).astype(np.uint32), bsz))
+    lib = _lib.hip()
+    FP = ctypes.POINTER(ctypes.c_float)
+    IP = ctypes.POINTER(ctypes.c_int)
+    lib.sayuri_hip_host_alloc.restype = ctypes.c_void_p
+    lib.sayuri_hip_host_alloc.argtypes = [ctypes.c_size_t]
+    lib.sayuri_hip_host_free.argtypes = [ctypes.c_void_p]
+    lib.sayuri_hip_submit_packed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, IP, FP, FP, FP, FP, IP]
+    lib.sayuri_hip_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=n, fp16=True)
+    raw = []
+    try:
+        ctx = pipe.ctx(0)
+        refs = [hip_forward_packed_raw(ctx, rec, 37, bsz, B) for rec, bsz in sets]
+        assert not np.array_equal(refs[0][0], refs[1][0])
+        sizes = (n * words, n * 5 * B * B, n * 5, n * 15, n * B * B, n)
+        bufs = []
+        for _ in range(2):
+            ptrs = [lib.sayuri_hip_host_alloc(k * 4) for k in sizes]
+            assert all(ptrs)
+            raw += ptrs
+            bufs.append(ptrs)
+        tick = [ctypes.c_int(-1), ctypes.c_int(-1)]
+        holds = [None, None]
+
+        def submit(i, k, pageable=False):
+            rec, bsz = sets[k]
+            pl, pr, pa, mi, ow, bz = bufs[i]
+            np.ctypeslib.as_array(ctypes.cast(bz, ctypes.POINTER(ctypes.c_int32)), (n,))[:] = np.asarray(bsz, np.int32)
+            if pageable:
+                holds[i] = np.ascontiguousarray(rec)  # kept alive until the wait
+                src = ctypes.c_void_p(holds[i].ctypes.data)
+            else:
+                np.ctypeslib.as_array(ctypes.cast(pl, ctypes.POINTER(ctypes.c_uint32)), (n * words,))[:] = rec.ravel()
+                src = ctypes.c_void_p(pl)
+            assert lib.sayuri_hip_submit_packed(ctx, n, src, 37, ctypes.cast(bz, IP), ctypes.cast(pr, FP), ctypes.cast(pa, FP),
+                                                ctypes.cast(mi, FP), ctypes.cast(ow, FP), ctypes.byref(tick[i])) == 0, lib.sayuri_hip_last_error()
+
+        def check(i, k):
+            assert lib.sayuri_hip_wait(ctx, tick[i].value) == 0
+            pl, pr, pa, mi, ow, bz = bufs[i]
+            got = (np.ctypeslib.as_array(ctypes.cast(pr, FP), (n, 5, B * B)), np.ctypeslib.as_array(ctypes.cast(pa, FP), (n, 5)),
+                   np.ctypeslib.as_array(ctypes.cast(mi, FP), (n, 15)), np.ctypeslib.as_array(ctypes.cast(ow, FP), (n, B * B)))
+            for a, b, what in zip(refs[k], got, ("prob", "pass", "misc", "own")):
+                assert np.array_equal(a, b), (k, what)
+
+        order = [0, 1, 2, 1, 0, 2, 2, 0, 1, 0]
+        submit(0, order[0]); submit(1, order[1])
+        for j in range(2, len(order)):
+            check(j & 1, order[j - 2]); submit(j & 1, order[j], pageable=(j >= 7))
+        check(0, order[-2]); check(1, order[-1])
+    finally:
+        for q in raw:
+            lib.sayuri_hip_host_free(ctypes.c_void_p(q))
+        pipe.Destroy()
+
+
 def test_fp16_error_is_measured_on_64_positions(tmp_weights_dir):
     """The fp16 gate is a measurement, not a guess: 64 positions of the 20b256 network against the reference's outputs
     (tests/golden/net_20b256_x64.npz).  Records max-abs error on the raw outputs and the reference's own SelfCheck L2
