@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -31,6 +32,7 @@
 namespace sayuri {
 
 static thread_local std::string g_err;
+static std::atomic<unsigned> g_host_free_gen{0};  // sayuri_hip_host_free calls so far (Engine::zc_device_pointer)
 static thread_local int g_test_conv_kind = 0;  // kernel family the last sayuri_hip_test_conv call ran: 0 generic, 1 glds, 2 board, 3 depthwise
 static int fail(const std::string& m) { g_err = m; return -1; }
 
@@ -653,7 +655,7 @@ public:
         hipStream_t up = inorder && !big_upload ? stream_ : h2d_stream_, down = inorder ? stream_ : d2h_stream_;
         if (!inorder) HIP_OK(hipStreamWaitEvent(h2d_stream_, fwd_done_[t], 0));  // the forward that last read this slot's inputs
         else if (big_upload && tick_ev_[t]) HIP_OK(hipStreamWaitEvent(h2d_stream_, tick_ev_[t], 0));
-        if (enqueue_inputs(n, planes, board_sizes, up, packed, binary, /*in_place=*/inorder)) return -1;
+        if (enqueue_inputs(n, planes, board_sizes, up, packed, binary, /*in_place=*/true)) return -1;
         if (!inorder || big_upload) {
             HIP_OK(hipEventRecord(h2d_done_[t], h2d_stream_));
             HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
@@ -760,6 +762,12 @@ public:
     // its results through the device-side copies and hipMemcpyAsync as before.
     float* zc_device_pointer(float* host) {
         if (!host) return nullptr;
+        // (an address may be handed out again after sayuri_hip_host_free, to memory of another kind: answers do not outlive a free)
+        const unsigned gen = g_host_free_gen.load(std::memory_order_acquire);
+        if (gen != zc_gen_) {
+            zc_known_.clear();
+            zc_gen_ = gen;
+        }
         auto it = zc_known_.find(host);
         if (it != zc_known_.end()) return it->second;
         void* dp = nullptr;
@@ -771,6 +779,7 @@ public:
         return ans;
     }
     std::map<float*, float*> zc_known_;
+    unsigned zc_gen_ = 0;
 
     // resident geometry arrays of a uniform batch of `bs` x `bs` boards (valid for every n <= max_batch)
     struct IdentGeom { int *off = nullptr, *bsz = nullptr, *perm = nullptr; };
@@ -2181,7 +2190,9 @@ void* sayuri_hip_host_alloc(size_t bytes) {
     return p;
 }
 void sayuri_hip_host_free(void* p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    g_host_free_gen.fetch_add(1, std::memory_order_release);
+    (void)hipHostFree(p);
 }
 
 size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->device_bytes() : 0; }

@@ -75,6 +75,7 @@ def run(lib, wpath, records, bsz, n, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--zc-in", action="store_true", help="SAYURI_IO_ZC_IN=1 against 0 under the engine's own stream choices")
     args = ap.parse_args()
     lib = _lib.hip()
     wpath = "/tmp/sayuri_c5_40b384.bin"
@@ -86,13 +87,17 @@ def main():
     planes = W.synthetic_planes(n, [int(b) for b in bsz], seed=5100)
     records = np.stack([pack_planes(p, 37) for p in planes])
     out = []
+    settings = [("1", "1", "1"), ("1", "2", "1"), ("0", "1", "1"), ("0", "2", "1")]
+    if args.zc_in:  # the engine's own choices, packed records read in place (default) against copied first
+        settings = [("0", "1", "1"), ("0", "1", "0")]
     for rep in range(2):
-        for chains, streams in (("1", "1"), ("1", "2"), ("0", "1"), ("0", "2")):
+        for chains, streams, zc_in in settings:
             os.environ["SAYURI_CHAINS"] = chains
             os.environ["SAYURI_COMPUTE_STREAMS"] = streams
+            os.environ["SAYURI_IO_ZC_IN"] = zc_in
             eps, ms, got = run(lib, wpath, records, bsz, n, args.steps)
-            row = {"SAYURI_CHAINS": chains, "SAYURI_COMPUTE_STREAMS": streams, "chains_per_forward": got, "evals_per_sec": round(eps, 1),
-                   "ms_per_batch": round(ms, 3), "rep": rep}
+            row = {"SAYURI_CHAINS": chains, "SAYURI_COMPUTE_STREAMS": streams, "SAYURI_IO_ZC_IN": zc_in, "chains_per_forward": got,
+                   "evals_per_sec": round(eps, 1), "ms_per_batch": round(ms, 3), "rep": rep}
             print(json.dumps(row), flush=True)
             out.append(row)
     with open(os.path.join(ROOT, "gpurun_out", "c5_pump.json"), "w") as f:
