@@ -5,6 +5,10 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/sp
 if [ -z "$SKIP_LONG" ]; then
+# the box's own microbench first: boxes of the pool differ by +-2.5 %, and the long run is read against it
+python bench.py --steps 50 --warmup 10 --selfplay-seconds 0 --no-cpu-baseline --no-config5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('microbench of this box:', d['value'], 'evals/s,', d['ms_per_step'], 'ms per batch; submit/wait packed', d['config'].get('pump_packed',{}).get('nn_evals_per_sec'))" | tee gpurun_out/sp/${TAG:-r05}_microbench.txt
 SAYURI_MEMSTAT=1 timeout 2100 python tools/selfplay_bench.py --seconds 1620 --games 512 --num-games 100000 2> gpurun_out/sp/long.err | tail -1 > gpurun_out/sp/${TAG:-r05}_selfplay_27min_512games.json
 python -c "
 import json
