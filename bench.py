@@ -426,9 +426,12 @@ def main():
                     "cache_hits": st["cache_hits"], "moves": st["moves"], "playouts": st["playouts"], "records": st["records"],
                     "elapsed": st["elapsed"]}
 
+        import resource
+        ru0, pt0 = resource.getrusage(resource.RUSAGE_SELF), pipe.pump_times()
         st = S.selfplay(pipe, sp_opts, seconds=args.selfplay_seconds, name_suffix=f"-r{rank}",
                         on_stats=None if args.no_exchange else (lambda snap, halt: pg.tick(local_record(snap), halt=halt)),
                         stats_interval=2.0)
+        ru1, pt1 = resource.getrusage(resource.RUSAGE_SELF), pipe.pump_times()
         tot = pg.drain(local_record(st))
         fin = gather_stats({"games_done": st["finished_moves"], "moves": st["prerolled_moves"], "elapsed": st["elapsed"]})
         # the writer's counters of all ranks, through the same record (the keys are only slots here)
@@ -476,6 +479,12 @@ def main():
                     # the path's one collective: issue -> landed per round, on the self-play loop's calling thread, beside the
                     # persistent tower launches of the two batches in flight (sayuri_amd/shard.py)
                     "exchange": pg.latency_summary(),
+                    # this rank's process: CPU seconds of all its threads (game fibers' scheduler threads, pump, writer, the
+                    # runtime's own) from the call to its return -- the pre-rolled openings and the writer's final flush
+                    # included, so an upper bound -- over the window's seconds; and the pump thread's account per batch
+                    "host_cpu_cores_busy": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(st["elapsed"], 1e-9), 2),
+                    "pump_us_per_batch": {k: round((pt1[k] - pt0[k]) / max(pt1["batches"] - pt0["batches"], 1))
+                                          for k in ("wait_batch_us", "gpu_queue_empty_us", "fill_us", "forward_us") if k in pt1},
                     "frac_of_microbench_evals": None}
 
     result = None
