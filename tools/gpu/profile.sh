@@ -10,8 +10,8 @@ B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-config5 --selfplay-se
 if [ -z "$SKIP_TESTS" ]; then
   timeout 2400 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
 fi
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof/kt -o p --output-format csv -- $B --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$O/prof/kt.out 2> $GRAFT_REPO_ROOT/$O/prof/kt.err); echo "kernel-trace rc=$?"
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-config5 --selfplay-seconds 0 --no-pump --steps 20 --warmup 5   ($(date -u +%FT%TZ))"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof/kt -o p --output-format csv -- $B --steps 100 --warmup 10 > $GRAFT_REPO_ROOT/$O/prof/kt.out 2> $GRAFT_REPO_ROOT/$O/prof/kt.err); echo "kernel-trace rc=$?"
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-config5 --selfplay-seconds 0 --no-pump --steps 100 --warmup 10   ($(date -u +%FT%TZ))"
   echo "# bench line of the same command:"; tail -1 $O/prof/kt.out | sed 's/^/# /' | cut -c1-1500
   find $O/prof/kt -name "*kernel_stats.csv" | head -1 | xargs cat; } > $O/rocprofv3_kernel_stats.txt
 head -8 $O/rocprofv3_kernel_stats.txt | cut -c1-220
