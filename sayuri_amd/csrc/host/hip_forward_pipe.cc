@@ -226,7 +226,7 @@ void HipForwardPipe::TraceDump() const {
     for (const auto& a : trace_resume_) std::fprintf(stderr, " %ld", a.load());
     std::fprintf(stderr, "\n[pipe trace] fibers, the game runs again -> its next request:");
     for (const auto& a : trace_think_) std::fprintf(stderr, " %ld", a.load());
-    std::fprintf(stderr, "\n[pipe trace] 85 %% rule, age of the running batch at the close:");
+    std::fprintf(stderr, "\n[pipe trace] tail rule (SAYURI_PIPE_TAIL), age of the running batch at the close:");
     for (const auto& a : trace_tail_) std::fprintf(stderr, " %ld", a.load());
     std::fprintf(stderr, "\n[pipe trace] batch sizes /16:");
     for (const auto& a : trace_size_) std::fprintf(stderr, " %ld", a.load());

@@ -195,9 +195,9 @@ private:
     std::atomic<long> trace_size_[17] = {};     // batch size / 16
     std::atomic<long> trace_resume_[32] = {};   // fibers: batch finished -> the game runs again
     std::atomic<long> trace_think_[32] = {};    // fibers: the game runs again -> its next request
-    std::atomic<long> trace_tail_[32] = {};     // 85 % rule: how long the running batch had been running when the set was closed
+    std::atomic<long> trace_tail_[32] = {};     // tail rule: how long the running batch had been running when the set was closed
     std::atomic<long> trace_reason_[4] = {};
-    double tail_frac_{0.85};                    // SAYURI_PIPE_TAIL (measuring aid): the fraction of a batch's time after which a partial set is enqueued behind it    // closed because: full, GPU idle + wait expired, 85 % of the running batch, stray
+    double tail_frac_{0.93};                    // SAYURI_PIPE_TAIL (measuring aid): the fraction of a batch's time after which a partial set is enqueued behind it    // closed because: full, GPU idle + wait expired, 93 % of the running batch, stray
     void TraceDump() const;
 };
 
