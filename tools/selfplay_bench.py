@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=0.0)
     ap.add_argument("--games", type=int, default=512, help="concurrent games")
-    ap.add_argument("--num-games", type=int, default=0, help="complete games to play (default: one per worker)")
+    ap.add_argument("--num-games", type=int, default=0, help="complete games to play (default: one per worker; with --seconds: no limit, a worker whose game ends starts the next)")
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--net", default="20b256")
     ap.add_argument("--board", type=int, default=19)
@@ -57,7 +57,7 @@ def main():
     if not args.out and not args.no_writer:
         scratch = args.out = tempfile.mkdtemp(prefix="sayuri_selfplay_chunks_")
     pipe = HipForwardPipe(wpath, board_size=args.board, batch_size=args.batch, fp16=not args.fp32, waittime_ms=args.waittime)
-    opts = dict(playouts=args.playouts, parallel_games=args.games, num_games=max(args.num_games, args.games), seed=args.seed,
+    opts = dict(playouts=args.playouts, parallel_games=args.games, num_games=max(args.num_games, args.games) if (args.num_games or args.seconds <= 0) else 1000000, seed=args.seed,
                 dirichlet_noise=1, dirichlet_epsilon=0.25, dirichlet_init=0.03, dirichlet_factor=361, first_pass_bonus=1,
                 random_moves_factor=0.1, komi_stddev=2.5, komi_big_stddev_prob=0.06, komi_big_stddev=12, lcb_reduction=0.0,
                 resign_playouts=80, resign_threshold=0.05, resign_discard_prob=0.9, early_symm_cache=1, cache_memory_mib=400,
