@@ -336,38 +336,50 @@ extern "C" int sayuri_pipe_netbench(void* hp, int threads, double seconds, int b
 #include "fiber.h"
 extern "C" long sayuri_fiber_selftest(int fibers, int threads, int rounds) {
     if (fibers <= 0 || threads <= 0 || rounds <= 0) return -1;
-    std::vector<std::atomic<int>> words(static_cast<size_t>(fibers));
+    std::vector<std::atomic<int>> words(static_cast<size_t>(fibers)), acks(static_cast<size_t>(fibers));
     for (auto& w : words) w.store(0);
+    for (auto& a : acks) a.store(0);
     std::atomic<long> waits{0};
     std::atomic<int> finished{0};
     sayuri_fiber::FiberPool pool(64 << 10);
     for (int f = 0; f < fibers; ++f)
         pool.Add([&, f] {
-            // some stack use and a value carried across every switch
+            // some stack use and a value carried across every switch (a fiber may resume on another thread: FiberPool::Run)
             volatile char pad[2048];
             pad[0] = static_cast<char>(f);
             long mine = 0;
             for (int r = 0; r < rounds; ++r) {
-                sayuri_fiber::WaitWhileEqual(&words[static_cast<size_t>(f)], r);
+                sayuri_fiber::WaitWhileEqual(&words[static_cast<size_t>(f)], r);  // until the driver has put r + 1 there
+                if (words[static_cast<size_t>(f)].load(std::memory_order_acquire) != r + 1) return;  // resumed too early: counted as a failure
                 ++mine;
+                acks[static_cast<size_t>(f)].store(r + 1, std::memory_order_release);
             }
             if (pad[0] == static_cast<char>(f)) waits.fetch_add(mine);
             finished.fetch_add(1);
         });
+    std::atomic<bool> give_up{false};
     std::thread driver([&] {
         std::mt19937 rng(7);
-        for (int r = 0; r < rounds; ++r) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < rounds && !give_up.load(); ++r) {
             std::vector<int> order(static_cast<size_t>(fibers));
             for (int i = 0; i < fibers; ++i) order[static_cast<size_t>(i)] = i;
             std::shuffle(order.begin(), order.end(), rng);
             for (int i : order) {
-                // a fiber may not have reached round r yet: words only ever go up by one when it has
-                while (words[static_cast<size_t>(i)].load() != r) std::this_thread::yield();
+                // the word of fiber i moves on only when the fiber has been through round r - 1: every round is a real suspension,
+                // and the new value often lands while the fiber is still on its way out (the case a thief must not act on early)
+                while (acks[static_cast<size_t>(i)].load(std::memory_order_acquire) != r) {
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { give_up.store(true); break; }
+                    std::this_thread::yield();
+                }
                 words[static_cast<size_t>(i)].store(r + 1, std::memory_order_release);
                 if ((i & 7) == 0) sayuri_fiber::NotifyAll();
             }
             sayuri_fiber::NotifyAll();
         }
+        if (give_up.load())  // let every fiber run out so that Run returns: the result reports the failure
+            for (int i = 0; i < fibers; ++i) words[static_cast<size_t>(i)].store(-1, std::memory_order_release);
+        sayuri_fiber::NotifyAll();
     });
     pool.Run(threads);
     driver.join();
