@@ -79,6 +79,35 @@ def hbm_traffic(fp16: bool, dominant: str) -> dict:
             "traffic_source": f"{os.path.relpath(path, ROOT)} ({t['source']}; measured on commit {t.get('commit', '?')}, file {age_h:.1f} h old)"}
 
 
+def long_run_games_per_hour() -> dict:
+    """games/hour by the reference's definition with nothing helping it (finished games / wall, every game from the EMPTY
+    board, more than one generation of the 512 games, the writer with the reference's pool; src/selfplay/pipe.cc:272-280) takes
+    a 27-minute run (tools/selfplay_bench.py --seconds 1620), not a window of this script: read from the latest such profile
+    kept under profiles/, the way `roofline.traffic` is read, with the file's age and the tree it was measured on."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_selfplay_27min_512games*.json")),
+                   key=lambda f: (os.path.basename(f)[:3], os.path.getmtime(f)))
+    if not found:
+        return {"games_per_hour_empty_board_27min": None}
+    path = found[-1]
+    d = json.load(open(path))
+    age_h = (time.time() - os.path.getmtime(path)) / 3600.0
+    return {"games_per_hour_empty_board_27min": d.get("games_per_hour"),
+            "games_per_hour_empty_board_27min_source": f"{os.path.relpath(path, ROOT)}: {d.get('games_done')} games finished in "
+            f"{d.get('elapsed', 0):.0f} s from the empty board at {d.get('nn_evals_per_sec')} NN evals/s, mean batch {d.get('mean_batch')}, "
+            f"{d.get('host_cpu_cores_busy')} host cores, {d.get('chunks_saved')} chunks written (measured on commit "
+            f"{d.get('commit', '?')}, file {age_h:.1f} h old; NOT measured in this run)"}
+
+
+def toolchain_line() -> str:
+    """First line of `hipcc --version` (the persistent tower kernel's seam is validated against one compiler)."""
+    try:
+        from sayuri_amd import _build
+        return _build._toolchain().splitlines()[0].strip()
+    except Exception as e:  # noqa: BLE001
+        return "unknown (%r)" % (e,)
+
+
 def mark_dominant(lib, ctx) -> str:
     """Mark the dominant kernel class for per-launch event timing inside the timed region: the persistent tower launch
     (one launch per run of board convolutions, conv_tower.h) when the engine uses it, else the per-layer tower convolutions
@@ -262,6 +291,26 @@ def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
                       "Eigen / OpenBLAS are not in this image, the three CPU variants differ only in the GEMM call (blas.cc:16-166)"}
 
 
+def launch_ranks(n: int, port: int) -> int:
+    """`python bench.py --gpus N` without a launcher: be the launcher.  Checks that the box has N devices (the HIP library's
+    own count; SAYURI_BENCH_SHARE_DEVICE is the one-GPU test hook that lets ranks share), then runs this file's own command line
+    under `torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 -- one rank per GPU, rank 0 prints the JSON line
+    to this process's stdout -- and returns its exit code."""
+    import subprocess
+    from sayuri_amd import _lib
+    have = int(_lib.hip().sayuri_hip_device_count())
+    if have < n and not os.environ.get("SAYURI_BENCH_SHARE_DEVICE"):
+        print(f"bench.py: --gpus {n} but this box has {have} HIP device(s)", file=sys.stderr)
+        return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")             # what torch.distributed.run would set, without its warning
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,11 +345,24 @@ def main():
     ap.add_argument("--dist-backend", default=os.environ.get("SAYURI_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend of the multi-rank run: nccl (= RCCL, the default) or gloo (CPU tests on the "
                          "fake device; also SAYURI_DIST_BACKEND)")
+    ap.add_argument("--master-port", type=int, default=int(os.environ.get("SAYURI_BENCH_MASTER_PORT", "29571")),
+                    help="rendezvous port of the ranks a plain `python bench.py --gpus N` starts itself")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # A plain `python bench.py --gpus N` (no launcher around it): start the N ranks here -- one process per GPU, the
+        # command line the docstring names, with this process as the launcher.  The reference does the in-process form of
+        # this: one NNGraph per listed GPU and one worker thread each (cuda_forward_pipe.cc:85-116, batch_forward_pipe.cc:80-97).
+        sys.exit(launch_ranks(args.gpus, args.master_port))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; the line's n_gpus "
+                         "would not be what was asked for")
 
     import torch
     dist = None
@@ -323,6 +385,8 @@ def main():
     from sayuri_amd.pipe import HipForwardPipe
 
     lib = _lib.hip()
+    if lib.sayuri_hip_device_count() < (1 if os.environ.get("SAYURI_BENCH_SHARE_DEVICE") else local_rank + 1):
+        raise SystemExit(f"bench.py: rank {rank} needs HIP device {local_rank}, this box has {lib.sayuri_hip_device_count()}")
     if os.environ.get("SAYURI_BENCH_SHARE_DEVICE"):
         # TEST HOOK (tests/test_gpu_dropin.py): the ranks of a multi-rank launch share the devices that exist, so that this file's
         # multi-rank path (barrier, max-over-ranks timing, stats gather, exchange rounds) runs against the real runtime on a
@@ -366,6 +430,8 @@ def main():
         if lib.sayuri_hip_time_runs(ctx, args.warmup, ctypes.byref(ms)):
             raise RuntimeError(lib.sayuri_hip_last_error().decode())
     dominant = mark_dominant(lib, ctx)
+    tower_state = ("persistent" if lib.sayuri_hip_tower_state(ctx) == 1 and dominant == "tower_run" else
+                   "per-layer (fp32 engine)" if not fp16 else "per-layer fallback")
 
     # ---- timed region: exactly K steps between barrier+sync pairs
     sync_all()
@@ -501,6 +567,9 @@ def main():
             "metric": "nn_evals_per_sec", "value": round(value, 1), "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            # which form of the tower ran: the persistent launch, or the per-layer fallback a build takes when tower_seam.py
+            # rejects the compiler's assembly (another hipcc) -- 1-2 % slower and without the in-kernel SE unit
+            "tower": tower_state, "hipcc": toolchain_line(),
             "config": {"workload": "configs[1]: 19x19, 20-block x 256-filter net (SE every 3rd block, heads 32ch, "
                                    "mish), batch=256 inference microbench, planes resident in HBM",
                        "batch_per_gpu": n, "global_batch": n * world, "board": 19, "parallelism": f"dp{world}",
@@ -523,6 +592,7 @@ def main():
             result["config"]["pump_packed"] = pump_packed
         if selfplay is not None:
             selfplay["frac_of_microbench_evals"] = round(selfplay["nn_evals_per_sec"] / value, 4)
+            selfplay.update(long_run_games_per_hour())
             result["selfplay"] = selfplay
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wpath, planes, args.cpu_seconds)

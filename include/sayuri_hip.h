@@ -177,6 +177,12 @@ size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* ctx);
  * kernel (cuda_forward_pipe.cc:713-981).  SAYURI_CHAINS=1 turns it off, =N forces N. */
 int sayuri_hip_last_chains(const sayuri_hip_ctx* ctx);
 
+/* 1 when the ctx runs its residual tower as ONE persistent launch (the code object of csrc/hip/conv_tower.h is in the library
+ * and loaded), 0 when it falls back to one launch per layer -- a build whose assembly post-processor (tower_seam.py, validated
+ * on ROCm 7.2's hipcc) rejected the compiler's output, SAYURI_TOWER=0, or the fp32 engine.  bench.py prints it on its line.
+ * The reference always launches per layer (cuda_forward_pipe.cc:713-981). */
+int sayuri_hip_tower_state(const sayuri_hip_ctx* ctx);
+
 /* Release everything (replaces NNGraph::DestroyGraph, cuda_forward_pipe.cc:1092-1130). */
 void sayuri_hip_destroy(sayuri_hip_ctx* ctx);
 

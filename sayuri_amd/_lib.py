@@ -20,7 +20,7 @@ class KernelStat(ctypes.Structure):
 HIP_SYMBOLS = [
     "sayuri_hip_device_count", "sayuri_hip_create", "sayuri_hip_load_tensor", "sayuri_hip_forward",
     "sayuri_hip_submit", "sayuri_hip_wait", "sayuri_hip_query", "sayuri_hip_upload", "sayuri_hip_run", "sayuri_hip_sync", "sayuri_hip_download", "sayuri_hip_time_runs",
-    "sayuri_hip_forward_packed", "sayuri_hip_submit_packed", "sayuri_hip_profile_run", "sayuri_hip_mark_kernel", "sayuri_hip_timed_stat", "sayuri_hip_host_alloc", "sayuri_hip_host_free", "sayuri_hip_device_bytes", "sayuri_hip_last_chains",
+    "sayuri_hip_forward_packed", "sayuri_hip_submit_packed", "sayuri_hip_profile_run", "sayuri_hip_mark_kernel", "sayuri_hip_timed_stat", "sayuri_hip_host_alloc", "sayuri_hip_host_free", "sayuri_hip_device_bytes", "sayuri_hip_last_chains", "sayuri_hip_tower_state",
     "sayuri_hip_destroy", "sayuri_hip_last_error", "sayuri_hip_test_conv", "sayuri_hip_test_last_conv_kind",
     "sayuri_hip_test_se_unit", "sayuri_hip_test_head_tail", "sayuri_hip_test_conv_se", "sayuri_hip_test_head_board",
 ]
@@ -66,6 +66,8 @@ def hip() -> ctypes.CDLL:
         lib.sayuri_hip_device_bytes.argtypes = [ctypes.c_void_p]
         lib.sayuri_hip_last_chains.restype = ctypes.c_int
         lib.sayuri_hip_last_chains.argtypes = [ctypes.c_void_p]
+        lib.sayuri_hip_tower_state.restype = ctypes.c_int
+        lib.sayuri_hip_tower_state.argtypes = [ctypes.c_void_p]
         if not fake:  # the stand-in has no kernels to tap
             lib.sayuri_hip_test_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -73,7 +73,19 @@ struct SearchParams {
     // visits and scores fpu + cpuct * psa * sqrt(N): monotone in its search policy psa, which is fixed for the whole search.  So
     // the root keeps its children's indices by descending psa and the (sorted) list of the children chosen so far; a call looks
     // at those and at the head of the never-chosen ones.  Built by PrepareRootNode, valid while `root_index_owner` is the root.
+    // The index is per-search scratch that lives here only because the selection gets at the parameters and not at the Search:
+    // a COPY of the parameters starts with an empty index (no stale owner pointer, no copied vectors) and whoever searches
+    // with the copy rebuilds it in PrepareRootNode.  One playout per tree at a time (the self-play rule) is what makes the
+    // mutation under a const Node safe; several threads in one tree would need the index on the Search.
     struct RootIndex {
+        RootIndex() = default;
+        RootIndex(const RootIndex&) {}
+        RootIndex& operator=(const RootIndex& o) {
+            if (this != &o) *this = RootIndex();
+            return *this;
+        }
+        RootIndex(RootIndex&&) = default;
+        RootIndex& operator=(RootIndex&&) = default;
         const void* owner{nullptr};
         std::vector<std::int16_t> by_psa;     // child indices, psa descending, ties: lower index first
         std::vector<std::int16_t> chosen;     // child indices that were returned by the selection, ascending

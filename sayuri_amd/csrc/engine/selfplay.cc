@@ -362,11 +362,12 @@ bool SelfplayPipe::WriteGzip(const std::string& name, const std::string& text) {
     gzFile f = gzopen(path.c_str(), "wb9");
     if (!f) return false;
     const int n = text.empty() ? 0 : gzwrite(f, text.data(), static_cast<unsigned>(text.size()));
-    gzclose(f);
+    const bool closed = gzclose(f) == Z_OK;  // the flush of the last block happens here: a full disk shows up in this call
+    if (!closed || !(text.empty() || n > 0)) return false;
     struct stat sb;
     if (::stat(path.c_str(), &sb) == 0) bytes_written_.fetch_add(static_cast<std::uint64_t>(sb.st_size), std::memory_order_relaxed);
     text_bytes_.fetch_add(text.size(), std::memory_order_relaxed);
-    return text.empty() || n > 0;
+    return true;
 }
 
 bool SelfplayPipe::SaveChunk(int id, float vdata_prob, std::vector<TrainingData>& chunk, Rng& rng) {
@@ -385,14 +386,16 @@ bool SelfplayPipe::SaveChunk(int id, float vdata_prob, std::vector<TrainingData>
 
 void SelfplayPipe::SaveSgf(const std::string& sgf) {
     std::ofstream f(sgf_dir_ + "/" + hash_ + ".sgf", std::ios_base::app);
-    if (f.is_open()) f << sgf << std::endl;
-    bytes_written_.fetch_add(sgf.size() + 1, std::memory_order_relaxed);
+    if (!f.is_open()) return;
+    f << sgf << std::endl;
+    if (f.good()) bytes_written_.fetch_add(sgf.size() + 1, std::memory_order_relaxed);
 }
 
 void SelfplayPipe::SaveNetQueries(int games, const std::string& text) {
     std::ofstream f(queries_dir_ + "/" + hash_ + ".txt", std::ios_base::app);
-    if (f.is_open()) f << games << " " << text << std::endl;
-    bytes_written_.fetch_add(text.size() + 8, std::memory_order_relaxed);
+    if (!f.is_open()) return;
+    f << games << " " << text << std::endl;
+    if (f.good()) bytes_written_.fetch_add(text.size() + 8, std::memory_order_relaxed);
 }
 
 void SelfplayPipe::WriterLoop() {
@@ -430,6 +433,9 @@ void SelfplayPipe::WriterLoop() {
             // The run is over and the pool is flushed (pipe.cc:206-208 drops the hold to 1): hundreds of games at gzip level 9,
             // 0.15 s each.  Every chunk is a file of its own, so the flush goes over a few threads -- ids, the shuffle and the
             // tdata / vdata split of every game are drawn here, in order, from the one generator; the SGF lines follow in id order.
+            // The ids are handed out up front, so a chunk that fails to write (gzopen / gzwrite / gzclose) leaves a GAP in the
+            // game_N numbering of this last flush and is not counted in chunks_ (the serial path below reuses the id; nothing is
+            // numbered after this flush, so a gap never collides with a later chunk).
             std::shuffle(pool.begin(), pool.end(), rng);
             struct Job { std::shared_ptr<DataSgf> item; int id; std::uint64_t seed; bool ok; };
             std::vector<Job> jobs;

@@ -648,6 +648,7 @@ int Node::GetBestMove(bool allow_pass) {
 }
 
 Node* Node::GetChild(int vertex) {
+    EnsureSorted();  // an edge inflated in the unsorted tail would be moved beyond inflated_hi_ by the next SortTail
     for (auto& c : children_)
         if (c.GetVertex() == vertex) return Inflate(c);
     return nullptr;

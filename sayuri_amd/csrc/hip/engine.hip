@@ -485,6 +485,7 @@ public:
     virtual int timed_stat(sayuri_hip_kernel_stat* row) = 0;
     virtual size_t device_bytes() const = 0;
     virtual int last_chains() const = 0;
+    virtual int tower_state() const = 0;  // 1: the persistent tower kernel is loaded, 0: one launch per layer (fallback)
     virtual int debug_read(int buf, void* host, size_t bytes) = 0;  // debugging tap: activation buffer `buf` of ticket 0
 };
 
@@ -502,10 +503,7 @@ public:
     int init() {
         HIP_OK(hipSetDevice(device_));
         HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-        // Both tickets run their forward graphs on ONE compute stream.  A second compute stream (SAYURI_COMPUTE_STREAMS=2:
-        // the next batch's kernels fill the CUs the current batch leaves idle -- second tile wave, small SE / head kernels,
-        // launch gaps) is supported -- each ticket has its own activations and tile tables -- but measured slower:
-        // 48.0 k vs 54.0 k evals/s through the queue, two graphs evict each other's weights and activations from L2.
+        // The tickets' compute streams: one shared stream to begin with; the rule below gives ticket 1 a stream of its own.
         compute_[0] = stream_;
         compute_[1] = stream_;
         HIP_OK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
@@ -527,17 +525,16 @@ public:
             tower_mod_ = nullptr;
             tower_fn_[0] = tower_fn_[1] = nullptr;
         }
-        // One stream per ticket only with the persistent launch: its workgroups hold every CU, so the two tickets' forwards
-        // follow one another whatever stream they are on.  Per-layer launches of two tickets would run side by side and evict
-        // each other's weights and activations from L2 (the measurement above): those keep the one compute stream.
-        // ... and only for networks whose tower the persistent launch actually covers: every 3x3 convolution of the blocks
-        // must have a channel tile that covers the layer (tower_ok: 256 or 128 padded output channels).  A 384- or
-        // 192-channel network has the code object loaded and still runs one launch per layer.
+        // One stream per ticket (everything of a ticket in order on its own stream, no event between streams) whenever the
+        // persistent kernel is loaded -- for every network, also one the launch does not cover (384 / 192 channels: the code
+        // object is loaded and the layers are still launched one by one).  History of the rule: round 1 measured two tickets'
+        // per-layer launches side by side as slower (48.0 k vs 54.0 k evals/s, the 482-workgroup kernel on the 256-channel
+        // network evicting each other's L2 lines) and kept one compute stream; round 5 re-measured on the kernels of today --
+        // 40b x 384 through submit / wait, two tickets in flight: a stream per ticket 26.3 k evals/s, one compute stream 23.7 k
+        // (a layer is 450 workgroups, two rounds of the CUs, and the other ticket's launches fill the second; 200 batches
+        // bit-identical to the solo result, tools/gpu/c5_pump.py, concurrent_ctx_dbg.py).  Without the code object
+        // (SAYURI_TOWER=0, or a build whose seam was rejected) the older three-stream arrangement stays.
         if (describe_layers()) return -1;
-        // (round 5, networks the launch does not cover: 40b x 384 through submit / wait, two tickets in flight -- a stream per ticket
-        // 26.3 k evals/s, one compute stream 23.7 k: a layer is 450 workgroups, two rounds of the CUs, and the other ticket's
-        // launches fill the second; 200 batches bit-identical to the solo result, tools/gpu/c5_pump.py, concurrent_ctx_dbg.py.
-        // The 48.0 k vs 54.0 k above was round 1's 482-workgroup kernel on the 256-channel network.)
         inorder_ = flags_.io_inorder && tower_fn_[0] != nullptr;
         if (flags_.compute_streams == 2 || inorder_) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
         return 0;
@@ -562,7 +559,6 @@ public:
     hipEvent_t chain_fork_ = nullptr, chain_join_[kMaxChains] = {};
     int rg_tile0_ = 0, rg_ntiles_ = -1, rg_n0_ = 0, rg_ns_ = -1;  // the tiles / samples the launches of forward_graph() cover (-1: all)
     int last_chains_ = 1;
-    bool solo_forward_ = true;  // submit(): false while the other ticket's batch is still in flight
     int range_ntiles() const { return rg_ntiles_ >= 0 ? rg_ntiles_ : board_plan_.ntiles; }
     int range_ns() const { return rg_ns_ >= 0 ? rg_ns_ : geom_.n; }
     double range_px() const { return rg_ns_ >= 0 ? (double)(geom_.off[rg_n0_ + rg_ns_] - geom_.off[rg_n0_]) : (double)geom_.total; }
@@ -677,12 +673,10 @@ public:
         // So nothing small is copied any more: the heads kernel stores pass / misc straight into the caller's pinned
         // buffers (20 KB of posted PCIe writes), a uniform batch uses geometry arrays that are resident (enqueue_inputs),
         // and the tower table does not depend on the batch size (tower_append).  The two large outputs keep their DMA copies.
-        solo_forward_ = !tick_ev_[t ^ 1] || hipEventQuery(tick_ev_[t ^ 1]) == hipSuccess;
         zc_pass_ = flags_.io_zc ? zc_device_pointer(pass) : nullptr;
         zc_misc_ = zc_pass_ ? zc_device_pointer(misc) : nullptr;
         if (!zc_misc_) zc_pass_ = nullptr;  // both or neither: the heads kernel takes one path
         const int frc = forward();
-        solo_forward_ = true;
         const bool small_direct = zc_pass_ != nullptr;
         zc_pass_ = zc_misc_ = nullptr;
         if (frc) return -1;
@@ -1028,6 +1022,7 @@ public:
 
     size_t device_bytes() const override { return dev_bytes_; }
     int last_chains() const override { return last_chains_; }
+    int tower_state() const override { return tower_fn_[0] != nullptr ? 1 : 0; }
     int debug_read(int buf, void* host, size_t bytes) override {
         if (buf < 0 || buf >= kNumBufs || !io_[0].bufs[buf]) return fail("debug_read: no such buffer");
         HIP_OK(hipSetDevice(device_));
@@ -2197,6 +2192,7 @@ void sayuri_hip_host_free(void* p) {
 
 size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->device_bytes() : 0; }
 int sayuri_hip_last_chains(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->last_chains() : 0; }
+int sayuri_hip_tower_state(const sayuri_hip_ctx* ctx) { return ctx ? ctx->eng->tower_state() : -1; }
 // debugging tap (not part of the ABI, not in the header): activation buffer `buf` (0..5) of ticket 0 as it stands after the last forward
 extern "C" int sayuri_hip_debug_read_activations(sayuri_hip_ctx* ctx, int buf, void* host, size_t bytes) {
     return ctx ? ctx->eng->debug_read(buf, host, bytes) : -1;

@@ -122,6 +122,8 @@ class PeriodicGather:
         if ev is None:
             work.wait()
             self._dst_host.copy_(self._dst)
+        else:
+            ev.synchronize()  # the read-back has landed (a no-op for every caller that polled _landed() first)
         self._inflight = None
         self.latencies_ms.append((time.perf_counter() - t0) * 1e3)
         rows = self._dst_host.view(self._world, len(STAT_KEYS)).tolist()
@@ -150,6 +152,8 @@ class PeriodicGather:
             self._account(_reduce_rows([[float(rec.get(k, 0.0)) for k in STAT_KEYS]]))
             self.latencies_ms.append(0.0)
             return self.any_halt
+        if self.all_done and self._inflight is None:
+            return self.any_halt  # every rank has reported done and seen that round: a new collective would have no peer
         deadline = time.perf_counter() + self.timeout
         if self._inflight is not None:  # a round that missed its deadline: collect it first, issue nothing beside it
             if not self._wait(deadline):
@@ -172,7 +176,8 @@ class PeriodicGather:
         while not self.all_done:
             self.tick(final, halt=self.any_halt, done=True)
         if self._inflight is not None:  # nothing may stay in flight behind the caller's back
-            self._wait(time.perf_counter() + 60.0)
+            if not self._wait(time.perf_counter() + 60.0):
+                raise RuntimeError("PeriodicGather.drain: the last exchange round has not landed after 60 s (a peer rank is gone?)")
             self._collect()
         return self.last
 

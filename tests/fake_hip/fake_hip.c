@@ -264,6 +264,7 @@ int sayuri_hip_query(sayuri_hip_ctx* c, int t) {
 }
 size_t sayuri_hip_device_bytes(const sayuri_hip_ctx* c) { (void)c; return 0; }
 int sayuri_hip_last_chains(const sayuri_hip_ctx* c) { (void)c; return 1; }
+int sayuri_hip_tower_state(const sayuri_hip_ctx* c) { (void)c; return 0; }
 
 /* ---- the resident-input entry points bench.py times (upload / run / sync / download / time_runs + the per-class event
  * bookkeeping): the serial model again -- a run occupies the "device" for FAKE_HIP_SERIAL_US (or FAKE_HIP_DELAY_US) --

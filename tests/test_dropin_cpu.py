@@ -148,15 +148,25 @@ def test_a_run_does_not_halt_over_its_own_network_spelled_differently(tmp_path):
     assert d["per_rank"][0]["games_done"] > 8, d["per_rank"][0]  # more than one game per worker: worker 0 checked at least once
 
 
-def _bench_on_the_fake_device(tmp_path, world, port, extra=()):
+def _bench_on_the_fake_device(tmp_path, world, port, extra=(), launcher=True, devices=None, seconds=10, check=True):
+    """launcher=True: the driver's command line for N > 1 (torch.distributed.run around bench.py); launcher=False: the PLAIN
+    command `python bench.py --gpus N ...`, which has to start its N ranks itself."""
     fake = str(tmp_path / "libfake_hip.so")
     subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", os.path.join(ROOT, "tests", "fake_hip", "fake_hip.c"), "-o", fake, "-lpthread"])
-    env = dict(os.environ, SAYURI_FAKE_HIP_LIB=fake, FAKE_HIP_DEVICES=str(world), FAKE_HIP_SERIAL_US="3800", FAKE_HIP_CHEAP="1",
-               MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2",
-           "--dist-backend", "gloo", "--selfplay-seconds", "10", "--selfplay-games", "64", "--selfplay-visits", "16"] + list(extra)
+    env = dict(os.environ, SAYURI_FAKE_HIP_LIB=fake, FAKE_HIP_DEVICES=str(world if devices is None else devices),
+               FAKE_HIP_SERIAL_US="3800", FAKE_HIP_CHEAP="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--gpus", str(world), "--steps", "5", "--warmup", "2", "--dist-backend", "gloo", "--selfplay-seconds", str(seconds),
+            "--selfplay-games", "64", "--selfplay-visits", "16"] + list(extra)
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--master-port", str(port)] + args
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    if not check:
+        return r
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
@@ -175,6 +185,41 @@ def test_bench_two_ranks_on_the_fake_device(tmp_path):
     sp = d["selfplay"]
     assert sp["exchange_rounds"] > 0 and sp["nn_evals_per_sec"] > 0 and sp["moves_per_sec"] > 0 and not sp["halt_seen"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_plain_bench_command_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the shape of the driver's N = 1 command with another N): the
+    script starts the two ranks itself and the line says n_gpus 2, with both ranks in every exchange round.  Rounds 1-5 parsed
+    --gpus and never read it: such a command ran one rank and printed n_gpus 1."""
+    d = _bench_on_the_fake_device(tmp_path, 2, 29551, launcher=False)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 512
+    assert 0.5 * 2 * 256 / 3.8e-3 < d["value"] < 1.05 * 2 * 256 / 3.8e-3, d["value"]
+    sp = d["selfplay"]
+    assert sp["exchange_rounds"] > 0 and sp["exchange"]["world"] == 2 and sp["exchange"]["rounds"] == sp["exchange_rounds"]
+    assert sp["nn_evals_per_sec"] > 0 and sp["games_per_hour_empty_board_27min"] is not None
+    assert d["tower"] == "per-layer fallback" and "hipcc" in d  # the fake device has no persistent kernel, and the line says so
+
+
+def test_plain_bench_command_with_eight_ranks(tmp_path):
+    """The same for the configuration the scaling run uses: `python bench.py --gpus 8` on eight fake devices."""
+    d = _bench_on_the_fake_device(tmp_path, 8, 29553, launcher=False, seconds=6, extra=["--no-pump"])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 8 * 256
+    assert d["selfplay"]["exchange"]["world"] == 8 and d["selfplay"]["exchange_rounds"] > 0
+    assert "cpu_baseline" not in d and "config5" not in d
+
+
+def test_bench_refuses_more_ranks_than_devices(tmp_path):
+    """--gpus 4 on a box with two devices fails loudly before anything is started; and a launcher whose world size differs
+    from --gpus is refused by the ranks (the line's n_gpus would not be what was asked for)."""
+    r = _bench_on_the_fake_device(tmp_path, 4, 29555, launcher=False, devices=2, check=False)
+    assert r.returncode != 0 and "--gpus 4 but this box has 2" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    fake = str(tmp_path / "libfake_hip.so")
+    env = dict(os.environ, SAYURI_FAKE_HIP_LIB=fake, FAKE_HIP_DEVICES="2", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29557")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr, r.stderr[-2000:]
 
 
 def test_exchange_round_that_misses_its_deadline_gloo_world2(tmp_path):
