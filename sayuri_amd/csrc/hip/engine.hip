@@ -25,6 +25,7 @@
 #include "conv_mfma.h"
 #include "conv_glds.h"
 #include "conv_board.h"
+#include "conv_board_sx.h"
 #include "conv_tower.h"
 #include "head_board.h"
 #include "small_ops.h"
@@ -137,6 +138,7 @@ static void enable_big_lds_glds() {
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)&conv_board_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     for (const auto& e : kHeadEntries) (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)&conv_board_sx_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     for (const auto& e : kBoardEntries) {
         (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
         if (e.fn_se) (void)hipFuncSetAttribute((const void*)e.fn_se, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
@@ -170,6 +172,12 @@ struct EngineFlags {
     bool io_zc_in = true;  // packed records read where the caller has them (SAYURI_IO_ZC_IN=0: copied first, rounds 2-4)
     bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
     bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
+    bool se_split = true;              // SAYURI_SE_SPLIT=0: SE units of layers split over several channel tiles (384 channels) as
+                                       // se_pool / se_fc / se_scale again instead of inside the convolution (conv_board_sx.h)
+    int sx_dbg = 0;                    // SAYURI_SX_DBG=n: s_memtime timeline of the n-th split SE convolution of a profiled forward
+    int dbg_recycle_input = 0;         // SAYURI_DEBUG_RECYCLE_INPUT=1: hand the packed input's buffer back to the pool after the input
+                                       // convolution, as rounds 3-4 did (the row-stride table below then REFUSES the forward); =2: and
+                                       // switch the table off -- the race of rounds 3-4 is back (tests/test_gpu_fuzz.py shows that it sees it)
     int compute_streams = 1;
     int chains = 0;                    // SAYURI_CHAINS: 0 = the engine decides, 1 = never, N = N chains whenever a batch qualifies (Engine::forward)
     bool io_inorder = true;            // each ticket's upload, forward and download on the ticket's own stream (submit()); SAYURI_IO_INORDER=0: three streams and events
@@ -187,6 +195,9 @@ struct EngineFlags {
         f.tower = !off("SAYURI_TOWER");
         f.tower_chain = !off("SAYURI_TOWER_CHAIN");
         f.tower_gen_epi = !off("SAYURI_TOWER_GEN_EPI");
+        if (const char* e = getenv("SAYURI_DEBUG_RECYCLE_INPUT")) f.dbg_recycle_input = atoi(e);
+        f.se_split = !off("SAYURI_SE_SPLIT");
+        if (const char* e = getenv("SAYURI_SX_DBG")) f.sx_dbg = atoi(e);
         f.io_v2 = !off("SAYURI_IO_V2");
         f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");
         f.io_zc_in = f.io_zc && !off("SAYURI_IO_ZC_IN");
@@ -371,6 +382,8 @@ struct FcLayerDev {
     float* b = nullptr;
     void* img16 = nullptr;  // SE units of the fp16 engine: the LDS-staging image of conv_board.h (BoardSeParams::w1h / w2h)
     int img_bytes = 0;      // bytes of one image (whole 1 KiB pieces)
+    void* sx_img = nullptr; // ... and the per-channel-tile images of conv_board_sx.h (BoardSxParams::w1t / w2t), layers of 2-4 tiles of 128
+    int sx_bytes = 0;
     FcDev dev() const { return FcDev{wt, b, in, out}; }
 };
 
@@ -401,6 +414,46 @@ static bool make_se_images(int C, int se, int board, const float* sq_w, const fl
     float* bias = (float*)(img2->data() + (size_t)se * 2 * C * 2);
     std::copy(ex_b, ex_b + 2 * C, bias);
     std::copy(sq_b, sq_b + se, bias + 2 * C);
+    *w1_bytes_out = w1_bytes;
+    *w2_bytes_out = w2_bytes;
+    return true;
+}
+
+// The same two FCs cut by 128-channel tile for conv_board_sx.h (a layer whose channels are split over kts workgroups): per tile kt
+// the squeeze rows of its 128 channels (mean rows with the scaled-mean third folded in, once per board size; then the max rows),
+// and the excite rows that produce its channels' gamma and beta, with their bias and the squeeze bias behind them.
+static bool make_sx_images(int C, int se, int kts, int board, const float* sq_w, const float* sq_b, const float* ex_w, const float* ex_b,
+                           std::vector<f16>* img1, std::vector<unsigned char>* img2, int* w1_bytes_out, int* w2_bytes_out) {
+    if (se <= 0 || se % 4 || se > kSxSlots || kts < 2 || kts > 4 || C > kts * 128) return false;
+    const int w1_bytes = round_up(256 * se * 2, 1024), w2_bytes = round_up(se * 256 * 2 + (256 + se) * 4, 1024);
+    if (w1_bytes + w2_bytes > SxLds::stage_bytes) return false;
+    img1->assign((size_t)kts * (board - 1) * (w1_bytes / 2), (f16)0.f);
+    img2->assign((size_t)kts * w2_bytes, 0);
+    for (int kt = 0; kt < kts; ++kt) {
+        for (int bs = 2; bs <= board; ++bs) {
+            const float sc = ((float)bs - 14.f) / 10.f;
+            f16* d = img1->data() + ((size_t)kt * (board - 1) + (bs - 2)) * (w1_bytes / 2);
+            for (int r = 0; r < 256; ++r) {
+                const int c = kt * 128 + (r & 127);
+                if (c >= C) continue;  // pad channels: x is 0 there, and their rows stay 0
+                for (int o = 0; o < se; ++o) {
+                    const float* w = sq_w + (size_t)o * 3 * C;
+                    d[(size_t)r * se + o] = (f16)(r < 128 ? w[c] + sc * w[C + c] : w[2 * C + c]);
+                }
+            }
+        }
+        unsigned char* base = img2->data() + (size_t)kt * w2_bytes;
+        f16* h = (f16*)base;
+        float* bias = (float*)(base + (size_t)se * 256 * 2);
+        for (int o = 0; o < 256; ++o) {
+            const int c = kt * 128 + (o & 127);
+            if (c >= C) continue;  // gamma = sigmoid(0), beta = 0 on x = 0
+            const int row = o < 128 ? c : C + c;
+            for (int i = 0; i < se; ++i) h[((size_t)(i >> 2) * 256 + o) * 4 + (i & 3)] = (f16)ex_w[(size_t)row * se + i];
+            bias[o] = ex_b[row];
+        }
+        std::copy(sq_b, sq_b + se, bias + 256);
+    }
     *w1_bytes_out = w1_bytes;
     *w2_bytes_out = w2_bytes;
     return true;
@@ -710,6 +763,7 @@ public:
         if (ticket < 0 || ticket > 1 || !tick_ev_[ticket]) return fail("wait: bad ticket");
         HIP_OK(hipSetDevice(device_));
         HIP_OK(hipEventSynchronize(tick_ev_[ticket]));
+        if (sx_check()) return -1;
         if (fwdstat_ && fs_pending_[ticket]) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, fs_ev_[ticket][0], fs_ev_[ticket][1]) == hipSuccess) {
@@ -907,7 +961,7 @@ public:
     int sync() override {
         HIP_OK(hipSetDevice(device_));
         HIP_OK(hipStreamSynchronize(stream_));
-        return 0;
+        return sx_check();
     }
 
     int download(float* prob, float* pass, float* misc, float* own) override {
@@ -918,7 +972,7 @@ public:
         if (misc) HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, stream_));
         if (own) HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, stream_));
         HIP_OK(hipStreamSynchronize(stream_));
-        return 0;
+        return sx_check();
     }
 
     int time_runs(int iters, float* ms) override {
@@ -988,6 +1042,16 @@ public:
                 const unsigned long long* d = &h[wg * 8];
                 fprintf(stderr, "[heads timeline wg%d] DMA + K loop %llu | act, per-pixel MFMA, pooling partials %llu | pool fold %llu | FC 1 %llu | FC 2 + row bias %llu | stores %llu | total %llu\n",
                         wg, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[6] - d[0]);
+            }
+        }
+        if (d_sxdbg_) {  // SAYURI_SX_DBG: the split SE convolution from inside (100 MHz ticks; blocks 0 / 8 / 16 = the siblings of a tile, 1)
+            std::vector<unsigned long long> h(4 * 64);
+            HIP_OK(hipMemcpy(h.data(), d_sxdbg_, h.size() * 8, hipMemcpyDeviceToHost));
+            static const char* who[4] = {"block 0 (tile 0, kt 0)", "block 8 (tile 0, kt 1)", "block 16 (tile 0, kt 2)", "block 1 (tile 1, kt 0)"};
+            for (int wg = 0; wg < 4; ++wg) {
+                const unsigned long long* d = &h[(size_t)wg * 64];
+                fprintf(stderr, "[split SE timeline %s] start +%llu | K loop %llu | pooling %llu | squeeze + publish %llu | siblings in %llu | mid + excite %llu | gate %llu | epilogue %llu | total %llu\n",
+                        who[wg], d[0] - h[0], d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[7] - d[0]);
             }
         }
         if (d_dbg_) {  // SAYURI_BOARD_DBG: s_memtime timeline of the last tower convolution (workgroups 0-3, all waves)
@@ -1246,6 +1310,13 @@ private:
         for (IoSlot& io : io_) {
             if (dev_alloc(&io.gate, (size_t)max_batch_ * 2 * round_up(desc_.residual_channels, 32))) return -1;
             if (dev_alloc(&io.separt, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
+            // conv_board_sx.h: the granules the sibling channel tiles of a board tile exchange, [tile][kt][sample][slot]
+            if (sx_kts_ && dev_alloc(&io.sx_xchg, (size_t)max_batch_ * sx_kts_ * kSxMaxSub * kSxSlots)) return -1;
+        }
+        if (sx_kts_) {
+            HIP_OK(hipHostMalloc((void**)&sx_err_host_, 64, hipHostMallocMapped));
+            std::memset(sx_err_host_, 0, 64);
+            HIP_OK(hipHostGetDevicePointer((void**)&sx_err_dev_, sx_err_host_, 0));
         }
         finalized_ = true;
         select_slot(0);
@@ -1271,8 +1342,20 @@ private:
             std::vector<f16> img1;
             std::vector<unsigned char> img2;
             int w1_bytes = 0, w2_bytes = 0;
-            if (!make_se_images(C, se, board_, sq.hw.data(), sq.hb.data(), ex.hw.data(), ex.hb.data(), &img1, &img2, &w1_bytes, &w2_bytes))
+            if (!make_se_images(C, se, board_, sq.hw.data(), sq.hb.data(), ex.hw.data(), ex.hb.data(), &img1, &img2, &w1_bytes, &w2_bytes)) {
+                // a layer too wide for one workgroup: the per-channel-tile images of conv_board_sx.h
+                const int kts = round_up(C, 128) / 128;
+                if (flags_.se_split && round_up(C, 32) == kts * 128 &&
+                    make_sx_images(C, se, kts, board_, sq.hw.data(), sq.hb.data(), ex.hw.data(), ex.hb.data(), &img1, &img2, &w1_bytes, &w2_bytes)) {
+                    f16* d1 = nullptr;
+                    unsigned char* d2 = nullptr;
+                    if (dev_upload(&d1, img1) || dev_upload(&d2, img2)) return -1;
+                    sq.sx_img = d1; sq.sx_bytes = w1_bytes;
+                    ex.sx_img = d2; ex.sx_bytes = w2_bytes;
+                    sx_kts_ = kts;
+                }
                 continue;
+            }
             f16* d1 = nullptr;
             unsigned char* d2 = nullptr;
             if (dev_upload(&d1, img1) || dev_upload(&d2, img2)) return -1;
@@ -1289,6 +1372,9 @@ private:
         ident_.clear();
         if (h_geom_) (void)hipHostFree(h_geom_);
         h_geom_ = nullptr;
+        if (sx_err_host_) (void)hipHostFree(sx_err_host_);
+        sx_err_host_ = nullptr;
+        sx_err_dev_ = nullptr;
         for (TowerSlot& ts : tower_)
             for (int i = 0; i < 2; ++i) {
                 if (ts.stage[i]) (void)hipHostFree(ts.stage[i]);
@@ -1358,6 +1444,7 @@ private:
             }
             launch();
             HIP_OK(hipGetLastError());
+            if (rg_ntiles_ < 0) rows_reset();  // a launch on the forward's one stream: ordered against everything behind it
             if (match) {
                 group_counts_.back() += 1;
                 light_flops_ = flops;
@@ -1368,6 +1455,7 @@ private:
         HIP_OK(hipEventRecord(ev0_, stream_));
         launch();
         HIP_OK(hipGetLastError());
+        rows_reset();
         HIP_OK(hipEventRecord(ev1_, stream_));
         HIP_OK(hipEventSynchronize(ev1_));
         float ms = 0.f;
@@ -1526,7 +1614,11 @@ private:
         const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out);
         const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
         if (board_row_order_ok(L, be, bp, act)) { p.w = L.w_board; p.bias = L.bias_board; bp.row_order = 1; }
-        if (!split && tower_ok(be->kot) && !bp.dbg) return tower_append(be->kot, sp, true, flops, bytes);
+        const bool to_run = !split && tower_ok(be->kot) && !bp.dbg;
+        if (!run_.empty() && !(to_run && run_kot_ == be->kot) && tower_flush()) return -1;
+        if (rows_use(in, L.cin_s, "conv3x3_tower_se") || rows_use(out, L.cout_s, "conv3x3_tower_se") || rows_use(res, L.cout_s, "conv3x3_tower_se"))
+            return -1;
+        if (to_run) return tower_append(be->kot, sp, true, flops, bytes);
         const auto fn = be->fn_se;
         const size_t lds = be->lds(board_plan_.npos);
         const int grid = split ? nbig : board_plan_.ntiles;
@@ -1543,6 +1635,89 @@ private:
         const int grid2 = rest.c.num_pix_tiles;  // be->kot covers the layer: one channel tile
         if (timed("conv3x3_tower", flops, bytes, [&] { hipLaunchKernelGGL(fn2, dim3(grid2), dim3(512), lds, stream_, rest); })) return -1;
         return se_unit(sq, ex, out, res, C, round_up(C, 32), act, nbig);
+    }
+
+
+    // A block's last 3x3 convolution with its SE unit when the layer's channels are split over kts = 2..4 workgroups of 128
+    // (conv_board_sx.h: the siblings exchange their partial squeeze sums inside the launch).  Returns 1 when the form does not apply
+    // (the caller runs conv + se_unit), 0 / -1.  WHICH samples take it is a property of the sample alone: a board of which at
+    // most kSxMaxSub fit a tile (9x9 and larger) ALWAYS does, a smaller one NEVER -- the device order is largest first, so the
+    // tiles [0, T) of the batch are fused and [T, ntiles) = the samples behind take the plain convolution + the unit's three
+    // kernels, exactly as conv_se splits a mixed batch.  Honours the tile range of a chained forward.
+    int conv_sx(const ConvLayerDev& L, const FcLayerDev& sq, const FcLayerDev& ex, const T* in, T* out, const T* res, int C, int act) {
+        if constexpr (sizeof(T) != 2) return 1;
+        if (!flags_.se_split || !sq.sx_img || !ex.sx_img || !sx_kts_ || L.ko_pad != sx_kts_ * 128 || L.cout_s != L.ko_pad) return 1;
+        int bkt = 0;
+        if (!choose_board(L, &bkt)) return 1;
+        const BoardEntry* be = nullptr;
+        for (const auto& e : kBoardEntries)
+            if (e.kot == 128 && e.lds(board_plan_.npos) <= kMaxLds) be = &e;
+        if (!be) return 1;
+        auto per_tile = [](int bs) {
+            BoardPack pk;
+            int k = 0;
+            while (pk.fits(bs)) { pk.add(bs); ++k; }
+            return k;
+        };
+        int nf = 0;
+        while (nf < geom_.n && per_tile(geom_.bsz[nf]) <= kSxMaxSub) ++nf;
+        int T0 = 0;  // first tile that is not fused
+        while (T0 < board_plan_.ntiles && board_plan_.tile_first[T0] < nf) ++T0;
+        const int t0 = rg_tile0_, t1 = rg_tile0_ + range_ntiles();
+        const int f0 = t0, f1 = std::min(t1, T0), r0 = std::max(t0, T0), r1 = t1;
+        if (!run_.empty() && tower_flush()) return -1;
+        const BoardTabs* tabs = nullptr;
+        if (board_tabs(&tabs)) return -1;
+        if (rows_use(in, L.cin_s, "conv3x3_tower_sx") || rows_use(out, L.cout_s, "conv3x3_tower_sx") || rows_use(res, L.cout_s, "conv3x3_tower_sx"))
+            return -1;
+        const unsigned epoch = sx_epoch0_ + 1u + (unsigned)sx_idx_++;
+        BoardSxParams sp;
+        std::memset(&sp, 0, sizeof(sp));
+        BoardParams& bp = sp.b;
+        bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos; bp.dbg = nullptr;
+        bp.uniform_info = board_plan_.uniform_info;
+        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && flags_.arith) ? 1 : 0;
+        ConvParams& p = bp.c;
+        p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
+        p.g = dgeom();
+        p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
+        p.taps = 9; p.act = act;
+        const size_t lds = be->lds(board_plan_.npos);
+        const int kts = sx_kts_;
+        const double px_all = range_px();
+        if (f1 > f0) {
+            p.npos = f0; p.num_pix_tiles = f1 - f0;
+            sp.w1t = sq.sx_img; sp.w2t = ex.sx_img; sp.w1_bytes = sq.sx_bytes; sp.w2_bytes = ex.sx_bytes;
+            sp.nsizes = board_ - 1; sp.se = sq.out; sp.kts = kts;
+            sp.xchg = io_[cur_slot_].sx_xchg; sp.epoch = epoch; sp.err = sx_err_dev_;
+            if (flags_.sx_dbg > 0 && profiling_ && sx_idx_ == flags_.sx_dbg) {
+                if (!d_sxdbg_ && dev_alloc(&d_sxdbg_, 4 * 64)) return -1;
+                sp.b.dbg = d_sxdbg_;
+            }
+            const int s0 = board_plan_.tile_first[f0], s1 = board_plan_.tile_first[f1];
+            const double px = (double)(geom_.off[s1] - geom_.off[s0]);
+            const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * (s1 - s0) * ((double)sq.in * sq.out + (double)ex.in * ex.out);
+            const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
+            const int grid = (f1 - f0 + 7) / 8 * 8 * kts;
+            if (timed("conv3x3_tower_sx", flops, bytes, [&] { hipLaunchKernelGGL(conv_board_sx_kernel<2>, dim3(grid), dim3(512), lds, stream_, sp); }))
+                return -1;
+        }
+        if (r1 > r0) {
+            // the small boards behind: the plain convolution (no activation, no residual) on their tiles, then the unit's kernels
+            BoardParams rest = bp;
+            rest.c.res = nullptr; rest.c.act = kIdentity;
+            rest.c.npos = r0; rest.c.num_pix_tiles = r1 - r0;
+            const int s0 = board_plan_.tile_first[r0], s1 = board_plan_.tile_first[r1];
+            const double px = (double)(geom_.off[s1] - geom_.off[s0]);
+            const double flops = 2.0 * px * L.cin * L.cout * 9;
+            const double bytes = sizeof(T) * (px * L.cin + px * L.cout + (double)L.cin * L.cout * 9);
+            const auto fn2 = be->fn;
+            const int grid2 = (r1 - r0) * kts;
+            if (timed("conv3x3_tower", flops, bytes, [&] { hipLaunchKernelGGL(fn2, dim3(grid2), dim3(512), lds, stream_, rest); })) return -1;
+            if (se_unit(sq, ex, out, res, C, round_up(C, 32), act, s0, s1 - s0)) return -1;
+        }
+        (void)px_all;
+        return 0;
     }
 
     int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
@@ -1578,7 +1753,11 @@ private:
             const double px = range_px();
             const double flops = 2.0 * px * L.cin * L.cout * 9;
             const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
-            if (bkt == 1 && tower_ok(be->kot) && !bp.dbg && rg_ntiles_ < 0) {
+            const bool to_run = bkt == 1 && tower_ok(be->kot) && !bp.dbg && rg_ntiles_ < 0;
+            // a pending run this layer does not join ends here (a launch = an ordered point: the table starts afresh)
+            if (!run_.empty() && !(to_run && run_kot_ == be->kot) && tower_flush()) return -1;
+            if (rows_use(in, L.cin_s, name) || rows_use(out, L.cout_s, name) || rows_use(res, L.cout_s, name)) return -1;
+            if (to_run) {
                 if (board_row_order_ok(L, be, bp, p.act)) { p.w = L.w_board; p.bias = L.bias_board; bp.row_order = 1; }
                 BoardSeParams sp;
                 std::memset(&sp, 0, sizeof(sp));
@@ -1668,6 +1847,44 @@ private:
 
     // small pool of activation buffers
     static constexpr int kNumBufs = 6;
+    // -------------------------------------------------------------- who may write which bytes when (the buffer table)
+    // Launches on one stream are ordered grid-wide; the layers INSIDE a persistent tower run are not (a workgroup walks the
+    // whole run on its own clock), and neither are the chains of a chained forward (streams of their own).  In such an
+    // UNORDERED SCOPE the only order is "this workgroup's / this chain's earlier layers", so a buffer may be written while
+    // other workgroups still have to read it -- sound exactly when the bytes a tile touches in a buffer are the same in every
+    // layer of the scope, i.e. when the buffer has ONE ROW STRIDE throughout it (a tile is whole samples, a sample's rows
+    // start at sample * slot_pix * stride):
+    //
+    //   buffer                    written by                     row stride              may be recycled
+    //   ------------------------  -----------------------------  ----------------------  ------------------------------------------
+    //   `in` (packed input)       pack_bits / pack_input         input conv's cin_s (64) never inside the forward (kept to its end)
+    //   pool buffers x, y, t0...  the convolution they are `out` the tower's cout_s      as soon as the layer that reads them is
+    //                             of (epilogue, own tile's rows)  (256 / 384 / 128)        appended: give() -> take(), SAME stride only
+    //   d_separt_, d_gate_        se_pool / se_fc, per sample     per-sample records      per sample, inside its chain
+    //   se_xchg (384-ch SE)       the sibling channel tiles       per (tile, channel tile) next SE layer (tagged with the layer's epoch)
+    //   d_prob_ ... d_own_        the heads kernel                per sample              by the ticket's next submit
+    //
+    // rounds 3-4 broke the first line (the input's buffer went back to the pool and came out again as a block's output with
+    // stride 256: a late workgroup's input lay under an early workgroup's third layer).  The table below is that rule as a
+    // run-time check: every use of a pool buffer inside an unordered scope names its stride, and a second stride is refused.
+    int rows_stride_[kNumBufs] = {};          // 0: not used yet in the current scope
+    const char* rows_first_[kNumBufs] = {};   // the layer that fixed it
+    void rows_reset() {
+        for (int i = 0; i < kNumBufs; ++i) rows_stride_[i] = 0;
+    }
+    int rows_use(const T* p, int stride, const char* layer) {
+        if (!p || flags_.dbg_recycle_input >= 2) return 0;
+        for (int i = 0; i < kNumBufs; ++i) {
+            if (bufs_[i] != p) continue;
+            if (rows_stride_[i] && rows_stride_[i] != stride)
+                return fail(std::string("activation buffer ") + std::to_string(i) + " is used with row stride " + std::to_string(stride) + " by " +
+                            layer + " and with " + std::to_string(rows_stride_[i]) + " by " + (rows_first_[i] ? rows_first_[i] : "?") +
+                            " inside one persistent run / chained forward: the rows of different tiles would overlap");
+            rows_stride_[i] = stride;
+            rows_first_[i] = layer;
+        }
+        return 0;
+    }
     int take() {
         for (int i = 0; i < kNumBufs; ++i)
             if (!busy_[i]) { busy_[i] = true; return i; }
@@ -1685,6 +1902,18 @@ private:
     int forward() {
         const int G = chains_for_batch();
         last_chains_ = G;
+        rows_reset();
+        if (sx_kts_) {
+            IoSlot& io = io_[cur_slot_];
+            int nse = 0;
+            for (const auto& b : blocks_) nse += b.apply_se ? 1 : 0;
+            if (io.sx_epoch > 0xfff00000u) {  // tags about to wrap: start over on a clean buffer (stream order: behind the last readers)
+                HIP_OK(hipMemsetAsync(io.sx_xchg, 0, sizeof(unsigned long long) * (size_t)max_batch_ * sx_kts_ * kSxMaxSub * kSxSlots, stream_));
+                io.sx_epoch = 0;
+            }
+            sx_epoch0_ = io.sx_epoch;
+            io.sx_epoch += (unsigned)nse;
+        }
         if (G <= 1) return forward_graph();
         if (chain_setup(G)) return -1;
         const BoardTabs* tabs = nullptr;
@@ -1720,6 +1949,7 @@ private:
         for (int i = 0; i < kNumBufs; ++i) busy_[i] = false;
         dbg_call_ = 0;
         dbg_se_call_ = 0;
+        sx_idx_ = 0;
         run_.clear();
         table_used_ = 0;
 
@@ -1760,6 +1990,7 @@ private:
                     return -1;
             }
             if (conv("conv3x3_input", L, bufs_[in], bufs_[x], nullptr, act)) return -1;
+            if (flags_.dbg_recycle_input) give(in);  // SAYURI_DEBUG_RECYCLE_INPUT: rounds 3-4's hand-back, to show what catches it
             // `in` is NOT handed back: it stays the packed input's buffer for the whole forward.  Its rows have the input
             // convolution's channel stride (64), every later buffer the tower's (256 / 384): recycled as a block's output, sample
             // m's rows would lie on top of sample n's packed input.  With a kernel boundary between every two layers and one
@@ -1785,6 +2016,9 @@ private:
                 if (se) {
                     fused = conv_se(cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)),
                                     fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[t0], bufs_[y], bufs_[x], C, act);
+                    if (fused == 1)
+                        fused = conv_sx(cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)),
+                                        fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[t0], bufs_[y], bufs_[x], C, act);
                     if (fused < 0) return -1;
                     se_done = fused == 0;
                 }
@@ -1971,6 +2205,21 @@ private:
         if (lrc != hipSuccess) return fail(std::string("hipModuleLaunchKernel(conv_tower_kernel): ") + hipGetErrorString(lrc));
         return rc;
     }
+    // conv_board_sx.h (SE units of layers split over channel tiles)
+    int sx_kts_ = 0;                      // channel tiles per layer (0: the network has no such unit)
+    unsigned* sx_err_host_ = nullptr;     // host-visible word a workgroup sets when its wait for the siblings ran out
+    unsigned* sx_err_dev_ = nullptr;
+    unsigned sx_epoch0_ = 0;              // tags of the current forward: sx_epoch0_ + 1 + index of the SE layer
+    int sx_idx_ = 0;
+    int sx_check() {
+        if (sx_err_host_ && *(volatile unsigned*)sx_err_host_) {
+            const unsigned e = *(volatile unsigned*)sx_err_host_;
+            *(volatile unsigned*)sx_err_host_ = 0;
+            return fail("SE exchange between the channel tiles of a board tile timed out (epoch " + std::to_string(e) +
+                        "): the results of this forward are invalid; SAYURI_SE_SPLIT=0 runs the unit as separate kernels");
+        }
+        return 0;
+    }
     EngineFlags flags_;
     hipModule_t tower_mod_ = nullptr;
     hipFunction_t tower_fn_[2] = {nullptr, nullptr};
@@ -2010,6 +2259,8 @@ private:
         int *off = nullptr, *bsz = nullptr, *perm = nullptr;
         T* bufs[kNumBufs] = {};
         float *gate = nullptr, *separt = nullptr;
+        unsigned long long* sx_xchg = nullptr;
+        unsigned sx_epoch = 0;  // the last tag used in sx_xchg
         std::map<int, TileTabs> tabs;   // index tables of the geometry this slot last ran (keyed by tile variant)
         BoardTabs board;
         std::vector<int> tabs_bsz;
@@ -2052,6 +2303,7 @@ private:
     int head_pt_ = 0, head_vt_ = 0;
     unsigned long long* d_hdbg_ = nullptr;  // SAYURI_HEADS_DBG timeline of head_board_kernel
     unsigned long long* d_dbg_ = nullptr;  // SAYURI_BOARD_DBG timeline of one tower convolution
+    unsigned long long* d_sxdbg_ = nullptr;  // SAYURI_SX_DBG timeline of one split SE convolution
     int dbg_call_ = 0, dbg_se_call_ = 0;
     bool dbg_is_se_ = false;
     bool board_plan_valid_ = false;

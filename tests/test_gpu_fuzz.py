@@ -1,0 +1,311 @@
+"""Standing bit-identity fuzz: a request's result is a function of the request (reference batch_forward_pipe.cc:15-33,48-68).
+
+The parity tests compare with the oracle at 1e-4 / 4e-3 x scale.  A scheduling-dependent corruption can live below that: the race of
+rounds 3-4 (the packed input's buffer recycled inside a persistent run) put ~1e-4 on outputs of scale 1 and
+passed every tolerance test for two rounds.  What catches that class is comparing BITS between two executions of the same engine that
+differ only in how the work is scheduled:
+
+    reference  = the same network on the same device, one launch per layer (SAYURI_TOWER=0), one chain (SAYURI_CHAINS=1), one
+                 blocking forward at a time on one stream, every pool position evaluated once in small batches
+    product    = the engine as shipped: persistent tower launch, chains, two tickets in flight on their own streams, packed
+                 records read in place, while (in half of the scenarios) a second context keeps the chip busy
+
+Every scenario draws a batch geometry (1 ... 600 positions; uniform 19x19, a 9/13/19 mix, or anything from 2x2 to 19x19), a
+network (20b x 256, 40b x 384, 6b x 96), one or two tickets in flight, chains auto / off, packed / fp32 planes, and checks
+EVERY sample of EVERY batch against the reference bits of its position.  test_fuzz_sees_the_recycled_input_buffer shows that the
+net is tight enough: with rounds 3-4's hand-back of the input buffer switched on again (SAYURI_DEBUG_RECYCLE_INPUT=2) the same
+fuzz comes back with wrong samples; with =1 the engine's row-stride table (engine.hip, "who may write which bytes when")
+refuses the forward before anything is launched.
+"""
+import ctypes
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from _golden import Golden
+from sayuri_amd import _lib
+from sayuri_amd import weights as W
+from sayuri_amd.engine import pack_planes
+from sayuri_amd.pipe import HipForwardPipe, hip_forward_packed_raw, hip_forward_raw
+
+pytestmark = pytest.mark.gpu
+
+B = 19
+MAXB = 640
+WORDS = 37 * 12 + 8
+FP = ctypes.POINTER(ctypes.c_float)
+IP = ctypes.POINTER(ctypes.c_int)
+MAIN_SIZES, ODD_SIZES = (9, 13, 19), (2, 3, 5, 7, 11, 14, 16, 17)
+SWITCHES = ("SAYURI_TOWER", "SAYURI_CHAINS", "SAYURI_DEBUG_RECYCLE_INPUT")
+
+
+class Pool:
+    """Positions of the fuzz: planes on the NN grid, packed records, board sizes -- 40 per main size, 6 per odd size."""
+
+    def __init__(self, seed=606):
+        sizes = [s for s in MAIN_SIZES for _ in range(40)] + [s for s in ODD_SIZES for _ in range(6)]
+        planes = W.synthetic_planes(len(sizes), sizes, seed=seed)
+        self.bsz = np.asarray(sizes, np.int32)
+        self.grid = np.zeros((len(sizes), 43, B * B), np.float32)
+        for i, (p, bs) in enumerate(zip(planes, sizes)):
+            self.grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+        self.rec = np.stack([pack_planes(p, 37) for p in planes]).astype(np.uint32)
+        self.by_size = {s: np.flatnonzero(self.bsz == s) for s in set(sizes)}
+
+    def draw(self, rng, n, mix):
+        if mix == "uniform19":
+            return rng.choice(self.by_size[19], size=n)
+        if mix == "mixed":
+            return np.asarray([rng.choice(self.by_size[int(s)]) for s in rng.choice(MAIN_SIZES, size=n)])
+        return rng.integers(0, len(self.bsz), size=n)  # "wild": anything from 2x2 to 19x19
+
+
+def make_pipe(path, env):
+    keep = {k: os.environ.get(k) for k in SWITCHES}
+    for k in SWITCHES:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        return HipForwardPipe(path, board_size=B, batch_size=MAXB, fp16=True)  # the switches are read at creation
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def reference_bits(path, pool):
+    """prob / pass / misc / own of every pool position from the per-layer, one-chain, one-stream engine."""
+    pipe = make_pipe(path, {"SAYURI_TOWER": "0", "SAYURI_CHAINS": "1"})
+    try:
+        ctx = pipe.ctx(0)
+        assert _lib.hip().sayuri_hip_tower_state(ctx) == 0
+        outs = []
+        for lo in range(0, len(pool.bsz), 96):
+            sl = slice(lo, lo + 96)
+            outs.append(hip_forward_raw(ctx, pool.grid[sl], pool.bsz[sl], B))
+        ref = tuple(np.concatenate([o[k] for o in outs]) for k in range(4))
+        # the reference itself must not care about batch mates: the pool once more, reversed, in batches of another size
+        order = np.arange(len(pool.bsz))[::-1]
+        for lo in range(0, len(order), 50):
+            idx = order[lo:lo + 50]
+            again = hip_forward_raw(ctx, pool.grid[idx], pool.bsz[idx], B)
+            for a, b in zip(ref, again):
+                assert np.array_equal(a[idx], b), "the per-layer reference engine depends on the batch"
+        return ref
+    finally:
+        pipe.Destroy()
+
+
+class Pinned:
+    """Two sets of page-locked staging buffers for submit / wait (what the pump owns)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        lib.sayuri_hip_host_alloc.restype = ctypes.c_void_p
+        lib.sayuri_hip_host_alloc.argtypes = [ctypes.c_size_t]
+        lib.sayuri_hip_host_free.argtypes = [ctypes.c_void_p]
+        lib.sayuri_hip_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, FP, IP, FP, FP, FP, FP, IP]
+        lib.sayuri_hip_submit_packed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, IP, FP, FP, FP, FP, IP]
+        lib.sayuri_hip_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.sizes = (MAXB * 43 * B * B, MAXB * 5 * B * B, MAXB * 5, MAXB * 15, MAXB * B * B, MAXB)
+        self.sets = []
+        for _ in range(2):
+            ptrs = [lib.sayuri_hip_host_alloc(k * 4) for k in self.sizes]
+            assert all(ptrs)
+            self.sets.append(ptrs)
+
+    def close(self):
+        for ptrs in self.sets:
+            for q in ptrs:
+                self.lib.sayuri_hip_host_free(ctypes.c_void_p(q))
+
+    def submit(self, ctx, i, pool, idx, packed):
+        pl, pr, pa, mi, ow, bz = self.sets[i]
+        n = len(idx)
+        np.ctypeslib.as_array(ctypes.cast(bz, ctypes.POINTER(ctypes.c_int32)), (n,))[:] = pool.bsz[idx]
+        tick = ctypes.c_int(-1)
+        args = (ctypes.cast(bz, IP), ctypes.cast(pr, FP), ctypes.cast(pa, FP), ctypes.cast(mi, FP), ctypes.cast(ow, FP), ctypes.byref(tick))
+        if packed:
+            np.ctypeslib.as_array(ctypes.cast(pl, ctypes.POINTER(ctypes.c_uint32)), (n * WORDS,))[:] = pool.rec[idx].ravel()
+            rc = self.lib.sayuri_hip_submit_packed(ctx, n, ctypes.c_void_p(pl), 37, *args)
+        else:
+            np.ctypeslib.as_array(ctypes.cast(pl, FP), (n * 43 * B * B,))[:] = pool.grid[idx].ravel()
+            rc = self.lib.sayuri_hip_submit(ctx, n, ctypes.cast(pl, FP), *args)
+        assert rc == 0, self.lib.sayuri_hip_last_error()
+        return tick.value
+
+    def wait(self, ctx, i, tick, n):
+        assert self.lib.sayuri_hip_wait(ctx, tick) == 0, self.lib.sayuri_hip_last_error()
+        _, pr, pa, mi, ow, _ = self.sets[i]
+        return (np.ctypeslib.as_array(ctypes.cast(pr, FP), (n, 5, B * B)).copy(), np.ctypeslib.as_array(ctypes.cast(pa, FP), (n, 5)).copy(),
+                np.ctypeslib.as_array(ctypes.cast(mi, FP), (n, 15)).copy(), np.ctypeslib.as_array(ctypes.cast(ow, FP), (n, B * B)).copy())
+
+
+def wrong_samples(ref, got, idx):
+    """Samples of a batch whose bits differ from their position's reference bits (any of the four outputs)."""
+    bad = np.zeros(len(idx), bool)
+    for a, b in zip(ref, got):
+        a = a[idx]
+        bad |= (a.reshape(len(idx), -1).view(np.uint32) != b.reshape(len(idx), -1).view(np.uint32)).any(axis=1)
+    return np.flatnonzero(bad)
+
+
+class Hammer:
+    """A second context of another network that runs forwards back to back on its own streams while a scenario runs."""
+
+    def __init__(self, pipe, pool):
+        self.pipe = pipe
+        self.ctx, self.pool, self.stop, self.count, self.err = pipe.ctx(0), pool, threading.Event(), 0, None
+        self.idx = np.arange(200) % len(pool.bsz)
+        self.thread = None
+
+    def start(self):
+        self.stop.clear()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            while not self.stop.is_set():
+                hip_forward_raw(self.ctx, self.pool.grid[self.idx], self.pool.bsz[self.idx], B)
+                self.count += 1
+        except Exception as e:  # noqa: BLE001
+            self.err = e
+
+    def end(self):
+        self.stop.set()
+        self.thread.join()
+        assert self.err is None, self.err
+
+
+def draw_n(rng):
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        return int(rng.integers(1, 9))
+    if kind == 1:
+        return int(rng.integers(9, 130))
+    if kind == 2:
+        return int(rng.integers(250, 262))      # around one full round of the CUs
+    if kind == 3:
+        return int(rng.integers(130, 250))
+    return int(rng.integers(262, 601))          # more tiles than CUs: workgroups of a second round start late
+
+
+def run_fuzz(nets, scenarios, seed, env_extra=None, stop_at_first=False, tmp_weights_dir=None, only=None):
+    """-> list of (scenario description, wrong samples, batch size) for every batch that came back with wrong bits."""
+    lib = _lib.hip()
+    pool = Pool()
+    rng = np.random.default_rng(seed)
+    paths = {name: Golden(name, tmp_weights_dir).weights_path for name in nets}
+    refs = {name: reference_bits(paths[name], pool) for name in nets}
+    pipes, pinned, failures, ran = {}, Pinned(lib), [], []
+    env_extra = env_extra or {}
+
+    def pipe_for(name, chains):
+        key = (name, chains)
+        if key not in pipes:
+            env = dict(env_extra)
+            if chains == "1":
+                env["SAYURI_CHAINS"] = "1"
+            pipes[key] = make_pipe(paths[name], env)
+        return pipes[key]
+
+    hammers = {}
+    try:
+        for k in range(scenarios):
+            name = only or str(rng.choice(nets, p=[0.45, 0.35, 0.2][:len(nets)] if len(nets) == 3 else None))
+            sc = dict(k=k, net=name, n=draw_n(rng), mix=str(rng.choice(["uniform19", "mixed", "mixed", "wild"])),
+                      tickets=int(rng.integers(1, 3)), chains=str(rng.choice(["auto", "1"])), packed=bool(rng.integers(0, 2)),
+                      hammer=bool(rng.integers(0, 2)))
+            pipe = pipe_for(name, sc["chains"])
+            ctx = pipe.ctx(0)
+            ham = None
+            if sc["hammer"]:
+                other = [x for x in nets if x != name][0] if len(nets) > 1 else name
+                if other not in hammers:
+                    hammers[other] = Hammer(make_pipe(paths[other], dict(env_extra)), pool)
+                ham = hammers[other]
+                ham.start()
+            try:
+                batches = []
+                if sc["tickets"] == 1:
+                    for _ in range(2):
+                        idx = pool.draw(rng, sc["n"], sc["mix"])
+                        got = (hip_forward_packed_raw(ctx, pool.rec[idx], 37, pool.bsz[idx], B) if sc["packed"] else
+                               hip_forward_raw(ctx, pool.grid[idx], pool.bsz[idx], B))
+                        batches.append((idx, got))
+                else:
+                    # two DIFFERENT batches in flight, six rounds; the second batch has its own size and mix
+                    n2, mix2 = draw_n(rng), str(rng.choice(["uniform19", "mixed", "wild"]))
+                    idxs = [pool.draw(rng, sc["n"], sc["mix"]), pool.draw(rng, n2, mix2)]
+                    sc["n2"], sc["mix2"] = n2, mix2
+                    tick = [pinned.submit(ctx, 0, pool, idxs[0], sc["packed"]), pinned.submit(ctx, 1, pool, idxs[1], sc["packed"])]
+                    for r in range(6):
+                        i = r & 1
+                        batches.append((idxs[i], pinned.wait(ctx, i, tick[i], len(idxs[i]))))
+                        if r < 4:
+                            idxs[i] = pool.draw(rng, len(idxs[i]), sc["mix"] if i == 0 else mix2)
+                            tick[i] = pinned.submit(ctx, i, pool, idxs[i], sc["packed"])
+            finally:
+                if ham is not None:
+                    ham.end()
+            sc["chains_ran"] = int(lib.sayuri_hip_last_chains(ctx))
+            ran.append(sc)
+            for idx, got in batches:
+                bad = wrong_samples(refs[name], got, idx)
+                if len(bad):
+                    failures.append((dict(sc), bad.tolist()[:16], len(idx), len(bad)))
+            if failures and stop_at_first:
+                break
+    finally:
+        pinned.close()
+        for p in pipes.values():
+            p.Destroy()
+        for h in hammers.values():
+            h.pipe.Destroy()
+    return failures, ran
+
+
+def test_bit_identity_fuzz(tmp_weights_dir, capsys):
+    """50 random scenarios; every sample of every batch must carry the bits of the per-layer, one-stream engine."""
+    t0 = time.time()
+    nets = ["net_20b256", "net_40b384", "net_6b96"]
+    seed = int(os.environ.get("SAYURI_FUZZ_SEED", "20260930"))
+    failures, ran = run_fuzz(nets, int(os.environ.get("SAYURI_FUZZ_SCENARIOS", "50")), seed, tmp_weights_dir=tmp_weights_dir)
+    with capsys.disabled():
+        by = {}
+        for sc in ran:
+            by[sc["net"]] = by.get(sc["net"], 0) + 1
+        print(f"\n[fuzz] seed {seed}: {len(ran)} scenarios in {time.time() - t0:.1f} s, by network {by}, "
+              f"two tickets in {sum(1 for s in ran if s['tickets'] == 2)}, hammered {sum(1 for s in ran if s['hammer'])}, "
+              f"packed {sum(1 for s in ran if s['packed'])}, chained forwards {sum(1 for s in ran if s['chains_ran'] > 1)}, "
+              f"batches of more than 256: {sum(1 for s in ran if s['n'] > 256)}; wrong batches: {len(failures)}")
+    assert not failures, failures[:5]
+    # the draw must have reached the corners this test exists for
+    assert any(s["net"] == "net_20b256" and s["n"] > 256 for s in ran) and any(s["tickets"] == 2 and s["mix"] != "uniform19" for s in ran)
+    assert any(s["chains_ran"] > 1 for s in ran) and any(s["hammer"] and s["tickets"] == 2 for s in ran)
+
+
+def test_fuzz_sees_the_recycled_input_buffer(tmp_weights_dir, capsys):
+    """The control experiment.  SAYURI_DEBUG_RECYCLE_INPUT=2 hands the packed input's buffer back to the pool after the input
+    convolution, as rounds 3-4 did, and switches the row-stride table off: the same fuzz must come back RED on the 20b x 256
+    network (late workgroups of the persistent launch find their input overwritten).  With =1 the table is on and refuses the
+    forward outright."""
+    failures, ran = run_fuzz(["net_20b256"], 40, 20260930, env_extra={"SAYURI_DEBUG_RECYCLE_INPUT": "2"}, stop_at_first=True,
+                             tmp_weights_dir=tmp_weights_dir, only="net_20b256")
+    with capsys.disabled():
+        print(f"\n[fuzz, input buffer recycled as in rounds 3-4] first wrong batch after {len(ran)} scenarios: "
+              f"{failures[0] if failures else 'NONE'}")
+    assert failures, "the fuzz did not see the recycled input buffer"
+    pipe = make_pipe(Golden("net_20b256", tmp_weights_dir).weights_path, {"SAYURI_DEBUG_RECYCLE_INPUT": "1"})
+    try:
+        pool = Pool()
+        idx = np.resize(pool.by_size[19], 256)  # a full batch: the layers go into one persistent run (an unordered scope)
+        with pytest.raises(RuntimeError, match="row stride"):
+            hip_forward_raw(pipe.ctx(0), pool.grid[idx], pool.bsz[idx], B)
+    finally:
+        pipe.Destroy()

@@ -463,6 +463,69 @@ def test_config5_full_mixed_batch_40b384(fp16, tmp_weights_dir):
         pipe.Destroy()
 
 
+def test_split_se_unit_inside_the_convolution_40b384(tmp_weights_dir, monkeypatch):
+    """Round 6: the SE unit of a layer whose channels are split over three 128-channel workgroups runs inside the convolution
+    (conv_board_sx.h: pooling per sample through LDS, partial squeeze sums exchanged between the sibling workgroups, gate on the
+    accumulators) instead of as se_pool / se_fc / se_scale.  A mixed batch -- one, two and four samples per tile, plus boards
+    too small for the form (5x5, 7x7: the separate kernels behind the fused tiles) -- must (a) really take the kernel, (b) agree
+    with the separate kernels (SAYURI_SE_SPLIT=0) within the fp16 gate (they round x to fp16 before the unit, the fused form does
+    not), (c) match the oracle, (d) give a position the same BITS alone, in this batch and in a batch of other mates."""
+    from sayuri_amd import _lib
+    from sayuri_amd.pipe import hip_forward_raw
+    g = Golden("net_40b384", tmp_weights_dir)
+    net = PortNet(g.weights_path)
+    B = 19
+    rng = np.random.default_rng(66)
+    bsz = [int(b) for b in rng.choice([9, 13, 19], size=90)] + [5, 7, 19, 7, 5, 13, 9]
+    n = len(bsz)
+    planes = W.synthetic_planes(n, bsz, seed=6600)
+    grid = np.zeros((n, 43, B * B), np.float32)
+    for i, (p, bs) in enumerate(zip(planes, bsz)):
+        grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+
+    def run(env, idx):
+        monkeypatch.delenv("SAYURI_SE_SPLIT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=128, fp16=True)
+        try:
+            ctx = pipe.ctx(0)
+            outs = [hip_forward_raw(ctx, grid[i], [bsz[k] for k in i], B) for i in idx]
+            rows = (_lib.KernelStat * 32)()
+            k = _lib.hip().sayuri_hip_profile_run(ctx, rows, 32)
+            names = {rows[i].name.decode(): rows[i].launches for i in range(k)}
+            return outs, names
+        finally:
+            pipe.Destroy()
+
+    alone = [[0], [1], [n - 2], [n - 1]]
+    other = list(range(n - 1, -1, -2))  # every second sample, reversed: other mates, other places in the tiles
+    (full, half, *solo), names = run({}, [list(range(n)), other] + alone)
+    assert names.get("conv3x3_tower_sx", 0) == 13 and names.get("se_scale", 0) == 0, names  # the last batch profiled: one 9x9 alone
+    (sep,), names0 = run({"SAYURI_SE_SPLIT": "0"}, [list(range(n))])
+    assert names0.get("conv3x3_tower_sx", 0) == 0 and names0.get("se_scale", 0) == 13, names0
+    scale = max(1.0, float(np.abs(sep[0]).max()))
+    for a, b, what in zip(full, sep, ("prob", "pass", "misc", "own")):
+        assert np.isfinite(a).all()
+        assert float(np.abs(a - b).max()) <= FP16_ATOL * scale, (what, float(np.abs(a - b).max()))
+    assert not all(np.array_equal(a, b) for a, b in zip(full, sep))  # the two forms round at different points
+    for i in (0, n - 7, n - 6, n - 5, n - 2, n - 1):  # against the oracle: a drawn board, 5x5, 7x7, 19x19, 13x13, 9x9
+        bs, s = bsz[i], bsz[i] ** 2
+        e_prob, e_pass, e_misc, e_own = net.forward_raw(planes[i], bs)
+        tol = FP16_ATOL * max(1.0, float(max(np.abs(e_prob).max(), np.abs(e_own).max(), np.abs(e_misc).max())))
+        crop = lambda a: a.reshape(B, B)[:bs, :bs].ravel()
+        for k in range(5):
+            assert np.abs(crop(full[0][i, k]) - e_prob[k]).max() <= tol, (i, bs, "prob", k)
+        assert np.abs(full[1][i] - e_pass).max() <= tol and np.abs(full[2][i] - e_misc).max() <= tol, (i, bs)
+        assert np.abs(crop(full[3][i]) - e_own).max() <= tol, (i, bs, "own")
+    for j, k in enumerate(other):  # the same bits among other batch mates ...
+        for a, b in zip(full, half):
+            assert np.array_equal(a[k], b[j]), ("mates", k, bsz[k])
+    for idx, out in zip(alone, solo):  # ... and alone
+        for a, b in zip(full, out):
+            assert np.array_equal(a[idx[0]], b[0]), ("alone", idx[0], bsz[idx[0]])
+
+
 def test_chained_forward(tmp_weights_dir, monkeypatch):
     """configs[4]: a batch whose layers are more than one round of workgroups (40b x 384: 150 board tiles x 3 channel tiles on
     256 CUs) is run as chains of per-layer launches over groups of tiles, each on a stream of its own (Engine::forward; +6...10 %
