@@ -254,7 +254,32 @@ def pump_segment(lib, ctx, grid, n: int, steps: int, packed: bool = False) -> di
                     "two batches in flight (PCIe-inclusive, so not `value`)"}
 
 
-def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
+def parity_sample(net, kind: str, pipe, planes, fp16: bool, k: int = 4) -> dict:
+    """The benchmarked engine against the CPU reference on the first k positions of the bench's own batch -- so that the line
+    that carries a throughput also carries the distance at which it was measured (north_star: 'within fp32 tolerance' holds for
+    the fp32 engine, --fp32, 1e-4 abs; the default engine stores fp16 and accumulates fp32, like the reference's fp16 CUDA
+    path, and is gated at 4e-3 x the output scale plus the reference's own SelfCheck, network.cc:333-359: L2 <= 0.2)."""
+    from _oracle import PortNet
+    got = pipe.BatchForward(planes[:k], [19] * k)
+    err = scale = l2max = 0.0
+    for p, g in zip(planes[:k], got):
+        exp = net.forward(p, 19)
+        err = max(err, float(np.abs(g - exp).max()))
+        scale = max(scale, float(np.abs(exp).max()))
+        a, b = PortNet.postprocess(g, 19), PortNet.postprocess(exp, 19)
+        va = np.concatenate([a[:362], [a[2 * 361 + 1 + 3]]])
+        vb = np.concatenate([b[:362], [b[2 * 361 + 1 + 3]]])
+        l2max = max(l2max, float(np.sqrt(((va - vb) ** 2).sum())))
+    gate = 4e-3 * max(1.0, scale) if fp16 else 1e-4
+    return {"engine": "fp16 storage / MFMA with fp32 accumulation" if fp16 else "fp32 storage / fp32 MFMA",
+            "against": f"the {kind} CPU pipe (BlasForwardPipe) on the first {k} positions of this run's batch, raw outputs",
+            "max_abs_err": round(err, 6), "output_scale": round(scale, 3), "gate": round(gate, 6),
+            "gate_rule": "4e-3 x max(1, output scale) and SelfCheck L2 <= 0.2 (fp16 engine)" if fp16 else "1e-4 abs (SURVEY 8c)",
+            "selfcheck_l2_max": round(l2max, 6), "within_gate": bool(err <= gate and l2max <= 0.2),
+            "strict_engine": "python bench.py --fp32: fp32 storage and MFMA, gated at 1e-4 abs, 5.7 k evals/s (profiles/r05_bench_fp32.json)"}
+
+
+def cpu_baseline(weights_path: str, planes, seconds: float = 15.0, pipe=None, fp16: bool = True):
     """Time the CPU pipe on this box's host cores on a bounded sample of the same workload.
     Prefers the reference's own BlasForwardPipe (oracle/_ref, kind "reference"); falls back to
     the C restatement (kind "port").  One independent evaluation per thread at a time, like the
@@ -285,7 +310,8 @@ def cpu_baseline(weights_path: str, planes, seconds: float = 15.0):
         t.join()
     dt = time.perf_counter() - t0
     total = sum(counts)
-    return {"value": round(total / dt, 3), "unit": "evals/s", "cores": threads, "kind": kind,
+    parity = parity_sample(net, kind, pipe, planes, fp16) if pipe is not None else None
+    return {"parity": parity, "value": round(total / dt, 3), "unit": "evals/s", "cores": threads, "kind": kind,
             "sample": f"{total} evals of the same 20b256 19x19 net in {dt:.1f}s, {threads} threads x batch 1 "
                       f"(1 thread alone: {1.0 / one:.2f} evals/s); the reference's BlasForwardPipe with its BUILT_IN sgemm -- "
                       "Eigen / OpenBLAS are not in this image, the three CPU variants differ only in the GEMM call (blas.cc:16-166)"}
@@ -595,7 +621,8 @@ def main():
             selfplay.update(long_run_games_per_hour())
             result["selfplay"] = selfplay
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(wpath, planes, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(wpath, planes, args.cpu_seconds, pipe=pipe, fp16=fp16)
+            result["parity"] = result["cpu_baseline"].pop("parity")
         if args.config5 and world == 1:
             result["config5"] = config5_segment(lib, local_rank, rank, min(args.steps, 30), min(args.warmup, 5))
         if args.profile:

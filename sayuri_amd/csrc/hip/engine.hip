@@ -174,6 +174,8 @@ struct EngineFlags {
     bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
     bool se_split = true;              // SAYURI_SE_SPLIT=0: SE units of layers split over several channel tiles (384 channels) as
                                        // se_pool / se_fc / se_scale again instead of inside the convolution (conv_board_sx.h)
+    int tower_noepi_after = -1;        // SAYURI_TOWER_NOEPI_AFTER=n (measuring): from the n-th persistent launch on, the layers with the
+                                       // generated epilogue skip it (row_order = 3): timing only, the outputs are stale
     int sx_dbg = 0;                    // SAYURI_SX_DBG=n: s_memtime timeline of the n-th split SE convolution of a profiled forward
     int dbg_recycle_input = 0;         // SAYURI_DEBUG_RECYCLE_INPUT=1: hand the packed input's buffer back to the pool after the input
                                        // convolution, as rounds 3-4 did (the row-stride table below then REFUSES the forward); =2: and
@@ -198,6 +200,7 @@ struct EngineFlags {
         if (const char* e = getenv("SAYURI_DEBUG_RECYCLE_INPUT")) f.dbg_recycle_input = atoi(e);
         f.se_split = !off("SAYURI_SE_SPLIT");
         if (const char* e = getenv("SAYURI_SX_DBG")) f.sx_dbg = atoi(e);
+        if (const char* e = getenv("SAYURI_TOWER_NOEPI_AFTER")) f.tower_noepi_after = atoi(e);
         f.io_v2 = !off("SAYURI_IO_V2");
         f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");
         f.io_zc_in = f.io_zc && !off("SAYURI_IO_ZC_IN");
@@ -2166,6 +2169,9 @@ private:
         }
         const int n = (int)run.size(), first = table_used_;
         if (first + n > kTowerCap) return fail("tower table overflow");
+        if (flags_.tower_noepi_after >= 0 && tower_launches_++ >= flags_.tower_noepi_after)
+            for (auto& t : run)
+                if (t.sp.b.row_order == 1 && !t.has_se) t.sp.b.row_order = 3;  // MEASURING: no epilogue (tower_seam.py epi_hook)
         for (int i = 0; i < n; ++i) {
             run[i].self = ts.dev + first + i;
             run[i].last = i + 1 == n ? 1 : 0;
@@ -2226,6 +2232,7 @@ private:
     TowerSlot tower_[2];
     std::vector<TowerLayer> run_;
     int run_kot_ = 0, table_used_ = 0;
+    long tower_launches_ = 0;
     int table_uploads_ = 0;
     // SAYURI_HIP_FWDSTAT: device time of the forwards sent through submit(), by batch-size class
     bool fwdstat_ = std::getenv("SAYURI_HIP_FWDSTAT") != nullptr;

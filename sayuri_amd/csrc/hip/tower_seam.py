@@ -416,6 +416,12 @@ def epi_hook(w, hook, acc, B):
     # computed table entries, channels = the channel tile: Engine::board_row_order_ok)
     a(f"\ts_cmp_eq_u32 {sr(s_arith)}, 0")
     a(f"\ts_cbranch_scc1 {L}_compiled")
+    # row_order = 3 (SAYURI_TOWER_NOEPI_AFTER=n, a MEASURING switch of the engine): this layer's epilogue is skipped -- nothing is
+    # stored, the activations stay what the last complete forward left (realistic operands for the next layer's MFMAs, unlike a
+    # build that never stores: that one multiplies zeros and gains clock).  What a launch costs without its epilogues bounds
+    # what hiding them under the MFMA stream could be worth.
+    a(f"\ts_cmp_eq_u32 {sr(s_arith)}, 3")
+    a(f"\ts_cbranch_scc1 {L}_done")
     # ---- geometry of this wave and lane (board_epilogue's first lines)
     a(f"\tv_and_b32_e32 {vr(v_lane)}, 63, {T}")
     a(f"\tv_lshrrev_b32_e32 {vr(v_R)}, 4, {vr(v_lane)}")
