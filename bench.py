@@ -124,7 +124,7 @@ def mark_dominant(lib, ctx) -> str:
     return "conv3x3_tower"
 
 
-def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
+def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int, device: int = None):
     """BASELINE.json configs[4] on this GPU: 40-block x 384-filter net, fp16, a batch of 256 samples whose board size is
     drawn uniformly from 9 / 13 / 19, planes resident in HBM.  Returns evals/s, the tower convolution's
     launch time and the MFMA fraction on the batch's REAL pixels (a 9x9 sample costs 81/361 of a 19x19 one)."""
@@ -149,7 +149,7 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
     for i, (p, b) in enumerate(zip(planes, bsz)):
         grid[i, :, :b, :b] = p.reshape(43, b, b)
     grid = np.ascontiguousarray(grid.reshape(n, 43, 361))
-    pipe = HipForwardPipe(wpath, board_size=19, batch_size=n, fp16=True, device=local_rank)
+    pipe = HipForwardPipe(wpath, board_size=19, batch_size=n, fp16=True, device=local_rank if device is None else device)
     ctx = pipe.ctx(0)
     if lib.sayuri_hip_upload(ctx, n, grid.ctypes.data_as(_lib.c_float_p), bsz.ctypes.data_as(_lib.c_int_p)):
         raise RuntimeError(lib.sayuri_hip_last_error().decode())
@@ -184,6 +184,7 @@ def config5_segment(lib, local_rank: int, rank: int, steps: int, warmup: int):
     tower_tf = (stat.flops / stat.launches) / (stat.total_ms / stat.launches * 1e-3) / 1e12 if stat.launches else None
     return {"workload": "configs[4]: 40-block x 384-filter net, fp16, batch 256 of mixed 9/13/19 boards (uniform draw, random order), "
                         "planes resident in HBM", "evals_per_sec": round(n * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+            "_evals": n * steps, "_seconds": el, "_flops": flops_batch * steps,
             "chains": chains, "ms_per_step_one_chain": round(el_one / steps * 1e3, 3), "evals_per_sec_one_chain": round(n * steps / el_one, 1),
             "real_pixel_fraction": round(px / (n * 361), 4), "gflop_per_batch": round(flops_batch / 1e9, 1),
             "whole_net_tflops": round(flops_batch * steps / el / 1e12, 1), "whole_net_mfma_frac": round(flops_batch * steps / el / 1e12 / 2500.0, 4),
@@ -356,7 +357,7 @@ def main():
                          "a window of minutes then sees games in every phase, as hours of self-play do, and games/hour can be counted")
     ap.add_argument("--config5", dest="config5", action="store_true", default=True, help="(the default)")
     ap.add_argument("--no-config5", dest="config5", action="store_false",
-                    help="skip configs[4] (40-block x 384 net, batch 256 of mixed 9/13/19 boards; single-GPU runs only; ~20 s: the "
+                    help="skip configs[4] (40-block x 384 net, batch 256 of mixed 9/13/19 boards, on every rank; ~20 s: the "
                          "generated weights are cached under /tmp)")
     ap.add_argument("--selfplay-games", type=int, default=512, help="concurrent self-play games per GPU")
     ap.add_argument("--selfplay-chunk-pool", type=int, default=16,
@@ -579,6 +580,24 @@ def main():
                                           for k in ("wait_batch_us", "gpu_queue_empty_us", "fill_us", "forward_us") if k in pt1},
                     "frac_of_microbench_evals": None}
 
+    # ---- third segment: BASELINE.json configs[4] (40b x 384, mixed 9/13/19 boards) on EVERY rank's GPU -- the configuration is
+    # quoted on 8 GPUs: each rank runs its own batch (weak scaling, no collective in the path), the line carries the sum of the
+    # ranks' evaluations over the slowest rank's time, and the per-rank rates beside it
+    config5 = None
+    if args.config5:
+        if dist is not None:
+            dist.barrier()
+        config5 = config5_segment(lib, local_rank, rank, min(args.steps, 30), min(args.warmup, 5), device=device)
+        ev, sec, fl = config5.pop("_evals"), config5.pop("_seconds"), config5.pop("_flops")
+        if dist is not None:
+            g5 = gather_stats({"nn_queries": ev, "elapsed": sec, "playouts": fl / 1e9})
+            config5["n_gpus"] = world
+            config5["per_rank_evals_per_sec"] = [round(r["nn_queries"] / r["elapsed"], 1) for r in g5["per_rank"]]
+            config5["evals_per_sec"] = round(g5["nn_queries"] / g5["elapsed_max"], 1)
+            config5["whole_net_tflops"] = round(g5["playouts"] * 1e9 / g5["elapsed_max"] / 1e12, 1)
+            config5["whole_net_mfma_frac"] = round(g5["playouts"] * 1e9 / g5["elapsed_max"] / 1e12 / (2500.0 * world), 4)
+            config5["what_is_per_rank"] = "chains, one-chain figures and the tower convolution's launch time are rank 0's"
+
     result = None
     if rank == 0:
         flops_eval = algorithmic_flops_per_eval(spec)
@@ -623,8 +642,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wpath, planes, args.cpu_seconds, pipe=pipe, fp16=fp16)
             result["parity"] = result["cpu_baseline"].pop("parity")
-        if args.config5 and world == 1:
-            result["config5"] = config5_segment(lib, local_rank, rank, min(args.steps, 30), min(args.warmup, 5))
+        if config5 is not None:
+            result["config5"] = config5
         if args.profile:
             rows = (_lib.KernelStat * 32)()
             k = lib.sayuri_hip_profile_run(ctx, rows, 32)

@@ -1,13 +1,12 @@
-// engine.hip -- the per-GPU forward graph behind include/sayuri_hip.h.
-//
-// Structural counterpart of the reference's CudaForwardPipe::NNGraph
-// (src/neural/cuda/cuda_forward_pipe.cc:133-1090) and its layer objects
-// (src/neural/cuda/cuda_layers.cc), re-designed for MI355X:
-//   * activations live in compact NHWC (see common.h), fp16 or fp32;
-//   * every convolution is ONE implicit-GEMM MFMA kernel with the bias/residual/activation
-//     epilogue fused (conv_mfma.h) instead of transform/GEMM/transform + add_spatial;
-//   * an SE unit is two launches (gate, scale), the whole head tail is one launch;
-//   * samples of different board sizes share a batch without any masked work.
+// engine.hip -- the C-ABI of include/sayuri_hip.h: one translation unit in three parts
+//   engine_plan.h   kernel registries, environment switches, batch geometry and tile plans, device images of the layers
+//   engine_graph.h  Engine<T>: the per-GPU forward graph -- counterpart of the reference's CudaForwardPipe::NNGraph
+//                   (src/neural/cuda/cuda_forward_pipe.cc:133-1090) and its layer objects (src/neural/cuda/cuda_layers.cc),
+//                   re-designed for MI355X: compact NHWC activations (common.h), one workgroup per board with the whole residual
+//                   tower as ONE persistent launch (conv_board.h, conv_tower.h), SE units inside the convolutions (conv_board.h,
+//                   conv_board_sx.h), both heads in one kernel (head_board.h), mixed board sizes without masked work
+//   engine_taps.h   layer-level test taps (sayuri_hip_test_*)
+// and, in this file, the entry points themselves.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -30,2306 +29,8 @@
 #include "head_board.h"
 #include "small_ops.h"
 
-namespace sayuri {
-
-static thread_local std::string g_err;
-static std::atomic<unsigned> g_host_free_gen{0};  // sayuri_hip_host_free calls so far (Engine::zc_device_pointer)
-static thread_local int g_test_conv_kind = 0;  // kernel family the last sayuri_hip_test_conv call ran: 0 generic, 1 glds, 2 board, 3 depthwise
-static int fail(const std::string& m) { g_err = m; return -1; }
-
-#define HIP_OK(expr)                                                                      \
-    do {                                                                                  \
-        hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess) {                                                           \
-            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
-            return -1;                                                                    \
-        }                                                                                 \
-    } while (0)
-
-static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-constexpr size_t kMaxLds = 160 * 1024;
-constexpr int kNumCU = 256;
-
-// ------------------------------------------------------------------ conv kernel registry
-template <typename T> struct ConvKernelTable {
-    typedef void (*Fn)(const ConvParams);
-    struct Entry { int wmt, wnt; Fn fn; size_t (*lds)(int); int npos_cap; };
-    static std::vector<Entry>& entries() {
-        static std::vector<Entry> e;
-        return e;
-    }
-};
-
-template <typename T, int WMT, int WNT> static void register_conv() {
-    typedef ConvCfg<T, WMT, WNT> Cfg;
-    auto fn = &conv_mfma_kernel<T, WMT, WNT>;
-    ConvKernelTable<T>::entries().push_back({WMT, WNT, fn, &Cfg::lds_bytes, Cfg::NPOS_CAP});
-}
-
-template <typename T> static void register_all_convs();
-template <> void register_all_convs<f16>() {
-    if (!ConvKernelTable<f16>::entries().empty()) return;
-    register_conv<f16, 1, 4>(); register_conv<f16, 2, 4>(); register_conv<f16, 3, 4>();
-    register_conv<f16, 4, 4>(); register_conv<f16, 6, 4>(); register_conv<f16, 8, 4>();
-    register_conv<f16, 1, 2>(); register_conv<f16, 2, 2>(); register_conv<f16, 3, 2>();
-    register_conv<f16, 4, 2>(); register_conv<f16, 6, 2>(); register_conv<f16, 8, 2>();
-    register_conv<f16, 6, 3>(); register_conv<f16, 8, 3>();
-}
-template <> void register_all_convs<float>() {
-    if (!ConvKernelTable<float>::entries().empty()) return;
-    register_conv<float, 1, 4>(); register_conv<float, 2, 4>(); register_conv<float, 3, 4>();
-    register_conv<float, 4, 4>();
-    register_conv<float, 1, 2>(); register_conv<float, 2, 2>(); register_conv<float, 3, 2>();
-    register_conv<float, 4, 2>();
-}
-
-// tuned fp16 3x3 kernels for any batch geometry (conv_glds.h): 192 / 128 / 64-pixel tiles across samples
-struct GldsEntry {
-    int wmt, wnt;
-    void (*fn)(const GldsParams);
-    void (*setup)(BatchGeom, int*, int2*);
-    size_t lds;
-    int npos_cap, npos, pt;
-};
-static std::vector<GldsEntry>& glds_entries() {
-    static std::vector<GldsEntry> e;
-    return e;
-}
-template <int WMT, int WNT> static void register_glds() {
-    typedef GldsCfg<WMT, WNT> Cfg;
-    glds_entries().push_back({WMT, WNT, &conv_glds_kernel<WMT, WNT>, &tile_setup_kernel<Cfg::PT, Cfg::NPOS>, Cfg::lds_bytes(),
-                              Cfg::NPOS_CAP, Cfg::NPOS, Cfg::PT});
-}
-static void register_all_glds() {
-    if (!glds_entries().empty()) return;
-    register_glds<8, 3>(); register_glds<8, 2>(); register_glds<8, 1>();
-    register_glds<4, 3>(); register_glds<4, 2>(); register_glds<4, 1>();
-}
-// The weight image of the board kernels with an even tile count: the same planes with their rows in board_row_channel order
-// (conv_board.h: a lane then holds 8 consecutive channels of a row-tile pair without any exchange).
-template <typename T> static std::vector<T> board_row_order(const std::vector<T>& img, int ko_pad) {
-    std::vector<T> out(img.size());
-    const size_t planes = img.size() / ((size_t)ko_pad * 8);
-    for (size_t pl = 0; pl < planes; ++pl)
-        for (int r = 0; r < ko_pad; ++r)
-            std::copy_n(img.begin() + (pl * ko_pad + board_row_channel(r)) * 8, 8, out.begin() + (pl * ko_pad + r) * 8);
-    return out;
-}
-static bool board_uses_row_order(int kot) { return (kot / 64) % 2 == 0; }  // 256 / 128: yes; 192 (three row tiles per wave): natural order
-// one-workgroup-per-board kernels (conv_board.h), by output-channel tile
-typedef void (*BoardFn)(const BoardParams);
-typedef void (*BoardSeFn)(const BoardSeParams);
-struct BoardEntry { int kot; BoardFn fn; BoardSeFn fn_se; size_t (*lds)(int); };
-static const BoardEntry kBoardEntries[] = {
-    {256, &conv_board_kernel<4>, &conv_board_se_kernel<4>, &BoardCfg<4>::lds_bytes},  // SAYURI_BOARD_DBG=n swaps in <4, true> (timeline)
-    {192, &conv_board_kernel<3>, nullptr, &BoardCfg<3>::lds_bytes},
-    {128, &conv_board_kernel<2>, &conv_board_se_kernel<2>, &BoardCfg<2>::lds_bytes},
-};
-// head_board_kernel variants: {row tiles, trunk chunks in flight}; the first that fits the LDS is used (head_board_fits)
-typedef void (*HeadFn)(const HeadBoardParams);
-struct HeadEntry { int rt, depth; HeadFn fn; };
-static const HeadEntry kHeadEntries[] = {
-    {2, 5, &head_board_kernel<2, 5>}, {4, 5, &head_board_kernel<4, 5>}, {4, 3, &head_board_kernel<4, 3>},
-    {6, 3, &head_board_kernel<6, 3>}, {6, 2, &head_board_kernel<6, 2>},
-};
-static void enable_big_lds_glds() {
-    register_all_glds();
-    for (const auto& e : glds_entries())
-        (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)&conv_board_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    for (const auto& e : kHeadEntries) (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)&conv_board_sx_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    for (const auto& e : kBoardEntries) {
-        (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-        if (e.fn_se) (void)hipFuncSetAttribute((const void*)e.fn_se, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    }
-}
-// Switches of one engine, read from the environment ONCE, in sayuri_hip_create (and per call in the layer-level test
-// taps): nothing on the launch path calls getenv.  They select between product paths that give the same results (A/B
-// measurements, tests that check one path against the other).  The measuring-only switches (in-kernel timelines, forced
-// activation / channel tile) exist only in builds with -DSAYURI_EXPERIMENTS.
-//   SAYURI_CONV=v0 | glds[:wnt]   3x3 layers on the generic / the LDS-DMA-tiles-across-samples kernel instead of one workgroup per board
-//   SAYURI_TOWER=0                one launch per convolution instead of one persistent launch per run of board convolutions
-//   SAYURI_SE_FUSED=0             SE unit as se_pool / se_fc / se_scale instead of inside the convolution
-//   SAYURI_HEADS_FUSED=0          conv1x1 x2 + head_tail instead of head_board_kernel
-//   SAYURI_NO_ARITH=1             board kernels read their index tables instead of computing the entries
-//   SAYURI_COMPUTE_STREAMS=2      the two tickets' forwards on two streams
-struct ConvOverride {
-    bool v0 = false, no_board = false;
-    int wnt = 0;
-    // The board kernel runs whenever the batch's boards fit its tiles, however empty the tiles are: which convolution kernel
-    // a sample meets must not depend on its batch mates (a lone 9x9 board fills a fifth of its tile; with the across-sample
-    // kernel it came out ~1e-4 away from the same position inside a larger batch).  SAYURI_BOARD_MIN_FILL=0.55 brings back the
-    // rule of rounds 2-4 (tiles less than 55 % full go to the across-sample kernel: half the latency of a lone small board).
-    double board_min_fill = 0.0;
-};
-struct EngineFlags {
-    ConvOverride conv;
-    bool tower = true, se_fused = true, heads_fused = true, arith = true;
-    bool se_by_geometry = true;        // which samples take the fused SE form depends on their board size alone (conv_se); SAYURI_SE_BY_GEOMETRY=0: on the tiles' occupancy
-    bool io_v2 = true;                 // SAYURI_IO_V2=0: geometry / small outputs by copies again (A/B; see submit())
-    bool io_zc = true, io_geom = true, io_prefix = true;  // its three parts, one at a time (SAYURI_IO_ZC / _GEOM / _PREFIX = 0)
-    bool io_zc_in = true;  // packed records read where the caller has them (SAYURI_IO_ZC_IN=0: copied first, rounds 2-4)
-    bool tower_chain = true;           // a layer of the persistent run fetches the next layer's first weight group (SAYURI_TOWER_CHAIN=0: off)
-    bool tower_gen_epi = true;         // Mish layers of the run take the generated epilogue (SAYURI_TOWER_GEN_EPI=0: the compiled one)
-    bool se_split = true;              // SAYURI_SE_SPLIT=0: SE units of layers split over several channel tiles (384 channels) as
-                                       // se_pool / se_fc / se_scale again instead of inside the convolution (conv_board_sx.h)
-    int tower_noepi_after = -1;        // SAYURI_TOWER_NOEPI_AFTER=n (measuring): from the n-th persistent launch on, the layers with the
-                                       // generated epilogue skip it (row_order = 3): timing only, the outputs are stale
-    int sx_dbg = 0;                    // SAYURI_SX_DBG=n: s_memtime timeline of the n-th split SE convolution of a profiled forward
-    int dbg_recycle_input = 0;         // SAYURI_DEBUG_RECYCLE_INPUT=1: hand the packed input's buffer back to the pool after the input
-                                       // convolution, as rounds 3-4 did (the row-stride table below then REFUSES the forward); =2: and
-                                       // switch the table off -- the race of rounds 3-4 is back (tests/test_gpu_fuzz.py shows that it sees it)
-    int compute_streams = 1;
-    int chains = 0;                    // SAYURI_CHAINS: 0 = the engine decides, 1 = never, N = N chains whenever a batch qualifies (Engine::forward)
-    bool io_inorder = true;            // each ticket's upload, forward and download on the ticket's own stream (submit()); SAYURI_IO_INORDER=0: three streams and events
-    int board_kot = 0;                 // experiments: only this channel tile
-    int act_override = -1;             // experiments: activation of every board convolution
-    int board_dbg = 0, heads_dbg = 0;  // experiments: in-kernel timelines
-    static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
-    static EngineFlags from_env() {
-        EngineFlags f;
-        if (const char* e = getenv("SAYURI_CONV")) {
-            if (!strncmp(e, "v0", 2)) { f.conv.v0 = true; f.conv.no_board = true; }
-            else if (!strncmp(e, "glds", 4)) { f.conv.no_board = true; (void)sscanf(e, "glds:%d", &f.conv.wnt); }
-        }
-        if (const char* e = getenv("SAYURI_BOARD_MIN_FILL")) f.conv.board_min_fill = atof(e);
-        f.tower = !off("SAYURI_TOWER");
-        f.tower_chain = !off("SAYURI_TOWER_CHAIN");
-        f.tower_gen_epi = !off("SAYURI_TOWER_GEN_EPI");
-        if (const char* e = getenv("SAYURI_DEBUG_RECYCLE_INPUT")) f.dbg_recycle_input = atoi(e);
-        f.se_split = !off("SAYURI_SE_SPLIT");
-        if (const char* e = getenv("SAYURI_SX_DBG")) f.sx_dbg = atoi(e);
-        if (const char* e = getenv("SAYURI_TOWER_NOEPI_AFTER")) f.tower_noepi_after = atoi(e);
-        f.io_v2 = !off("SAYURI_IO_V2");
-        f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");
-        f.io_zc_in = f.io_zc && !off("SAYURI_IO_ZC_IN");
-        f.io_geom = f.io_v2 && !off("SAYURI_IO_GEOM");
-        f.io_prefix = f.io_v2 && !off("SAYURI_IO_PREFIX");
-        f.se_fused = !off("SAYURI_SE_FUSED");
-        f.se_by_geometry = !off("SAYURI_SE_BY_GEOMETRY");
-        f.heads_fused = !off("SAYURI_HEADS_FUSED");
-        f.arith = !getenv("SAYURI_NO_ARITH");
-        if (const char* e = getenv("SAYURI_COMPUTE_STREAMS")) f.compute_streams = atoi(e) == 2 ? 2 : 1;
-        if (const char* e = getenv("SAYURI_CHAINS")) f.chains = std::max(0, std::min(atoi(e), 4));
-        if (const char* e = getenv("SAYURI_IO_INORDER")) f.io_inorder = atoi(e) != 0;
-#ifdef SAYURI_EXPERIMENTS
-        if (const char* e = getenv("SAYURI_BOARD_KOT")) f.board_kot = atoi(e);
-        if (const char* e = getenv("SAYURI_ACT_OVERRIDE")) f.act_override = atoi(e);
-        if (const char* e = getenv("SAYURI_BOARD_DBG")) f.board_dbg = atoi(e);
-        if (getenv("SAYURI_HEADS_DBG")) f.heads_dbg = 1;
-        if (f.board_dbg || f.heads_dbg || f.act_override >= 0) f.tower = false;
-#endif
-        return f;
-    }
-};
-
-// allow > 64 KiB of dynamic LDS on the current device
-template <typename T> static void enable_big_lds() {
-    register_all_convs<T>();
-    for (const auto& e : ConvKernelTable<T>::entries())
-        (void)hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-}
-
-// candidate output-channel tiles, largest first
-static int pick_wmt(int cout_s, bool fp16) {
-    // KO_T = 32*WMT.  Smallest tile that covers cout_s, else the tile with least padding.
-    const int opts16[] = {1, 2, 3, 4, 6, 8};
-    const int opts32[] = {1, 2, 3, 4};
-    const int* opts = fp16 ? opts16 : opts32;
-    const int nopts = fp16 ? 6 : 4;
-    for (int i = 0; i < nopts; ++i)
-        if (opts[i] * 32 >= cout_s) return opts[i];
-    int best = opts[nopts - 1], best_pad = 1 << 30;
-    for (int i = nopts - 1; i >= 0; --i) {
-        const int kot = opts[i] * 32, pad = round_up(cout_s, kot) - cout_s;
-        if (pad < best_pad) { best_pad = pad; best = opts[i]; }
-    }
-    return best;
-}
-
-// ------------------------------------------------------------------ host-side geometry
-struct HostGeom {
-    std::vector<int> bsz, off;  // off has n+1 entries
-    int n = 0, total = 0;
-    // bs*bs when every sample has the same board size, else 0
-    int uniform_sq() const {
-        for (int i = 1; i < n; ++i)
-            if (bsz[i] != bsz[0]) return 0;
-        return n > 0 ? bsz[0] * bsz[0] : 0;
-    }
-    // worst-case LDS halo positions / subregions of any PT-pixel tile
-    void tile_bounds(int PT, int* npos_out, int* nsub_out) const {
-        int max_pos = 0, max_sub = 0;
-        int s = 0;
-        for (int g0 = 0; g0 < total; g0 += PT) {
-            const int g1 = std::min(g0 + PT, total);
-            while (s + 1 < n && off[s + 1] <= g0) ++s;
-            int pos = 0, sub = 0;
-            for (int m = s; m < n && off[m] < g1; ++m) {
-                const int bs = bsz[m];
-                const int a = std::max(g0, off[m]) - off[m], b = std::min(g1, off[m + 1]) - off[m];
-                const int rows = (b - 1) / bs - a / bs + 3;
-                pos += rows * (bs + 2);
-                ++sub;
-            }
-            max_pos = std::max(max_pos, pos);
-            max_sub = std::max(max_sub, sub);
-        }
-        *npos_out = round_up(std::max(max_pos, 16), 16);
-        *nsub_out = max_sub;
-    }
-};
-
-// Choose the tuned LDS-DMA kernel variant for an fp16 3x3 layer with `ko_pad` weight rows on
-// this batch geometry; nullptr when none applies (the generic conv_mfma kernel is used then).
-static const GldsEntry* pick_glds(const HostGeom& geom, int ko_pad, int* ntiles_out, const ConvOverride& ov) {
-    if (ko_pad % 128 != 0) return nullptr;
-    if (ov.v0) return nullptr;
-    const int wmt = ko_pad % 256 == 0 ? 8 : 4;
-    const int kot_tiles = ko_pad / (wmt * 32);
-    const GldsEntry* best = nullptr;
-    double best_cost = 1e30;
-    for (const auto& e : glds_entries()) {
-        if (e.wmt != wmt) continue;
-        if (ov.wnt && e.wnt != ov.wnt) continue;
-        const int PT = e.pt;
-        int npos, nsub;
-        geom.tile_bounds(PT, &npos, &nsub);
-        if (npos > e.npos_cap || nsub > kMaxSub || e.lds > kMaxLds) continue;
-        const int ntiles = (geom.total + PT - 1) / PT;
-        const double waves = std::ceil((double)ntiles * kot_tiles / kNumCU);
-        const double cost = waves * (PT + 24);
-        if (cost < best_cost) { best_cost = cost; best = &e; *ntiles_out = ntiles; }
-    }
-    return best;
-}
-
-// The one-workgroup-per-board plan of a batch geometry (conv_board.h): consecutive samples packed greedily.
-struct BoardPlan {
-    int ntiles = 0, npos = 0;
-    bool ok = false, single = false;  // single: one sample per tile
-    int uniform_info = -1;            // every tile has this (column tiles | board size << 8), or -1
-    double fill = 0;
-    std::vector<int> tile_first;      // first sample of every tile, then the number of samples (ntiles + 1 entries)
-};
-static BoardPlan board_plan(const HostGeom& geom, const ConvOverride& ov) {
-    BoardPlan bp;
-    if (ov.no_board || geom.n <= 0) return bp;
-    BoardPack pk;
-    int max_pos = 0, info0 = -2;
-    int tile_start = 0;
-    auto close_tile = [&] {
-        bp.tile_first.push_back(tile_start);
-        max_pos = std::max(max_pos, pk.pos);
-        const int info = ((pk.px + 15) / 16) | (pk.bs0 << 8);
-        info0 = info0 == -2 ? info : (info0 == info ? info0 : -1);
-        ++bp.ntiles;
-    };
-    for (int s = 0; s < geom.n; ++s) {
-        const int bs = geom.bsz[s];
-        if (!BoardPack{}.fits(bs)) return bp;  // a board that does not fit a tile on its own
-        if (pk.cnt > 0 && !pk.fits(bs)) {
-            close_tile();
-            pk = BoardPack{};
-            tile_start = s;
-        }
-        pk.add(bs);
-    }
-    close_tile();
-    bp.tile_first.push_back(geom.n);
-    bp.uniform_info = info0;
-    bp.npos = round_up(max_pos, 64);
-    bp.fill = (double)geom.total / ((double)bp.ntiles * kBoardPT);
-    bp.single = bp.ntiles == geom.n;
-    bp.ok = true;
-    return bp;
-}
-static const BoardEntry* pick_board(const BoardPlan& bp, int ko_pad, int* kot_tiles, int force = 0) {
-    if (!bp.ok) return nullptr;
-    // the channel tile that needs the fewest rounds of workgroups over the 256 CUs (time of a round ~ its channel count);
-    // ties go to the larger tile (the halo is staged once per workgroup)
-    const BoardEntry* best = nullptr;
-    long best_cost = 0;
-    for (const auto& e : kBoardEntries) {
-        if (ko_pad % e.kot != 0 || e.lds(bp.npos) > kMaxLds) continue;
-        if (force && force != e.kot) continue;
-        const long kts = ko_pad / e.kot, rounds = (bp.ntiles * kts + kNumCU - 1) / kNumCU, cost = rounds * e.kot;
-        if (!best || cost < best_cost) { best = &e; best_cost = cost; *kot_tiles = (int)kts; }
-    }
-    return best;
-}
-
-struct Stat {
-    int launches = 0;
-    float ms = 0.f;
-    double flops = 0, bytes = 0;
-};
-
-// ------------------------------------------------------------------ layers
-struct ConvLayerDev {
-    int cin = 0, cout = 0, k = 0;
-    bool depthwise = false, with_bn_fold = false;
-    std::vector<float> hw, hb;  // host tensors as handed over the ABI
-    int cin_s = 0, cout_s = 0, wmt = 0, ko_pad = 0;
-    void* w = nullptr;      // MFMA image, or [k*k][cs] fp32 for depthwise
-    void* w_board = nullptr;  // the same image in board_row_channel order (fp16 3x3 layers a board kernel may run) ...
-    float* bias_board = nullptr;  // ... and the bias in the same order: what a layer gets whose epilogue is the generated one
-    float* bias = nullptr;  // [ko_pad] / [cs]
-    float* w32 = nullptr;   // plain fp32 copy [cout][cin] for the tiny head convs
-};
-struct FcLayerDev {
-    int in = 0, out = 0;
-    std::vector<float> hw, hb;
-    float* wt = nullptr;  // [in][out]
-    float* b = nullptr;
-    void* img16 = nullptr;  // SE units of the fp16 engine: the LDS-staging image of conv_board.h (BoardSeParams::w1h / w2h)
-    int img_bytes = 0;      // bytes of one image (whole 1 KiB pieces)
-    void* sx_img = nullptr; // ... and the per-channel-tile images of conv_board_sx.h (BoardSxParams::w1t / w2t), layers of 2-4 tiles of 128
-    int sx_bytes = 0;
-    FcDev dev() const { return FcDev{wt, b, in, out}; }
-};
-
-// ------------------------------------------------------------------ host-side images shared by the engine and the test taps
-// fp16 images of an SE unit's two FCs for the LDS staging of board_se_stage (conv_board.h, BoardSeParams::w1h / w2h):
-// the squeeze weights once per board size 2..board with the scaled-mean third of the pooled vector folded into the mean
-// third (reference GlobalPooling<false>, se_unit.cc:9-40: pool = (mean, mean * (B-14)/10, max)), the excite weights with
-// both bias vectors behind them.  sq_w [se][3C], ex_w [2C][se] as handed over the ABI.  false: the unit does not fit.
-static bool make_se_images(int C, int se, int board, const float* sq_w, const float* sq_b, const float* ex_w, const float* ex_b,
-                           std::vector<f16>* img1, std::vector<unsigned char>* img2, int* w1_bytes_out, int* w2_bytes_out) {
-    if (se <= 0 || se % 4 || se > 512 || 2 * C > 512) return false;
-    const int w1_bytes = round_up(2 * C * se * 2, 1024), w2_bytes = round_up(se * 2 * C * 2 + (2 * C + se) * 4, 1024);
-    if ((size_t)w1_bytes + w2_bytes + 20 * 1024 > kMaxLds) return false;
-    img1->assign((size_t)(board - 1) * (w1_bytes / 2), (f16)0.f);
-    for (int bs = 2; bs <= board; ++bs) {
-        const float sc = ((float)bs - 14.f) / 10.f;
-        f16* d = img1->data() + (size_t)(bs - 2) * (w1_bytes / 2);
-        for (int r = 0; r < 2 * C; ++r)
-            for (int o = 0; o < se; ++o) {
-                const float* w = sq_w + (size_t)o * 3 * C;
-                d[(size_t)r * se + o] = (f16)(r < C ? w[r] + sc * w[C + r] : w[2 * C + (r - C)]);
-            }
-    }
-    img2->assign(w2_bytes, 0);
-    f16* h = (f16*)img2->data();
-    for (int i = 0; i < se; ++i)
-        for (int o = 0; o < 2 * C; ++o) h[((size_t)(i >> 2) * 2 * C + o) * 4 + (i & 3)] = (f16)ex_w[(size_t)o * se + i];
-    float* bias = (float*)(img2->data() + (size_t)se * 2 * C * 2);
-    std::copy(ex_b, ex_b + 2 * C, bias);
-    std::copy(sq_b, sq_b + se, bias + 2 * C);
-    *w1_bytes_out = w1_bytes;
-    *w2_bytes_out = w2_bytes;
-    return true;
-}
-
-// The same two FCs cut by 128-channel tile for conv_board_sx.h (a layer whose channels are split over kts workgroups): per tile kt
-// the squeeze rows of its 128 channels (mean rows with the scaled-mean third folded in, once per board size; then the max rows),
-// and the excite rows that produce its channels' gamma and beta, with their bias and the squeeze bias behind them.
-static bool make_sx_images(int C, int se, int kts, int board, const float* sq_w, const float* sq_b, const float* ex_w, const float* ex_b,
-                           std::vector<f16>* img1, std::vector<unsigned char>* img2, int* w1_bytes_out, int* w2_bytes_out) {
-    if (se <= 0 || se % 4 || se > kSxSlots || kts < 2 || kts > 4 || C > kts * 128) return false;
-    const int w1_bytes = round_up(256 * se * 2, 1024), w2_bytes = round_up(se * 256 * 2 + (256 + se) * 4, 1024);
-    if (w1_bytes + w2_bytes > SxLds::stage_bytes) return false;
-    img1->assign((size_t)kts * (board - 1) * (w1_bytes / 2), (f16)0.f);
-    img2->assign((size_t)kts * w2_bytes, 0);
-    for (int kt = 0; kt < kts; ++kt) {
-        for (int bs = 2; bs <= board; ++bs) {
-            const float sc = ((float)bs - 14.f) / 10.f;
-            f16* d = img1->data() + ((size_t)kt * (board - 1) + (bs - 2)) * (w1_bytes / 2);
-            for (int r = 0; r < 256; ++r) {
-                const int c = kt * 128 + (r & 127);
-                if (c >= C) continue;  // pad channels: x is 0 there, and their rows stay 0
-                for (int o = 0; o < se; ++o) {
-                    const float* w = sq_w + (size_t)o * 3 * C;
-                    d[(size_t)r * se + o] = (f16)(r < 128 ? w[c] + sc * w[C + c] : w[2 * C + c]);
-                }
-            }
-        }
-        unsigned char* base = img2->data() + (size_t)kt * w2_bytes;
-        f16* h = (f16*)base;
-        float* bias = (float*)(base + (size_t)se * 256 * 2);
-        for (int o = 0; o < 256; ++o) {
-            const int c = kt * 128 + (o & 127);
-            if (c >= C) continue;  // gamma = sigmoid(0), beta = 0 on x = 0
-            const int row = o < 128 ? c : C + c;
-            for (int i = 0; i < se; ++i) h[((size_t)(i >> 2) * 256 + o) * 4 + (i & 3)] = (f16)ex_w[(size_t)row * se + i];
-            bias[o] = ex_b[row];
-        }
-        std::copy(sq_b, sq_b + se, bias + 256);
-    }
-    *w1_bytes_out = w1_bytes;
-    *w2_bytes_out = w2_bytes;
-    return true;
-}
-
-// Images of head_board_kernel (head_board.h): the stacked [policy | value] 1x1 head convolutions as one MFMA image
-// (rows: policy channels rounded to a row tile of 16, then the value channels up to an even number of row tiles), the
-// per-pixel weights (policy planes over the policy rows, ownership over the value rows) in the accumulator's channel
-// order, the stacked bias.  Returns the kernel variant that fits, or nullptr (the separate head kernels run then).
-struct HeadImages {
-    std::vector<f16> img, img2;
-    std::vector<float> bias;
-    int PT = 0, VT = 0;
-};
-static HeadFn make_head_images(int C, int Cp, int Cv, int prob_ch, int board, const float* p_w, const float* p_b, const float* v_w,
-                               const float* v_b, const float* prob_w, const float* own_w, HeadImages* out) {
-    if (board * board > kHeadPix || prob_ch > 8) return nullptr;
-    const int PT = round_up(Cp, 16), rows = round_up(PT + Cv, 32), VT = rows - PT, cs = round_up(C, 32), nch = cs / 32;
-    HeadFn fn = nullptr;
-    for (const auto& e : kHeadEntries)
-        if (e.rt * 16 == rows && head_board_fits(rows, nch, e.depth)) { fn = e.fn; break; }
-    if (!fn) return nullptr;
-    // per-pixel weights in the accumulator's channel order: k-group kg of pair t holds stacked rows 32t + 4kg + s (s < 4)
-    // and 32t + 16 + 4kg + (s - 4); row k < prob_ch = policy plane k over the policy rows, row prob_ch = ownership
-    out->img2.assign((size_t)(rows / 32) * 4 * 16 * 8, (f16)0.f);
-    for (int t = 0; t < rows / 32; ++t)
-        for (int kg = 0; kg < 4; ++kg)
-            for (int e = 0; e < 8; ++e) {
-                const int ch = 32 * t + (e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4));
-                for (int k = 0; k < prob_ch; ++k)
-                    if (ch < Cp) out->img2[(((size_t)t * 4 + kg) * 16 + k) * 8 + e] = (f16)prob_w[(size_t)k * Cp + ch];
-                if (ch >= PT && ch - PT < Cv) out->img2[(((size_t)t * 4 + kg) * 16 + prob_ch) * 8 + e] = (f16)own_w[ch - PT];
-            }
-    out->img.assign((size_t)nch * 4 * rows * 8, (f16)0.f);
-    out->bias.assign(rows, 0.f);
-    for (int half = 0; half < 2; ++half) {
-        const float* w = half ? v_w : p_w;
-        const float* b = half ? v_b : p_b;
-        const int cout = half ? Cv : Cp, r0 = half ? PT : 0;
-        for (int ko = 0; ko < cout; ++ko) {
-            out->bias[r0 + ko] = b[ko];
-            for (int c = 0; c < C; ++c)
-                out->img[(((size_t)(c / 32) * 4 + (c % 32) / 8) * rows + r0 + ko) * 8 + c % 8] = (f16)w[(size_t)ko * C + c];
-        }
-    }
-    out->PT = PT;
-    out->VT = VT;
-    return fn;
-}
-
-// the persistent tower kernels (conv_tower.h) out of the embedded code object: [0] 256-channel tile, [1] 128-channel tile
-}  // namespace sayuri
-extern "C" const unsigned char sayuri_tower_hsaco[];
-extern "C" const unsigned long long sayuri_tower_hsaco_size;
-namespace sayuri {
-static int load_tower_module(hipModule_t* mod, hipFunction_t fn[2]) {
-    // an EMPTY blob: the build went on without the persistent kernel because tower_seam.py did not recognise the compiler's
-    // assembly (sayuri_amd/_build.py tower_blob_from_asm); the caller reports the fallback and launches per layer
-    if (sayuri_tower_hsaco_size == 0) return fail("this build carries no persistent tower kernel: tower_seam.py rejected the compiler's assembly at build time");
-    HIP_OK(hipModuleLoadData(mod, sayuri_tower_hsaco));
-    HIP_OK(hipModuleGetFunction(&fn[0], *mod, "_ZN6sayuri17conv_tower_kernelILi4EEEvPKNS_10TowerLayerE"));
-    HIP_OK(hipModuleGetFunction(&fn[1], *mod, "_ZN6sayuri17conv_tower_kernelILi2EEEvPKNS_10TowerLayerE"));
-    return 0;
-}
-
-class EngineBase {
-public:
-    virtual ~EngineBase() {}
-    virtual int load_tensor(int layer, int kind, const float* host, size_t n) = 0;
-    // `packed` != null: the inputs are packed records (packed_planes.h) with `binary` bit planes, `planes` is ignored
-    virtual int upload(int n, const float* planes, const int* board_sizes, const unsigned* packed = nullptr, int binary = 0) = 0;
-    virtual int run() = 0;
-    virtual int sync() = 0;
-    virtual int download(float* prob, float* pass, float* misc, float* own) = 0;
-    virtual int time_runs(int iters, float* ms) = 0;
-    virtual int profile_run(sayuri_hip_kernel_stat* rows, int cap) = 0;
-    virtual int submit(int n, const float* planes, const int* bsz, float* prob, float* pass, float* misc, float* own,
-                       int* ticket, const unsigned* packed = nullptr, int binary = 0) = 0;
-    virtual int wait(int ticket) = 0;
-    virtual int query(int ticket) = 0;
-    virtual int mark_kernel(const char* name) = 0;
-    virtual int timed_stat(sayuri_hip_kernel_stat* row) = 0;
-    virtual size_t device_bytes() const = 0;
-    virtual int last_chains() const = 0;
-    virtual int tower_state() const = 0;  // 1: the persistent tower kernel is loaded, 0: one launch per layer (fallback)
-    virtual int debug_read(int buf, void* host, size_t bytes) = 0;  // debugging tap: activation buffer `buf` of ticket 0
-};
-
-template <typename T> class Engine : public EngineBase {
-public:
-    struct TileTabs { int* src = nullptr; int2* pix = nullptr; bool fresh = false; };
-    struct BoardTabs { int* src = nullptr; int2* pix = nullptr; int* cols = nullptr; int npos_built = 0; int ntiles_built = 0; bool fresh = false; };
-    Engine(int device, const sayuri_hip_netdesc& d, int max_batch, int board, const EngineFlags& flags)
-        : flags_(flags), device_(device), desc_(d), max_batch_(max_batch), board_(board) {
-        blocks_.assign(d.blocks, d.blocks + d.residual_blocks);
-        desc_.blocks = blocks_.data();
-    }
-    ~Engine() override { release(); }
-
-    int init() {
-        HIP_OK(hipSetDevice(device_));
-        HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-        // The tickets' compute streams: one shared stream to begin with; the rule below gives ticket 1 a stream of its own.
-        compute_[0] = stream_;
-        compute_[1] = stream_;
-        HIP_OK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
-        HIP_OK(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking));
-        for (int t = 0; t < 2; ++t) {
-            HIP_OK(hipEventCreateWithFlags(&h2d_done_[t], hipEventDisableTiming));
-            HIP_OK(hipEventCreateWithFlags(&fwd_done_[t], hipEventDisableTiming));
-        }
-        HIP_OK(hipEventCreate(&ev0_));
-        HIP_OK(hipEventCreate(&ev1_));
-        enable_big_lds<T>();
-        if (sizeof(T) == 2) enable_big_lds_glds();
-        if (sizeof(T) == 2 && flags_.tower && tower_load()) {
-            // the persistent launch is an optimisation: without its code object the per-layer launches (SAYURI_TOWER=0) run
-            // the same kernels.  Say so once, loudly, and go on.
-            std::fprintf(stderr, "[sayuri_hip] persistent tower kernel not loaded (%s): falling back to one launch per layer\n",
-                         sayuri_hip_last_error());
-            if (tower_mod_) (void)hipModuleUnload(tower_mod_);
-            tower_mod_ = nullptr;
-            tower_fn_[0] = tower_fn_[1] = nullptr;
-        }
-        // One stream per ticket (everything of a ticket in order on its own stream, no event between streams) whenever the
-        // persistent kernel is loaded -- for every network, also one the launch does not cover (384 / 192 channels: the code
-        // object is loaded and the layers are still launched one by one).  History of the rule: round 1 measured two tickets'
-        // per-layer launches side by side as slower (48.0 k vs 54.0 k evals/s, the 482-workgroup kernel on the 256-channel
-        // network evicting each other's L2 lines) and kept one compute stream; round 5 re-measured on the kernels of today --
-        // 40b x 384 through submit / wait, two tickets in flight: a stream per ticket 26.3 k evals/s, one compute stream 23.7 k
-        // (a layer is 450 workgroups, two rounds of the CUs, and the other ticket's launches fill the second; 200 batches
-        // bit-identical to the solo result, tools/gpu/c5_pump.py, concurrent_ctx_dbg.py).  Without the code object
-        // (SAYURI_TOWER=0, or a build whose seam was rejected) the older three-stream arrangement stays.
-        if (describe_layers()) return -1;
-        inorder_ = flags_.io_inorder && tower_fn_[0] != nullptr;
-        if (flags_.compute_streams == 2 || inorder_) HIP_OK(hipStreamCreateWithFlags(&compute_[1], hipStreamNonBlocking));
-        return 0;
-    }
-    // every 3x3 convolution of the residual tower has 128 or 256 (padded) output channels and there is at least one
-    bool tower_covers_net() const {
-        int n3 = 0;
-        for (const auto& kv : convs_) {
-            const ConvLayerDev& L = kv.second;
-            if (L.k != 3 || L.depthwise || kv.first == SAYURI_L_INPUT_CONV) continue;
-            const int cs = round_up(L.cout, 32);
-            if (cs != 256 && cs != 128) return false;
-            ++n3;
-        }
-        const int c0 = round_up(desc_.residual_channels, 32);
-        return n3 > 0 && (c0 == 256 || c0 == 128);
-    }
-
-    // -------------------------------------------------------------- chains (see forward())
-    static constexpr int kMaxChains = 4;
-    hipStream_t chain_stream_[kMaxChains] = {};
-    hipEvent_t chain_fork_ = nullptr, chain_join_[kMaxChains] = {};
-    int rg_tile0_ = 0, rg_ntiles_ = -1, rg_n0_ = 0, rg_ns_ = -1;  // the tiles / samples the launches of forward_graph() cover (-1: all)
-    int last_chains_ = 1;
-    int range_ntiles() const { return rg_ntiles_ >= 0 ? rg_ntiles_ : board_plan_.ntiles; }
-    int range_ns() const { return rg_ns_ >= 0 ? rg_ns_ : geom_.n; }
-    double range_px() const { return rg_ns_ >= 0 ? (double)(geom_.off[rg_n0_ + rg_ns_] - geom_.off[rg_n0_]) : (double)geom_.total; }
-    int chain_setup(int G) {
-        if (!chain_fork_) HIP_OK(hipEventCreateWithFlags(&chain_fork_, hipEventDisableTiming));
-        for (int g = 0; g < G; ++g) {
-            if (!chain_stream_[g]) HIP_OK(hipStreamCreateWithFlags(&chain_stream_[g], hipStreamNonBlocking));
-            if (!chain_join_[g]) HIP_OK(hipEventCreateWithFlags(&chain_join_[g], hipEventDisableTiming));
-        }
-        return 0;
-    }
-    // How many chains the current batch is run as.  A layer of a network the persistent launch does not cover is one launch of
-    // (tiles x channel tiles) workgroups of equal cost; at 450 of them (configs[4]: 150 tiles x three 128-channel tiles) the 256 CUs
-    // run two rounds, the second 76 % full, whatever the item size.  The boards of a batch are independent: cut into G groups of
-    // tiles, each a chain of per-layer launches on a stream of its own, a group's next layer starts on the CUs another group's
-    // round leaves free -- the cross-layer pipelining of a persistent (layer, tile, channel tile) run, done by the dispatcher
-    // instead of by dependency counters.  Measured from outside the engine (tools/gpu/c5_streams.py, G contexts): 24.4 k evals/s
-    // as one chain, 25.8 / 25.9 / 25.6 k as 2 / 3 / 4, 21.4 k as 6.
-    int chains_for_batch() {
-        // The chains share the forward's activation buffers: a tile is whole samples, every layer of a network that qualifies has
-        // ONE channel stride, and the packed input keeps a buffer of its own (forward_graph), so the chains' rows are disjoint
-        // bytes in every buffer.  (The first version recycled the packed input's buffer, whose rows have another stride: a chain
-        // that ran ahead overwrote a later chain's input -- a few dozen samples per batch off in two runs of three.)
-        if (sizeof(T) != 2 || flags_.chains == 1 || profiling_ || light_ || !head_img_ || !heads_fused_enabled()) return 1;
-        if (desc_.policy_head_type != 0 || tower_covers_net()) return 1;
-        for (const auto& b : blocks_)
-            if (b.type != SAYURI_BLOCK_RESIDUAL) return 1;  // every layer of the graph must be a board convolution or a per-sample kernel
-        const ConvLayerDev& L = cv(SAYURI_L_BLOCK(0, SAYURI_S_CONV1));
-        // (a network whose SE units could run inside the convolution keeps one chain: conv_se launches over the whole batch)
-        for (const auto& e : kBoardEntries)
-            if (e.fn_se && e.kot == L.ko_pad)
-                for (const auto& b : blocks_)
-                    if (b.apply_se) return 1;
-        int kts = 0;
-        if (!choose_board(L, &kts) || !board_plan_.ok) return 1;
-        const int wgs = board_plan_.ntiles * kts;
-        if (wgs <= kNumCU) return 1;  // one round already
-        int G = flags_.chains > 1 ? flags_.chains : std::min(kMaxChains, std::max(2, (wgs + 159) / 160));
-        G = std::min(G, board_plan_.ntiles / 8);
-        return std::max(G, 1);
-    }
-
-    // -------------------------------------------------------------- weights
-    int load_tensor(int layer, int kind, const float* host, size_t n) override {
-        if (finalized_) return fail("load_tensor after the first forward");
-        auto ci = convs_.find(layer);
-        if (ci != convs_.end()) {
-            ConvLayerDev& L = ci->second;
-            const size_t expect = kind == SAYURI_T_WEIGHTS
-                                      ? (size_t)(L.depthwise ? 1 : L.cin) * L.cout * L.k * L.k
-                                      : (size_t)L.cout;
-            if (n != expect) return fail("conv tensor size mismatch for layer " + std::to_string(layer));
-            (kind == SAYURI_T_WEIGHTS ? L.hw : L.hb).assign(host, host + n);
-            return 0;
-        }
-        auto fi = fcs_.find(layer);
-        if (fi != fcs_.end()) {
-            FcLayerDev& L = fi->second;
-            const size_t expect = kind == SAYURI_T_WEIGHTS ? (size_t)L.in * L.out : (size_t)L.out;
-            if (n != expect) return fail("fc tensor size mismatch for layer " + std::to_string(layer));
-            (kind == SAYURI_T_WEIGHTS ? L.hw : L.hb).assign(host, host + n);
-            return 0;
-        }
-        return fail("unknown layer id " + std::to_string(layer));
-    }
-
-    // -------------------------------------------------------------- batch i/o
-    // asynchronous: H2D, graph, D2H enqueued on the stream, an event marks the end
-    int submit(int n, const float* planes, const int* board_sizes, float* prob, float* pass, float* misc, float* own,
-               int* ticket, const unsigned* packed = nullptr, int binary = 0) override {
-        // The planes of batch k+1 cross PCIe while batch k computes, and the results of batch k while batch k+1 computes; each
-        // of the two tickets owns its own device input / geometry / output buffers (and, by default, its own stream: below).
-        const int t = next_ticket_;
-        next_ticket_ ^= 1;
-        HIP_OK(hipSetDevice(device_));
-        if (finalize()) return -1;
-        select_slot(t);
-        // Default (SAYURI_IO_INORDER=0 is the older arrangement below): everything of a ticket on the ticket's own stream, in
-        // order -- no event between streams at all.  Each record / wait is a marker the runtime's signal thread handles; the
-        // seven per batch of the three-stream arrangement kept that thread at a full host core during self-play (one of
-        // eight busy; profiles/r04_host_profile.txt), for the same evals/s.  The other ticket's stream overlaps its copies
-        // with this one's kernels as before; a ticket's slot is free when its stream gets to the next use.
-        const bool inorder = inorder_;
-        // One exception: fp32 planes (62 KB per sample, 16 MB per batch).  On the ticket's own stream, behind kernels, the runtime
-        // moves them with a copy KERNEL, which cannot run beside the other ticket's persistent launch: the upload waited for that
-        // launch to end (72.1 -> 65.0 k evals/s through submit / wait; packed planes are 0.5 MB and do not show it).  They keep the
-        // upload stream and one event; the slot is free for them when the ticket's last completion event has fired, which the
-        // caller has normally seen already.
-        const bool big_upload = inorder && packed == nullptr;
-        hipStream_t up = inorder && !big_upload ? stream_ : h2d_stream_, down = inorder ? stream_ : d2h_stream_;
-        if (!inorder) HIP_OK(hipStreamWaitEvent(h2d_stream_, fwd_done_[t], 0));  // the forward that last read this slot's inputs
-        else if (big_upload && tick_ev_[t]) HIP_OK(hipStreamWaitEvent(h2d_stream_, tick_ev_[t], 0));
-        if (enqueue_inputs(n, planes, board_sizes, up, packed, binary, /*in_place=*/true)) return -1;
-        if (!inorder || big_upload) {
-            HIP_OK(hipEventRecord(h2d_done_[t], h2d_stream_));
-            HIP_OK(hipStreamWaitEvent(stream_, h2d_done_[t], 0));
-            if (!inorder && tick_ev_[t]) HIP_OK(hipStreamWaitEvent(stream_, tick_ev_[t], 0));  // the download that last read this slot's outputs
-        }
-        have_batch_ = true;
-        if (fwdstat_) {  // SAYURI_HIP_FWDSTAT (measuring aid): device time of every submitted forward
-            for (int k = 0; k < 2; ++k)
-                if (!fs_ev_[t][k]) HIP_OK(hipEventCreate(&fs_ev_[t][k]));
-
-            HIP_OK(hipEventRecord(fs_ev_[t][0], stream_));
-        }
-        const int uploads_before = table_uploads_;
-        // The persistent tower launch holds every CU (all registers, all LDS) for the whole forward.  A copy the runtime
-        // does with a blit KERNEL (everything below 16 KB: pass, misc, the three geometry arrays, the tower table) can
-        // therefore not run beside the OTHER ticket's tower launch: with two batches in flight a finished batch's small
-        // downloads -- and with them its completion event -- waited for the next batch's 3.5 ms launch to end, the next
-        // batch's geometry uploads likewise (driver line of round 3: 64.4 k evals/s in self-play against 70.5 k resident).
-        // So nothing small is copied any more: the heads kernel stores pass / misc straight into the caller's pinned
-        // buffers (20 KB of posted PCIe writes), a uniform batch uses geometry arrays that are resident (enqueue_inputs),
-        // and the tower table does not depend on the batch size (tower_append).  The two large outputs keep their DMA copies.
-        zc_pass_ = flags_.io_zc ? zc_device_pointer(pass) : nullptr;
-        zc_misc_ = zc_pass_ ? zc_device_pointer(misc) : nullptr;
-        if (!zc_misc_) zc_pass_ = nullptr;  // both or neither: the heads kernel takes one path
-        const int frc = forward();
-        const bool small_direct = zc_pass_ != nullptr;
-        zc_pass_ = zc_misc_ = nullptr;
-        if (frc) return -1;
-        if (fwdstat_) {
-            HIP_OK(hipEventRecord(fs_ev_[t][1], stream_));
-            fs_pending_[t] = true;
-            fs_n_[t] = n;
-            fs_uploads_ += table_uploads_ - uploads_before;
-        }
-        if (!inorder) {
-            HIP_OK(hipEventRecord(fwd_done_[t], stream_));
-            HIP_OK(hipStreamWaitEvent(d2h_stream_, fwd_done_[t], 0));
-        }
-        const size_t B2 = (size_t)board_ * board_;
-        HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, down));
-        if (!small_direct) {
-            HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, down));
-            HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, down));
-        }
-        HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, down));
-        if (!tick_ev_[t]) HIP_OK(hipEventCreateWithFlags(&tick_ev_[t], hipEventDisableTiming));
-        HIP_OK(hipEventRecord(tick_ev_[t], down));
-        if (fwdstat_) {
-            if (!fs_ev_[t][2]) HIP_OK(hipEventCreate(&fs_ev_[t][2]));
-            HIP_OK(hipEventRecord(fs_ev_[t][2], down));
-        }
-        *ticket = t;
-        return 0;
-    }
-    int wait(int ticket) override {
-        if (ticket < 0 || ticket > 1 || !tick_ev_[ticket]) return fail("wait: bad ticket");
-        HIP_OK(hipSetDevice(device_));
-        HIP_OK(hipEventSynchronize(tick_ev_[ticket]));
-        if (sx_check()) return -1;
-        if (fwdstat_ && fs_pending_[ticket]) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, fs_ev_[ticket][0], fs_ev_[ticket][1]) == hipSuccess) {
-                const int b = fs_n_[ticket] >= max_batch_ ? 2 : (fs_n_[ticket] * 2 > max_batch_ ? 1 : 0);
-                fs_ms_[b] += ms;
-                fs_cnt_[b] += 1;
-            }
-            if (fs_ev_[ticket][2] && hipEventElapsedTime(&ms, fs_ev_[ticket][1], fs_ev_[ticket][2]) == hipSuccess) {
-                fs_d2h_ms_ += ms;
-                fs_d2h_max_ = std::max(fs_d2h_max_, (double)ms);
-                fs_d2h_slow_ += ms > 1.0f;
-            }
-
-            fs_pending_[ticket] = false;
-        }
-        return 0;
-    }
-    int query(int ticket) override {
-        if (ticket < 0 || ticket > 1 || !tick_ev_[ticket]) return fail("query: bad ticket");
-        const hipError_t e = hipEventQuery(tick_ev_[ticket]);
-        if (e == hipSuccess) return 1;
-        if (e == hipErrorNotReady) return 0;
-        return fail(std::string("hipEventQuery: ") + hipGetErrorString(e));
-    }
-
-    int upload(int n, const float* planes, const int* board_sizes, const unsigned* packed = nullptr, int binary = 0) override {
-        HIP_OK(hipSetDevice(device_));
-        if (finalize()) return -1;
-        HIP_OK(hipStreamSynchronize(h2d_stream_));
-        HIP_OK(hipStreamSynchronize(d2h_stream_));
-        for (hipStream_t cs : compute_)
-            if (cs) HIP_OK(hipStreamSynchronize(cs));
-        select_slot(0);
-        if (enqueue_inputs(n, planes, board_sizes, stream_, packed, binary)) return -1;
-        HIP_OK(hipStreamSynchronize(stream_));
-        have_batch_ = true;
-        return 0;
-    }
-
-    // The heads kernel stores pass / misc straight into the caller's buffers when the device can address them: page-locked
-    // memory that is MAPPED (sayuri_hip_host_alloc, hipHostMalloc, hipHostRegister with the mapped flag).  Anything else --
-    // pinned but unmapped, pageable, another allocator's -- would fault the GPU inside the kernel with no error returned, so a
-    // pointer is asked about once (hipHostGetDevicePointer) and the answer kept; a buffer that is not device-addressable gets
-    // its results through the device-side copies and hipMemcpyAsync as before.
-    float* zc_device_pointer(float* host) {
-        if (!host) return nullptr;
-        // (an address may be handed out again after sayuri_hip_host_free, to memory of another kind: answers do not outlive a free)
-        const unsigned gen = g_host_free_gen.load(std::memory_order_acquire);
-        if (gen != zc_gen_) {
-            zc_known_.clear();
-            zc_gen_ = gen;
-        }
-        auto it = zc_known_.find(host);
-        if (it != zc_known_.end()) return it->second;
-        void* dp = nullptr;
-        float* ans = nullptr;
-        if (hipHostGetDevicePointer(&dp, host, 0) == hipSuccess && dp) ans = (float*)dp;
-        else (void)hipGetLastError();  // not an error of this engine: the fallback path is taken
-        if (zc_known_.size() >= 64) zc_known_.clear();
-        zc_known_[host] = ans;
-        return ans;
-    }
-    std::map<float*, float*> zc_known_;
-    unsigned zc_gen_ = 0;
-
-    // resident geometry arrays of a uniform batch of `bs` x `bs` boards (valid for every n <= max_batch)
-    struct IdentGeom { int *off = nullptr, *bsz = nullptr, *perm = nullptr; };
-    const IdentGeom* ident_geom(int bs) {
-        auto it = ident_.find(bs);
-        if (it != ident_.end()) return &it->second;
-        IdentGeom g;
-        std::vector<int> off(max_batch_ + 1), bz(max_batch_, bs), pm(max_batch_);
-        for (int i = 0; i <= max_batch_; ++i) off[i] = i * bs * bs;
-        for (int i = 0; i < max_batch_; ++i) pm[i] = i;
-        if (dev_upload(&g.off, off) || dev_upload(&g.bsz, bz) || dev_upload(&g.perm, pm)) return nullptr;
-        return &ident_.emplace(bs, g).first->second;
-    }
-    std::map<int, IdentGeom> ident_;
-
-    // geometry + planes H2D on the stream (no sync).  The geometry arrays are staged in a
-    // 2-deep pinned ring so a second batch can be enqueued while the first is still copying.
-    int enqueue_inputs(int n, const float* planes, const int* board_sizes, hipStream_t copy_stream, const unsigned* packed = nullptr,
-                       int binary = 0, bool in_place = false) {
-        HIP_OK(hipSetDevice(device_));
-        if (n <= 0 || n > max_batch_) return fail("batch size out of range");
-        if (packed && (binary <= 0 || binary > desc_.input_channels || desc_.input_channels - binary > 8 || board_ * board_ > 12 * 32))
-            return fail("packed planes: bad binary plane count for this network");
-        if (finalize()) return -1;
-        prev_bsz_.swap(geom_.bsz);
-        geom_.n = n;
-        geom_.bsz.resize(n);
-        geom_.off.resize(n + 1);
-        geom_.off[0] = 0;
-        // Device order = the batch's samples sorted by board size (largest first, stable): samples of one size become
-        // neighbours, so the one-workgroup-per-board convolution packs them into full tiles (two 13x13 or four 9x9 boards
-        // per tile) whatever order the queue collected them in.  perm[i] = the caller's slot of device sample i; only
-        // pack_input (reads the planes) and head_tail (writes the outputs) see the caller's order.
-        perm_.resize(n);
-        bool mixed = false;
-        for (int i = 0; i < n; ++i) {
-            const int bs = board_sizes ? board_sizes[i] : board_;
-            if (bs < 2 || bs > board_) return fail("sample board size out of range");
-            perm_[i] = i;
-            mixed |= board_sizes && bs != board_sizes[0];
-        }
-        if (mixed) std::stable_sort(perm_.begin(), perm_.end(), [&](int a, int b) { return board_sizes[a] > board_sizes[b]; });
-        for (int i = 0; i < n; ++i) {
-            geom_.bsz[i] = board_sizes ? board_sizes[perm_[i]] : board_;
-            geom_.off[i + 1] = geom_.off[i] + geom_.bsz[i] * geom_.bsz[i];
-        }
-        geom_.total = geom_.off[n];
-        if (geom_.bsz != prev_bsz_) {  // tile choices and index tables depend on the geometry only
-            tile_cache_.clear();
-            glds_cache_.clear();
-            board_plan_valid_ = false;
-        }
-        IoSlot& slot = io_[cur_slot_];
-        const bool uniform = !mixed;
-        // One sample per tile and one board size: the tables of a LONGER batch of the same size serve a shorter one (tile i
-        // depends on sample i alone), so a queue that alternates between 256 and 250 positions keeps its tables.
-        const bool one_per_tile = uniform && 2 * geom_.bsz[0] * geom_.bsz[0] > kBoardPT;
-        const bool prefix = flags_.io_prefix && one_per_tile && slot.tabs_single && slot.tabs_bsz.size() >= (size_t)n &&
-                            slot.tabs_bsz[0] == geom_.bsz[0];
-        if (!prefix && slot.tabs_bsz != geom_.bsz) {  // this slot's tables were built for another geometry
-            for (auto& kv : slot.tabs) kv.second.fresh = false;
-            slot.board.fresh = false;
-            slot.tabs_bsz = geom_.bsz;
-            slot.tabs_single = one_per_tile;
-        }
-        // the tables of the across-sample tiles (conv_glds.h) know the pixel total: they serve exactly the batch size they were
-        // built for (the board tables above serve every prefix)
-        if (slot.tabs_n != n) {
-            for (auto& kv : slot.tabs) kv.second.fresh = false;
-            slot.tabs_n = n;
-        }
-        // Geometry arrays on the device.  A uniform batch (the self-play queue: every position on the NN board) uses arrays
-        // that are resident -- off[i] = i * bs^2, bsz[i] = bs, perm[i] = i hold for every n -- so nothing is copied.  A mixed
-        // batch stages its arrays in a pinned ring and a one-workgroup kernel ON THE FORWARD'S OWN STREAM moves them: a
-        // copy of a few KB is a blit kernel to the runtime, and on the copy stream it would wait for the other ticket's
-        // persistent tower launch to give up a CU (see submit()).
-        if (flags_.io_geom) {
-            if (uniform) {
-                const IdentGeom* id = ident_geom(geom_.bsz[0]);
-                if (!id) return -1;
-                d_off_ = id->off; d_bsz_ = id->bsz; d_perm_ = id->perm;
-            } else {
-                d_off_ = slot.off; d_bsz_ = slot.bsz; d_perm_ = slot.perm;
-                int* hg = h_geom_ + (size_t)geom_slot_ * (3 * max_batch_ + 1);
-                geom_slot_ ^= 1;
-                std::memcpy(hg, geom_.off.data(), sizeof(int) * (n + 1));
-                std::memcpy(hg + max_batch_ + 1, geom_.bsz.data(), sizeof(int) * n);
-                std::memcpy(hg + 2 * max_batch_ + 1, perm_.data(), sizeof(int) * n);
-                hipLaunchKernelGGL(geom_stage_kernel, dim3(1), dim3(256), 0, stream_, (const int*)hg, max_batch_, n, d_off_, d_bsz_, d_perm_);
-                HIP_OK(hipGetLastError());
-            }
-        } else {
-            int* hg = h_geom_ + (size_t)geom_slot_ * (3 * max_batch_ + 1);
-            geom_slot_ ^= 1;
-            std::memcpy(hg, geom_.off.data(), sizeof(int) * (n + 1));
-            std::memcpy(hg + max_batch_ + 1, geom_.bsz.data(), sizeof(int) * n);
-            std::memcpy(hg + 2 * max_batch_ + 1, perm_.data(), sizeof(int) * n);
-            HIP_OK(hipMemcpyAsync(d_off_, hg, sizeof(int) * (n + 1), hipMemcpyHostToDevice, copy_stream));
-            HIP_OK(hipMemcpyAsync(d_bsz_, hg + max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
-            HIP_OK(hipMemcpyAsync(d_perm_, hg + 2 * max_batch_ + 1, sizeof(int) * n, hipMemcpyHostToDevice, copy_stream));
-        }
-        IoSlot& io = io_[cur_slot_];
-        io.packed_binary = packed ? binary : 0;
-        if (packed) {
-            const size_t words = (size_t)binary * 12 + 8;
-            // Packed records in device-addressable host memory (sayuri_hip_host_alloc: the pump's buffers) are not copied at all:
-            // pack_bits_kernel reads the 1.8 KB per sample across PCIe itself.  The copy was 14 us of DMA -- but the copy engine
-            // takes its packets in the order they were submitted, and the OTHER ticket's two downloads, submitted earlier and
-            // waiting for that ticket's heads kernel, were ahead of it: batch k+1's upload, and with it pack_bits and the tower
-            // launch, started only after batch k's results had gone out (135 us between two tower launches against 54 us for
-            // one forward after another on one stream; tools/pump_gaps.py, profiles/r05_pump_gaps.txt).  The caller keeps the
-            // records untouched until wait(), as it must for the asynchronous copy.
-            io.packed_src = nullptr;
-            if (in_place && flags_.io_zc_in) io.packed_src = (const unsigned*)zc_device_pointer((float*)const_cast<unsigned*>(packed));
-            if (io.packed_src) return 0;
-            if (!io.packed && dev_alloc(&io.packed, (size_t)max_batch_ * (40 * 12 + 8))) return -1;
-            HIP_OK(hipMemcpyAsync(io.packed, packed, sizeof(unsigned) * n * words, hipMemcpyHostToDevice, copy_stream));
-            return 0;
-        }
-        HIP_OK(hipMemcpyAsync(d_planes_, planes, sizeof(float) * (size_t)n * desc_.input_channels * board_ * board_,
-                              hipMemcpyHostToDevice, copy_stream));
-        return 0;
-    }
-
-    int run() override {
-        if (!have_batch_) return fail("run before upload");
-        HIP_OK(hipSetDevice(device_));
-        return forward();
-    }
-
-    int sync() override {
-        HIP_OK(hipSetDevice(device_));
-        HIP_OK(hipStreamSynchronize(stream_));
-        return sx_check();
-    }
-
-    int download(float* prob, float* pass, float* misc, float* own) override {
-        HIP_OK(hipSetDevice(device_));
-        const size_t n = geom_.n, B2 = (size_t)board_ * board_;
-        if (prob) HIP_OK(hipMemcpyAsync(prob, d_prob_, sizeof(float) * n * desc_.probabilities_channels * B2, hipMemcpyDeviceToHost, stream_));
-        if (pass) HIP_OK(hipMemcpyAsync(pass, d_pass_, sizeof(float) * n * desc_.pass_probability_outputs, hipMemcpyDeviceToHost, stream_));
-        if (misc) HIP_OK(hipMemcpyAsync(misc, d_misc_, sizeof(float) * n * desc_.value_misc_outputs, hipMemcpyDeviceToHost, stream_));
-        if (own) HIP_OK(hipMemcpyAsync(own, d_own_, sizeof(float) * n * B2, hipMemcpyDeviceToHost, stream_));
-        HIP_OK(hipStreamSynchronize(stream_));
-        return sx_check();
-    }
-
-    int time_runs(int iters, float* ms) override {
-        if (!have_batch_) return fail("time_runs before upload");
-        HIP_OK(hipSetDevice(device_));
-        pool_used_ = 0;
-        group_counts_.clear();
-        group_open_ = false;
-        light_ = !light_name_.empty();
-        HIP_OK(hipEventRecord(ev0_, stream_));
-        for (int i = 0; i < iters; ++i)
-            if (forward()) { light_ = false; return -1; }
-        if (group_open_ && close_group()) { light_ = false; return -1; }
-        HIP_OK(hipEventRecord(ev1_, stream_));
-        light_ = false;
-        HIP_OK(hipEventSynchronize(ev1_));
-        HIP_OK(hipEventElapsedTime(ms, ev0_, ev1_));
-        // fold the event pairs of the marked kernel class into one stat row (a pair brackets group_counts_[k] launches)
-        timed_stat_ = Stat{};
-        for (size_t k = 0; k < group_counts_.size() && 2 * k + 1 < pool_used_; ++k) {
-            float t = 0.f;
-            HIP_OK(hipEventElapsedTime(&t, pool_[2 * k], pool_[2 * k + 1]));
-            timed_stat_.launches += group_counts_[k];
-            timed_stat_.ms += t;
-            timed_stat_.flops += light_flops_ * group_counts_[k];
-            timed_stat_.bytes += light_bytes_ * group_counts_[k];
-        }
-        return 0;
-    }
-
-    // "class" brackets every launch of the class with its own event pair; "class/N" brackets RUNS of up to N consecutive
-    // launches of the class with one pair (a launch of another class ends the run).  An event is a barrier packet on the
-    // stream: the launch that follows it starts from an empty pipeline (~2-3 us), which a pair per launch both adds to
-    // the step (34 tower launches: ~5 %) and counts into every measured duration; per run of five it is a fifth of that.
-    int mark_kernel(const char* name) override {
-        light_name_ = name ? name : "";
-        light_group_ = 1;
-        const size_t slash = light_name_.find('/');
-        if (slash != std::string::npos) {
-            light_group_ = std::max(1, atoi(light_name_.c_str() + slash + 1));
-            light_name_.resize(slash);
-        }
-        return 0;
-    }
-    int timed_stat(sayuri_hip_kernel_stat* row) override {
-        std::memset(row, 0, sizeof(*row));
-        std::snprintf(row->name, sizeof(row->name), "%s", light_name_.c_str());
-        row->launches = timed_stat_.launches;
-        row->total_ms = timed_stat_.ms;
-        row->flops = timed_stat_.flops;
-        row->bytes = timed_stat_.bytes;
-        return 0;
-    }
-
-    int profile_run(sayuri_hip_kernel_stat* rows, int cap) override {
-        if (!have_batch_) return fail("profile_run before upload");
-        HIP_OK(hipSetDevice(device_));
-        stats_.clear();
-        profiling_ = true;
-        const int rc = forward();
-        profiling_ = false;
-        if (rc) return -1;
-        if (d_hdbg_) {
-            std::vector<unsigned long long> h(4 * 8);
-            HIP_OK(hipMemcpy(h.data(), d_hdbg_, h.size() * 8, hipMemcpyDeviceToHost));
-            for (int wg = 0; wg < 4; ++wg) {
-                const unsigned long long* d = &h[wg * 8];
-                fprintf(stderr, "[heads timeline wg%d] DMA + K loop %llu | act, per-pixel MFMA, pooling partials %llu | pool fold %llu | FC 1 %llu | FC 2 + row bias %llu | stores %llu | total %llu\n",
-                        wg, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[6] - d[0]);
-            }
-        }
-        if (d_sxdbg_) {  // SAYURI_SX_DBG: the split SE convolution from inside (100 MHz ticks; blocks 0 / 8 / 16 = the siblings of a tile, 1)
-            std::vector<unsigned long long> h(4 * 64);
-            HIP_OK(hipMemcpy(h.data(), d_sxdbg_, h.size() * 8, hipMemcpyDeviceToHost));
-            static const char* who[4] = {"block 0 (tile 0, kt 0)", "block 8 (tile 0, kt 1)", "block 16 (tile 0, kt 2)", "block 1 (tile 1, kt 0)"};
-            for (int wg = 0; wg < 4; ++wg) {
-                const unsigned long long* d = &h[(size_t)wg * 64];
-                fprintf(stderr, "[split SE timeline %s] start +%llu | K loop %llu | pooling %llu | squeeze + publish %llu | siblings in %llu | mid + excite %llu | gate %llu | epilogue %llu | total %llu\n",
-                        who[wg], d[0] - h[0], d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[7] - d[0]);
-            }
-        }
-        if (d_dbg_) {  // SAYURI_BOARD_DBG: s_memtime timeline of the last tower convolution (workgroups 0-3, all waves)
-            std::vector<unsigned long long> h(4 * 8 * 8);
-            HIP_OK(hipMemcpy(h.data(), d_dbg_, h.size() * 8, hipMemcpyDeviceToHost));
-            for (int wg = 0; wg < 4 && dbg_is_se_; ++wg)
-                for (int w = 0; w < 8; w += 4) {
-                    const unsigned long long* d = &h[((size_t)wg * 8 + w) * 8];
-                    fprintf(stderr, "[board+SE timeline wg%d wave%d] prologue+K loop %llu | pooling %llu | squeeze FC %llu | excite FC %llu | gate applied %llu | epilogue %llu | total %llu\n",
-                            wg, w, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[6] - d[0]);
-                }
-            for (int wg = 0; wg < 4 && !dbg_is_se_; ++wg)
-                for (int w = 0; w < 8; ++w) {
-                    const unsigned long long* d = &h[((size_t)wg * 8 + w) * 8];
-                    fprintf(stderr, "[board timeline wg%d wave%d] tables+first DMA %llu | first barrier %llu | main loop %llu (sync %llu) | epilogue %llu | total %llu\n",
-                            wg, w, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[5], d[4] - d[3], d[4] - d[0]);
-                }
-        }
-        int i = 0;
-        for (auto& kv : stats_) {
-            if (i >= cap) break;
-            std::memset(&rows[i], 0, sizeof(rows[i]));
-            std::snprintf(rows[i].name, sizeof(rows[i].name), "%s", kv.first.c_str());
-            rows[i].launches = kv.second.launches;
-            rows[i].total_ms = kv.second.ms;
-            rows[i].flops = kv.second.flops;
-            rows[i].bytes = kv.second.bytes;
-            ++i;
-        }
-        return i;
-    }
-
-    size_t device_bytes() const override { return dev_bytes_; }
-    int last_chains() const override { return last_chains_; }
-    int tower_state() const override { return tower_fn_[0] != nullptr ? 1 : 0; }
-    int debug_read(int buf, void* host, size_t bytes) override {
-        if (buf < 0 || buf >= kNumBufs || !io_[0].bufs[buf]) return fail("debug_read: no such buffer");
-        HIP_OK(hipSetDevice(device_));
-        HIP_OK(hipDeviceSynchronize());
-        const size_t have = (size_t)max_batch_ * slot_pix_ * cs_max_ * sizeof(T);
-        HIP_OK(hipMemcpy(host, io_[0].bufs[buf], std::min(bytes, have), hipMemcpyDeviceToHost));
-        return 0;
-    }
-
-private:
-    // -------------------------------------------------------------- construction helpers
-    void add_conv(int id, int cin, int cout, int k, bool depthwise = false) {
-        ConvLayerDev L;
-        L.cin = cin; L.cout = cout; L.k = k; L.depthwise = depthwise;
-        convs_[id] = L;
-    }
-    void add_fc(int id, int in, int out) {
-        FcLayerDev L;
-        L.in = in; L.out = out;
-        fcs_[id] = L;
-    }
-
-    int describe_layers() {
-        const auto& d = desc_;
-        const int C = d.residual_channels;
-        if (C <= 0 || d.input_channels <= 0) return fail("bad net description");
-        add_conv(SAYURI_L_INPUT_CONV, d.input_channels, C, 3);
-        cs_max_ = std::max(round_up(C, 32), round_up(d.input_channels, 32));
-        for (int b = 0; b < d.residual_blocks; ++b) {
-            const auto& bd = blocks_[b];
-            const int I = bd.bottleneck_channels, F = bd.feedforward_channels;
-            switch (bd.type) {
-            case SAYURI_BLOCK_RESIDUAL:
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1), C, C, 3);
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2), C, C, 3);
-                break;
-            case SAYURI_BLOCK_BOTTLENECK:
-            case SAYURI_BLOCK_NESTED_BOTTLENECK:
-                if (I <= 0) return fail("bottleneck block without bottleneck_channels");
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_PRE_BTL), C, I, 1);
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1), I, I, 3);
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2), I, I, 3);
-                if (bd.type == SAYURI_BLOCK_NESTED_BOTTLENECK) {
-                    add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV3), I, I, 3);
-                    add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV4), I, I, 3);
-                }
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_POST_BTL), I, C, 1);
-                cs_max_ = std::max(cs_max_, round_up(I, 32));
-                break;
-            case SAYURI_BLOCK_MIXER:
-                if (F <= 0 || bd.dw_filter <= 0) return fail("mixer block without ffn channels / dw filter");
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_DW_CONV), C, C, bd.dw_filter, true);
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1), C, F, 1);
-                add_conv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2), F, C, 1);
-                cs_max_ = std::max(cs_max_, round_up(F, 32));
-                break;
-            default:
-                return fail("unknown block type");
-            }
-            if (bd.apply_se) {
-                if (bd.se_size <= 0) return fail("SE block without se_size");
-                add_fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE), 3 * C, bd.se_size);
-                add_fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE), bd.se_size, 2 * C);
-            }
-        }
-        const int Cp = d.policy_head_channels, Cv = d.value_head_channels;
-        if (Cp <= 0 || Cv <= 0) return fail("bad head channels");
-        if (d.ownership_channels != 1) return fail("ownership_channels must be 1");
-        if (d.probabilities_channels > 8) return fail("too many policy planes");
-        add_conv(SAYURI_L_P_HD_CONV, C, Cp, 1);
-        if (d.policy_head_type == 1) {
-            if (d.policy_dw_filter <= 0) return fail("RepLK head without dw filter");
-            add_conv(SAYURI_L_P_DW_CONV, Cp, Cp, d.policy_dw_filter, true);
-            add_conv(SAYURI_L_P_PT_CONV, Cp, Cp, 1);
-        }
-        add_fc(SAYURI_L_P_INTER_FC, 3 * Cp, Cp);
-        add_conv(SAYURI_L_PROB_CONV, Cp, d.probabilities_channels, 1);
-        add_fc(SAYURI_L_PASS_FC, Cp, d.pass_probability_outputs);
-        add_conv(SAYURI_L_V_HD_CONV, C, Cv, 1);
-        add_fc(SAYURI_L_V_INTER_FC, 3 * Cv, 3 * Cv);
-        add_conv(SAYURI_L_V_OWNERSHIP, Cv, 1, 1);
-        add_fc(SAYURI_L_V_MISC, 3 * Cv, d.value_misc_outputs);
-        cs_max_ = std::max(cs_max_, std::max(round_up(Cp, 32), round_up(Cv, 32)));
-        return 0;
-    }
-
-    template <typename U> int dev_alloc(U** p, size_t count) {
-        void* q = nullptr;
-        const size_t bytes = std::max<size_t>(count * sizeof(U), 256);
-        HIP_OK(hipMalloc(&q, bytes));
-        // The zero fill runs on the NULL stream and hipMemset returns before it has: this engine's streams are non-blocking, so
-        // a copy or kernel they write into the new buffer right away could be overtaken by it (round 4: the first packed batch of
-        // a staging slot lost the tail of its records to the fill of the buffer allocated for them one call earlier).
-        HIP_OK(hipMemset(q, 0, bytes));
-        HIP_OK(hipStreamSynchronize(nullptr));
-        allocs_.push_back(q);
-        dev_bytes_ += bytes;
-        *p = (U*)q;
-        return 0;
-    }
-    template <typename U> int dev_upload(U** p, const std::vector<U>& h) {
-        if (dev_alloc(p, h.size())) return -1;
-        HIP_OK(hipMemcpy(*p, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice));
-        return 0;
-    }
-
-    static bool is_tiny_head_conv(int id) { return id == SAYURI_L_PROB_CONV || id == SAYURI_L_V_OWNERSHIP; }
-
-    bool heads_fused_enabled() const { return flags_.heads_fused; }
-    // Stacked [policy | value] head-convolution image for head_board_kernel (fp16 engine, normal policy head).
-    int build_head_image() {
-        const sayuri_hip_netdesc& d = desc_;
-        if (sizeof(T) != 2 || d.policy_head_type != 0) return 0;
-        const ConvLayerDev& P = convs_.at(SAYURI_L_P_HD_CONV);
-        const ConvLayerDev& V = convs_.at(SAYURI_L_V_HD_CONV);
-        const ConvLayerDev& PW = convs_.at(SAYURI_L_PROB_CONV);
-        const ConvLayerDev& OW = convs_.at(SAYURI_L_V_OWNERSHIP);
-        if (P.hw.empty() || V.hw.empty() || P.hb.empty() || V.hb.empty() || PW.hw.empty() || OW.hw.empty()) return 0;
-        HeadImages hi;
-        head_fn_ = make_head_images(P.cin, P.cout, V.cout, d.probabilities_channels, board_, P.hw.data(), P.hb.data(), V.hw.data(),
-                                    V.hb.data(), PW.hw.data(), OW.hw.data(), &hi);
-        if (!head_fn_) return 0;
-        f16 *w = nullptr, *w2 = nullptr;
-        if (dev_upload(&w2, hi.img2) || dev_upload(&w, hi.img) || dev_upload(&head_bias_, hi.bias)) return -1;
-        head_img2_ = w2;
-        head_img_ = w;
-        head_pt_ = hi.PT;
-        head_vt_ = hi.VT;
-        return 0;
-    }
-
-    int finalize() {
-        if (finalized_) return 0;
-        if (build_head_image()) return -1;
-        for (auto& kv : convs_) {
-            ConvLayerDev& L = kv.second;
-            if (L.hw.empty() || L.hb.empty()) return fail("missing tensors for conv layer " + std::to_string(kv.first));
-            L.cin_s = round_up(L.cin, 32);
-            L.cout_s = round_up(L.cout, 32);
-            if (is_tiny_head_conv(kv.first)) {  // consumed by head_tail_kernel in fp32
-                if (dev_upload(&L.w32, L.hw) || dev_upload(&L.bias, L.hb)) return -1;
-            } else if (L.depthwise) {
-                const int kk = L.k * L.k;
-                std::vector<float> wt((size_t)kk * L.cout_s, 0.f), b(L.cout_s, 0.f);
-                for (int c = 0; c < L.cout; ++c) {
-                    for (int t = 0; t < kk; ++t) wt[(size_t)t * L.cout_s + c] = L.hw[(size_t)c * kk + t];
-                    b[c] = L.hb[c];
-                }
-                float* w = nullptr;
-                if (dev_upload(&w, wt) || dev_upload(&L.bias, b)) return -1;
-                L.w = w;
-            } else {
-                L.wmt = pick_wmt(L.cout_s, sizeof(T) == 2);
-                const int kot = L.wmt * 32;
-                L.ko_pad = round_up(L.cout_s, kot);
-                const int taps = L.k * L.k, nch = L.cin_s / 32;
-                std::vector<T> img((size_t)taps * nch * 4 * L.ko_pad * 8, from_float_host(0.f));
-                for (int t = 0; t < taps; ++t)
-                    for (int ch = 0; ch < nch; ++ch)
-                        for (int kg = 0; kg < 4; ++kg)
-                            for (int ko = 0; ko < L.cout; ++ko)
-                                for (int e = 0; e < 8; ++e) {
-                                    const int c = ch * 32 + kg * 8 + e;
-                                    if (c >= L.cin) continue;
-                                    const float v = L.hw[((size_t)ko * L.cin + c) * taps + t];
-                                    img[((((size_t)t * nch + ch) * 4 + kg) * L.ko_pad + ko) * 8 + e] = from_float_host(v);
-                                }
-                std::vector<float> b(L.ko_pad, 0.f);
-                std::copy(L.hb.begin(), L.hb.end(), b.begin());
-                T* w = nullptr;
-                if (dev_upload(&w, img) || dev_upload(&L.bias, b)) return -1;
-                L.w = w;
-                if (sizeof(T) == 2 && L.k == 3 && L.ko_pad % 128 == 0) {
-                    T* wb = nullptr;
-                    std::vector<float> bb(L.ko_pad);
-                    for (int r = 0; r < L.ko_pad; ++r) bb[r] = b[board_row_channel(r)];
-                    if (dev_upload(&wb, board_row_order(img, L.ko_pad)) || dev_upload(&L.bias_board, bb)) return -1;
-                    L.w_board = wb;
-                }
-            }
-            std::vector<float>().swap(L.hw);
-            std::vector<float>().swap(L.hb);
-        }
-        if (build_se_images()) return -1;
-        for (auto& kv : fcs_) {
-            FcLayerDev& L = kv.second;
-            if (L.hw.empty() || L.hb.empty()) return fail("missing tensors for fc layer " + std::to_string(kv.first));
-            std::vector<float> wt((size_t)L.in * L.out);
-            for (int o = 0; o < L.out; ++o)
-                for (int i = 0; i < L.in; ++i) wt[(size_t)i * L.out + o] = L.hw[(size_t)o * L.in + i];
-            if (dev_upload(&L.wt, wt) || dev_upload(&L.b, L.hb)) return -1;
-            std::vector<float>().swap(L.hw);
-            std::vector<float>().swap(L.hb);
-        }
-        // workspaces
-        slot_pix_ = board_ * board_;
-        const size_t act_elems = (size_t)max_batch_ * slot_pix_ * cs_max_;
-        // the board kernels address an activation buffer with 24-bit row indices (__umul24) and 32-bit byte offsets from a
-        // uniform base (conv_board.h epilogue): both must cover the largest batch this ctx can be handed
-        if ((size_t)max_batch_ * slot_pix_ >= (size_t(1) << 24) || act_elems * sizeof(T) >= (size_t(1) << 32))
-            return fail("max_batch " + std::to_string(max_batch_) + " is too large for this network on one ctx: max_batch * board^2 must stay below 2^24 rows and an activation buffer (" +
-                        std::to_string(act_elems * sizeof(T) >> 20) + " MiB) below 4 GiB");
-        for (IoSlot& io : io_)
-            for (int i = 0; i < kNumBufs; ++i)
-                // every activation buffer starts kZeroPrefix bytes into its (zero-filled) allocation: conv_board.h reads
-                // its halo cells from that prefix
-                if (dev_alloc(&io.bufs[i], act_elems + kZeroPrefix / sizeof(T))) return -1;
-                else io.bufs[i] += kZeroPrefix / sizeof(T);
-        const size_t B2 = (size_t)board_ * board_;
-        for (IoSlot& io : io_) {
-            if (dev_alloc(&io.planes, (size_t)max_batch_ * desc_.input_channels * B2)) return -1;
-            if (dev_alloc(&io.packed, (size_t)max_batch_ * (40 * 12 + 8))) return -1;  // the packed form of the same planes (packed_planes.h)
-            if (dev_alloc(&io.off, max_batch_ + 1) || dev_alloc(&io.bsz, max_batch_) || dev_alloc(&io.perm, max_batch_)) return -1;
-            if (dev_alloc(&io.prob, (size_t)max_batch_ * desc_.probabilities_channels * B2)) return -1;
-            if (dev_alloc(&io.pass, (size_t)max_batch_ * desc_.pass_probability_outputs)) return -1;
-            if (dev_alloc(&io.misc, (size_t)max_batch_ * desc_.value_misc_outputs)) return -1;
-            if (dev_alloc(&io.own, (size_t)max_batch_ * B2)) return -1;
-        }
-        if (dev_alloc(&d_zeros_, 64)) return -1;
-        HIP_OK(hipHostMalloc((void**)&h_geom_, sizeof(int) * 2 * (3 * max_batch_ + 1), hipHostMallocDefault));
-        for (IoSlot& io : io_) {
-            if (dev_alloc(&io.gate, (size_t)max_batch_ * 2 * round_up(desc_.residual_channels, 32))) return -1;
-            if (dev_alloc(&io.separt, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
-            // conv_board_sx.h: the granules the sibling channel tiles of a board tile exchange, [tile][kt][sample][slot]
-            if (sx_kts_ && dev_alloc(&io.sx_xchg, (size_t)max_batch_ * sx_kts_ * kSxMaxSub * kSxSlots)) return -1;
-        }
-        if (sx_kts_) {
-            HIP_OK(hipHostMalloc((void**)&sx_err_host_, 64, hipHostMallocMapped));
-            std::memset(sx_err_host_, 0, 64);
-            HIP_OK(hipHostGetDevicePointer((void**)&sx_err_dev_, sx_err_host_, 0));
-        }
-        finalized_ = true;
-        select_slot(0);
-        return 0;
-    }
-
-    static T from_float_host(float v) { return (T)v; }
-
-    // fp16 images of the SE units' two FCs, laid out for the LDS-DMA staging of board_se_stage (conv_board.h): the squeeze
-    // weights once per board size 2..board with the scaled-mean third of the pooled vector folded into the mean third
-    // (reference GlobalPooling<false>, se_unit.cc:9-40: pool = (mean, mean * (B-14)/10, max)), the excite weights with
-    // both bias vectors behind them.  Units whose images do not fit the LDS keep reading fp32 weights from L2.
-    int build_se_images() {
-        if (sizeof(T) != 2) return 0;
-        const int C = desc_.residual_channels;
-        for (int b = 0; b < desc_.residual_blocks; ++b) {
-            if (!blocks_[b].apply_se) continue;
-            FcLayerDev& sq = fcs_.at(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE));
-            FcLayerDev& ex = fcs_.at(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE));
-            const int se = sq.out;
-            if (sq.hw.empty() || ex.hw.empty() || sq.hb.empty() || ex.hb.empty()) continue;  // finalize() reports it
-            if (sq.in != 3 * C || ex.in != se || ex.out != 2 * C) continue;
-            std::vector<f16> img1;
-            std::vector<unsigned char> img2;
-            int w1_bytes = 0, w2_bytes = 0;
-            if (!make_se_images(C, se, board_, sq.hw.data(), sq.hb.data(), ex.hw.data(), ex.hb.data(), &img1, &img2, &w1_bytes, &w2_bytes)) {
-                // a layer too wide for one workgroup: the per-channel-tile images of conv_board_sx.h
-                const int kts = round_up(C, 128) / 128;
-                if (flags_.se_split && round_up(C, 32) == kts * 128 &&
-                    make_sx_images(C, se, kts, board_, sq.hw.data(), sq.hb.data(), ex.hw.data(), ex.hb.data(), &img1, &img2, &w1_bytes, &w2_bytes)) {
-                    f16* d1 = nullptr;
-                    unsigned char* d2 = nullptr;
-                    if (dev_upload(&d1, img1) || dev_upload(&d2, img2)) return -1;
-                    sq.sx_img = d1; sq.sx_bytes = w1_bytes;
-                    ex.sx_img = d2; ex.sx_bytes = w2_bytes;
-                    sx_kts_ = kts;
-                }
-                continue;
-            }
-            f16* d1 = nullptr;
-            unsigned char* d2 = nullptr;
-            if (dev_upload(&d1, img1) || dev_upload(&d2, img2)) return -1;
-            sq.img16 = d1; sq.img_bytes = w1_bytes;
-            ex.img16 = d2; ex.img_bytes = w2_bytes;
-        }
-        return 0;
-    }
-
-    void release() {
-        (void)hipSetDevice(device_);
-        for (void* p : allocs_) (void)hipFree(p);
-        allocs_.clear();
-        ident_.clear();
-        if (h_geom_) (void)hipHostFree(h_geom_);
-        h_geom_ = nullptr;
-        if (sx_err_host_) (void)hipHostFree(sx_err_host_);
-        sx_err_host_ = nullptr;
-        sx_err_dev_ = nullptr;
-        for (TowerSlot& ts : tower_)
-            for (int i = 0; i < 2; ++i) {
-                if (ts.stage[i]) (void)hipHostFree(ts.stage[i]);
-                if (ts.staged[i]) (void)hipEventDestroy(ts.staged[i]);
-                ts.stage[i] = nullptr; ts.staged[i] = nullptr;
-            }
-        if (tower_mod_) (void)hipModuleUnload(tower_mod_);
-        tower_mod_ = nullptr;
-        for (hipStream_t& cs : chain_stream_) { if (cs) (void)hipStreamDestroy(cs); cs = nullptr; }
-        for (hipEvent_t& e : chain_join_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        if (chain_fork_) (void)hipEventDestroy(chain_fork_);
-        chain_fork_ = nullptr;
-        if (fwdstat_ && fs_cnt_[0] + fs_cnt_[1] + fs_cnt_[2] > 0) {
-            const long all = fs_cnt_[0] + fs_cnt_[1] + fs_cnt_[2];
-            std::fprintf(stderr, "[hip fwdstat] forwards by batch size (<= half | partial | full): %ld / %ld / %ld, mean device ms %.4f / %.4f / %.4f, tower table uploads %ld; "
-                         "forward end -> downloads done: mean %.3f ms, max %.3f, > 1 ms: %ld\n",
-                         fs_cnt_[0], fs_cnt_[1], fs_cnt_[2], fs_cnt_[0] ? fs_ms_[0] / fs_cnt_[0] : 0.0, fs_cnt_[1] ? fs_ms_[1] / fs_cnt_[1] : 0.0,
-                         fs_cnt_[2] ? fs_ms_[2] / fs_cnt_[2] : 0.0, fs_uploads_, fs_d2h_ms_ / all, fs_d2h_max_, fs_d2h_slow_);
-            fs_cnt_[0] = fs_cnt_[1] = fs_cnt_[2] = 0;
-        }
-        for (auto& pr : fs_ev_) for (hipEvent_t& e : pr) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        for (hipEvent_t& e : tick_ev_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
-        pool_.clear();
-        if (ev0_) (void)hipEventDestroy(ev0_);
-        if (ev1_) (void)hipEventDestroy(ev1_);
-        for (hipEvent_t& e : h2d_done_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        for (hipEvent_t& e : fwd_done_) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        stream_ = compute_[0];
-        if (compute_[1] && compute_[1] != compute_[0]) (void)hipStreamDestroy(compute_[1]);
-        compute_[1] = nullptr;
-        if (stream_) (void)hipStreamDestroy(stream_);
-        if (h2d_stream_) (void)hipStreamDestroy(h2d_stream_);
-        if (d2h_stream_) (void)hipStreamDestroy(d2h_stream_);
-        ev0_ = ev1_ = nullptr;
-        stream_ = h2d_stream_ = d2h_stream_ = nullptr;
-    }
-
-    // -------------------------------------------------------------- launch plumbing
-    BatchGeom dgeom() const { return BatchGeom{d_off_, d_bsz_, geom_.n, geom_.total, slot_pix_}; }
-
-    int close_group() {
-        HIP_OK(hipEventRecord(pool_[pool_used_ + 1], stream_));
-        pool_used_ += 2;
-        group_open_ = false;
-        return 0;
-    }
-    template <typename F> int timed(const char* name, double flops, double bytes, F&& launch) {
-        if (!run_.empty() && tower_flush()) return -1;  // the pending run of board convolutions goes first (stream order)
-        if (!profiling_) {
-            // light mode: un-synchronised event pairs around runs of the dominant kernel class only
-            const bool match = light_ && light_name_ == name;
-            if (group_open_ && (!match || group_counts_.back() >= light_group_)) {
-                if (close_group()) return -1;
-            }
-            if (match && !group_open_) {
-                if (pool_used_ + 2 > pool_.size()) {
-                    for (int i = 0; i < 64; ++i) {
-                        hipEvent_t e;
-                        HIP_OK(hipEventCreate(&e));
-                        pool_.push_back(e);
-                    }
-                }
-                HIP_OK(hipEventRecord(pool_[pool_used_], stream_));
-                group_counts_.push_back(0);
-                group_open_ = true;
-            }
-            launch();
-            HIP_OK(hipGetLastError());
-            if (rg_ntiles_ < 0) rows_reset();  // a launch on the forward's one stream: ordered against everything behind it
-            if (match) {
-                group_counts_.back() += 1;
-                light_flops_ = flops;
-                light_bytes_ = bytes;
-            }
-            return 0;
-        }
-        HIP_OK(hipEventRecord(ev0_, stream_));
-        launch();
-        HIP_OK(hipGetLastError());
-        rows_reset();
-        HIP_OK(hipEventRecord(ev1_, stream_));
-        HIP_OK(hipEventSynchronize(ev1_));
-        float ms = 0.f;
-        HIP_OK(hipEventElapsedTime(&ms, ev0_, ev1_));
-        Stat& s = stats_[name];
-        s.launches += 1;
-        s.ms += ms;
-        s.flops += flops;
-        s.bytes += bytes;
-        return 0;
-    }
-
-    struct TileChoice { int wnt, npos, ntiles; const typename ConvKernelTable<T>::Entry* e; };
-
-    int choose_tile(int wmt, int kot_tiles, TileChoice* out) {
-        auto it = tile_cache_.find(wmt * 1024 + kot_tiles);
-        if (it != tile_cache_.end()) { *out = it->second; return 0; }
-        double best_cost = 1e30;
-        TileChoice best{};
-        bool found = false;
-        for (const auto& e : ConvKernelTable<T>::entries()) {
-            if (e.wmt != wmt) continue;
-            const int PT = 64 * e.wnt;
-            int npos, nsub;
-            geom_.tile_bounds(PT, &npos, &nsub);
-            if (npos > e.npos_cap || nsub > kMaxSub || e.lds(npos) > kMaxLds) continue;
-            const int ntiles = (geom_.total + PT - 1) / PT;
-            const double waves = std::ceil((double)ntiles * kot_tiles / kNumCU);
-            const double cost = waves * (PT + 24);
-            if (cost < best_cost) { best_cost = cost; best = TileChoice{e.wnt, npos, ntiles, &e}; found = true; }
-        }
-        if (!found) return fail("no conv tile configuration fits this batch geometry");
-        tile_cache_[wmt * 1024 + kot_tiles] = best;
-        *out = best;
-        return 0;
-    }
-
-    struct GldsChoice { const GldsEntry* e; int ntiles; };
-    // index tables of the current batch geometry for pixel-tile size 64*wnt (built on first use)
-    int tile_tabs(const GldsEntry& e, const TileTabs** out) {
-        TileTabs& t = io_[cur_slot_].tabs[e.wnt];
-        if (!t.src) {
-            const size_t max_tiles = ((size_t)max_batch_ * slot_pix_ + e.pt - 1) / e.pt;
-            if (dev_alloc(&t.src, max_tiles * e.npos) || dev_alloc(&t.pix, max_tiles * e.pt)) return -1;
-        }
-        if (!t.fresh) {
-            const int ntiles = (geom_.total + e.pt - 1) / e.pt;
-            hipLaunchKernelGGL(e.setup, dim3(ntiles), dim3(256), 0, stream_, dgeom(), t.src, t.pix);
-            HIP_OK(hipGetLastError());
-            t.fresh = true;
-        }
-        *out = &t;
-        return 0;
-    }
-    const GldsChoice* choose_glds(const ConvLayerDev& L) {
-        if (sizeof(T) != 2 || L.k != 3 || L.ko_pad % 128 != 0) return nullptr;
-        const int key = L.ko_pad % 256 == 0 ? 8 : 4;
-        auto it = glds_cache_.find(key);
-        if (it == glds_cache_.end()) {
-            GldsChoice c{nullptr, 0};
-            c.e = pick_glds(geom_, L.ko_pad, &c.ntiles, flags_.conv);
-            it = glds_cache_.emplace(key, c).first;
-        }
-        return it->second.e ? &it->second : nullptr;
-    }
-
-    // index tables of the current batch geometry for conv_board_kernel (built on first use)
-    int board_tabs(const BoardTabs** out) {
-        BoardTabs& t = io_[cur_slot_].board;
-        if (!t.src) {
-            // a tile holds at least one sample
-            if (dev_alloc(&t.src, (size_t)max_batch_ * kBoardMaxPos) || dev_alloc(&t.pix, (size_t)max_batch_ * kBoardPT) ||
-                dev_alloc(&t.cols, max_batch_))
-                return -1;
-        }
-        // (a slot's tables may be kept for a shorter batch of the same geometry -- enqueue_inputs' prefix rule trusts the
-        // sizes recorded at enqueue time; what counts here is how many tiles the tables were BUILT for)
-        if (!t.fresh || t.npos_built != board_plan_.npos || board_plan_.ntiles > t.ntiles_built) {
-            hipLaunchKernelGGL(board_setup_kernel, dim3(board_plan_.ntiles), dim3(256), 0, stream_, dgeom(), board_plan_.npos, t.src,
-                               t.pix, t.cols);
-            HIP_OK(hipGetLastError());
-            t.fresh = true;
-            t.npos_built = board_plan_.npos;
-            t.ntiles_built = board_plan_.ntiles;
-        }
-        *out = &t;
-        return 0;
-    }
-    // the one-workgroup-per-board kernel applies to fp16 3x3 layers whose boards fit a tile and fill it reasonably
-    const BoardEntry* choose_board(const ConvLayerDev& L, int* kot_tiles) {
-        if (sizeof(T) != 2 || L.k != 3) return nullptr;
-        if (!board_plan_valid_) { board_plan_ = board_plan(geom_, flags_.conv); board_plan_valid_ = true; }
-        if (!board_plan_.ok || board_plan_.fill < flags_.conv.board_min_fill) return nullptr;
-        return pick_board(board_plan_, L.ko_pad, kot_tiles, flags_.board_kot);
-    }
-
-    // Does this layer of the persistent launch get the generated epilogue (tower_seam.py epi_hook)?  Then its weights and bias go
-    // in board_row_channel order and BoardParams::row_order says so.  What the generated text covers: Mish / ReLU / no activation, one sample per tile
-    // with computed table entries (arith), the layer's channels = the channel tile, an even number of row tiles per wave.
-    bool board_row_order_ok(const ConvLayerDev& L, const BoardEntry* be, const BoardParams& bp, int act) const {
-        return flags_.tower_gen_epi && tower_ok(be->kot) && !bp.dbg && board_uses_row_order(be->kot) && bp.arith &&
-               (act == kMish || act == kReLU || act == kIdentity) &&
-               L.cout_s == be->kot && L.ko_pad == be->kot && L.w_board && L.bias_board;
-    }
-
-    // A block's last 3x3 convolution with the squeeze-and-excitation unit that follows it inside the kernel
-    // (conv_board.h).  Returns 1 when the fused kernel does not apply (the caller then runs conv + se_unit), 0 / -1.
-    int conv_se(const ConvLayerDev& L, const FcLayerDev& sq, const FcLayerDev& ex, const T* in, T* out, const T* res, int C, int act) {
-        const bool off = !flags_.se_fused;
-        int bkt = 0;
-        const BoardEntry* be = nullptr;
-        // the variant whose channel tile covers the whole layer, whatever the batch size: a position's result must not
-        // depend on how many others share its batch (a small batch would otherwise pick two half-width workgroups and
-        // the separate SE kernels, which round x to fp16 before pooling)
-        if (!off && choose_board(L, &bkt))
-            for (const auto& e : kBoardEntries)
-                if (e.fn_se && e.kot == L.ko_pad && e.lds(board_plan_.npos) <= kMaxLds) be = &e;
-        if (!be || C > be->kot) return 1;
-        const bool staged = sq.img16 && ex.img16;
-        if (!staged && (sq.out % 4 || sq.out > 512 || ex.out % 4 || ex.out > 2048 || 512 % (sq.out / 4) || 512 % (ex.out / 4))) return 1;
-        if constexpr (sizeof(T) != 2) return 1;
-        // WHICH samples take the fused form is a property of the sample alone, never of its batch mates (a position's result
-        // must not depend on what else the queue collected: the fused form pools the fp32 accumulators, the separate kernels
-        // pool x rounded to fp16): a board too large to share a tile with another of its size (2 bs^2 > 384 pixel slots, i.e.
-        // bs >= 14) is ALWAYS alone in its tile and ALWAYS fused; a smaller board ALWAYS goes through the separate kernels, also
-        // when it happens to sit alone in a tile.  The device order is largest first, so the fused samples -- and their tiles,
-        // one each -- lead the batch: tiles [0, nbig) fused, tiles [nbig, ntiles) = samples [nbig, n) plain convolution + SE unit.
-        int nbig = 0;
-        while (nbig < geom_.n && 2 * geom_.bsz[nbig] * geom_.bsz[nbig] > kBoardPT) ++nbig;
-        if (!flags_.se_by_geometry) nbig = board_plan_.single ? geom_.n : 0;  // SAYURI_SE_BY_GEOMETRY=0: round 4's rule (A/B, tests)
-        if (nbig == 0) return 1;
-        const bool split = nbig < geom_.n;
-        const BoardTabs* tabs = nullptr;
-        if (board_tabs(&tabs)) return -1;
-        BoardSeParams sp;
-        std::memset(&sp, 0, sizeof(sp));  // padding too: the tower table is compared bytewise with its cached copy
-        BoardParams& bp = sp.b;
-        bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos; bp.dbg = nullptr;
-        bp.uniform_info = board_plan_.uniform_info;
-        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && flags_.arith) ? 1 : 0;
-        ConvParams& p = bp.c;
-        p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
-        p.g = dgeom();
-        p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
-        p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = board_plan_.ntiles;
-        sp.squeeze = sq.dev(); sp.excite = ex.dev(); sp.C = C;
-        sp.w1h = staged ? sq.img16 : nullptr; sp.w2h = staged ? ex.img16 : nullptr;
-        sp.w1_bytes = sq.img_bytes; sp.w2_bytes = ex.img_bytes;
-#ifdef SAYURI_EXPERIMENTS
-        if (flags_.board_dbg < 0) {  // negative n: timeline of the n-th SE convolution of the forward
-            if (!d_dbg_ && dev_alloc(&d_dbg_, 4 * 8 * 8)) return -1;
-            if (++dbg_se_call_ == -flags_.board_dbg) { bp.dbg = d_dbg_; dbg_is_se_ = true; }
-        }
-#endif
-        const double px = geom_.total;
-        const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * geom_.n * ((double)sq.in * sq.out + (double)ex.in * ex.out);
-        const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
-        if (board_row_order_ok(L, be, bp, act)) { p.w = L.w_board; p.bias = L.bias_board; bp.row_order = 1; }
-        const bool to_run = !split && tower_ok(be->kot) && !bp.dbg;
-        if (!run_.empty() && !(to_run && run_kot_ == be->kot) && tower_flush()) return -1;
-        if (rows_use(in, L.cin_s, "conv3x3_tower_se") || rows_use(out, L.cout_s, "conv3x3_tower_se") || rows_use(res, L.cout_s, "conv3x3_tower_se"))
-            return -1;
-        if (to_run) return tower_append(be->kot, sp, true, flops, bytes);
-        const auto fn = be->fn_se;
-        const size_t lds = be->lds(board_plan_.npos);
-        const int grid = split ? nbig : board_plan_.ntiles;
-        if (timed("conv3x3_tower_se", flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, sp); })) return -1;
-        if (!split) return 0;
-        // the small boards of the batch: the same convolution without epilogue extras on the tiles behind, then the unit's
-        // three kernels on the samples behind
-        BoardParams rest = bp;
-        rest.row_order = 0;
-        rest.c.w = L.w; rest.c.bias = L.bias; rest.c.res = nullptr; rest.c.act = kIdentity;
-        rest.c.npos = nbig;  // first tile of the launch (conv_board_kernel)
-        rest.c.num_pix_tiles = board_plan_.ntiles - nbig;
-        const auto fn2 = be->fn;
-        const int grid2 = rest.c.num_pix_tiles;  // be->kot covers the layer: one channel tile
-        if (timed("conv3x3_tower", flops, bytes, [&] { hipLaunchKernelGGL(fn2, dim3(grid2), dim3(512), lds, stream_, rest); })) return -1;
-        return se_unit(sq, ex, out, res, C, round_up(C, 32), act, nbig);
-    }
-
-
-    // A block's last 3x3 convolution with its SE unit when the layer's channels are split over kts = 2..4 workgroups of 128
-    // (conv_board_sx.h: the siblings exchange their partial squeeze sums inside the launch).  Returns 1 when the form does not apply
-    // (the caller runs conv + se_unit), 0 / -1.  WHICH samples take it is a property of the sample alone: a board of which at
-    // most kSxMaxSub fit a tile (9x9 and larger) ALWAYS does, a smaller one NEVER -- the device order is largest first, so the
-    // tiles [0, T) of the batch are fused and [T, ntiles) = the samples behind take the plain convolution + the unit's three
-    // kernels, exactly as conv_se splits a mixed batch.  Honours the tile range of a chained forward.
-    int conv_sx(const ConvLayerDev& L, const FcLayerDev& sq, const FcLayerDev& ex, const T* in, T* out, const T* res, int C, int act) {
-        if constexpr (sizeof(T) != 2) return 1;
-        if (!flags_.se_split || !sq.sx_img || !ex.sx_img || !sx_kts_ || L.ko_pad != sx_kts_ * 128 || L.cout_s != L.ko_pad) return 1;
-        int bkt = 0;
-        if (!choose_board(L, &bkt)) return 1;
-        const BoardEntry* be = nullptr;
-        for (const auto& e : kBoardEntries)
-            if (e.kot == 128 && e.lds(board_plan_.npos) <= kMaxLds) be = &e;
-        if (!be) return 1;
-        auto per_tile = [](int bs) {
-            BoardPack pk;
-            int k = 0;
-            while (pk.fits(bs)) { pk.add(bs); ++k; }
-            return k;
-        };
-        int nf = 0;
-        while (nf < geom_.n && per_tile(geom_.bsz[nf]) <= kSxMaxSub) ++nf;
-        int T0 = 0;  // first tile that is not fused
-        while (T0 < board_plan_.ntiles && board_plan_.tile_first[T0] < nf) ++T0;
-        const int t0 = rg_tile0_, t1 = rg_tile0_ + range_ntiles();
-        const int f0 = t0, f1 = std::min(t1, T0), r0 = std::max(t0, T0), r1 = t1;
-        if (!run_.empty() && tower_flush()) return -1;
-        const BoardTabs* tabs = nullptr;
-        if (board_tabs(&tabs)) return -1;
-        if (rows_use(in, L.cin_s, "conv3x3_tower_sx") || rows_use(out, L.cout_s, "conv3x3_tower_sx") || rows_use(res, L.cout_s, "conv3x3_tower_sx"))
-            return -1;
-        const unsigned epoch = sx_epoch0_ + 1u + (unsigned)sx_idx_++;
-        BoardSxParams sp;
-        std::memset(&sp, 0, sizeof(sp));
-        BoardParams& bp = sp.b;
-        bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos; bp.dbg = nullptr;
-        bp.uniform_info = board_plan_.uniform_info;
-        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && flags_.arith) ? 1 : 0;
-        ConvParams& p = bp.c;
-        p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
-        p.g = dgeom();
-        p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
-        p.taps = 9; p.act = act;
-        const size_t lds = be->lds(board_plan_.npos);
-        const int kts = sx_kts_;
-        const double px_all = range_px();
-        if (f1 > f0) {
-            p.npos = f0; p.num_pix_tiles = f1 - f0;
-            sp.w1t = sq.sx_img; sp.w2t = ex.sx_img; sp.w1_bytes = sq.sx_bytes; sp.w2_bytes = ex.sx_bytes;
-            sp.nsizes = board_ - 1; sp.se = sq.out; sp.kts = kts;
-            sp.xchg = io_[cur_slot_].sx_xchg; sp.epoch = epoch; sp.err = sx_err_dev_;
-            if (flags_.sx_dbg > 0 && profiling_ && sx_idx_ == flags_.sx_dbg) {
-                if (!d_sxdbg_ && dev_alloc(&d_sxdbg_, 4 * 64)) return -1;
-                sp.b.dbg = d_sxdbg_;
-            }
-            const int s0 = board_plan_.tile_first[f0], s1 = board_plan_.tile_first[f1];
-            const double px = (double)(geom_.off[s1] - geom_.off[s0]);
-            const double flops = 2.0 * px * L.cin * L.cout * 9 + 2.0 * (s1 - s0) * ((double)sq.in * sq.out + (double)ex.in * ex.out);
-            const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
-            const int grid = (f1 - f0 + 7) / 8 * 8 * kts;
-            if (timed("conv3x3_tower_sx", flops, bytes, [&] { hipLaunchKernelGGL(conv_board_sx_kernel<2>, dim3(grid), dim3(512), lds, stream_, sp); }))
-                return -1;
-        }
-        if (r1 > r0) {
-            // the small boards behind: the plain convolution (no activation, no residual) on their tiles, then the unit's kernels
-            BoardParams rest = bp;
-            rest.c.res = nullptr; rest.c.act = kIdentity;
-            rest.c.npos = r0; rest.c.num_pix_tiles = r1 - r0;
-            const int s0 = board_plan_.tile_first[r0], s1 = board_plan_.tile_first[r1];
-            const double px = (double)(geom_.off[s1] - geom_.off[s0]);
-            const double flops = 2.0 * px * L.cin * L.cout * 9;
-            const double bytes = sizeof(T) * (px * L.cin + px * L.cout + (double)L.cin * L.cout * 9);
-            const auto fn2 = be->fn;
-            const int grid2 = (r1 - r0) * kts;
-            if (timed("conv3x3_tower", flops, bytes, [&] { hipLaunchKernelGGL(fn2, dim3(grid2), dim3(512), lds, stream_, rest); })) return -1;
-            if (se_unit(sq, ex, out, res, C, round_up(C, 32), act, s0, s1 - s0)) return -1;
-        }
-        (void)px_all;
-        return 0;
-    }
-
-    int conv(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
-        int bkt = 0;
-        if (const BoardEntry* be = choose_board(L, &bkt)) {
-            const BoardTabs* tabs = nullptr;
-            if (board_tabs(&tabs)) return -1;
-            BoardParams bp;
-            std::memset(&bp, 0, sizeof(bp));
-            bp.tab_src = tabs->src; bp.tab_pix = tabs->pix; bp.tab_cols = tabs->cols; bp.npos = board_plan_.npos;
-            bp.dbg = nullptr;
-            bp.uniform_info = board_plan_.uniform_info;
-        bp.arith = (board_plan_.single && board_plan_.uniform_info >= 0 && flags_.arith) ? 1 : 0;
-            auto fn = be->fn;
-#ifdef SAYURI_EXPERIMENTS
-            if (be->kot == 256 && flags_.board_dbg > 0 && !strcmp(name, "conv3x3_tower")) {
-                // in-kernel timeline of the SAYURI_BOARD_DBG-th tower convolution of the forward (1 = first)
-                if (!d_dbg_ && dev_alloc(&d_dbg_, 4 * 8 * 8)) return -1;
-                if (++dbg_call_ == flags_.board_dbg) {
-                    bp.dbg = d_dbg_;
-                    fn = &conv_board_kernel<4, true>;
-                }
-            }
-#endif
-            ConvParams& p = bp.c;
-            p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
-            p.g = dgeom();
-            p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
-            p.taps = 9; p.act = act; p.npos = rg_tile0_; p.num_pix_tiles = range_ntiles();  // (npos: the launch's first tile, conv_board_kernel)
-#ifdef SAYURI_EXPERIMENTS
-            if (flags_.act_override >= 0) p.act = flags_.act_override;  // timing experiments only
-#endif
-            const double px = range_px();
-            const double flops = 2.0 * px * L.cin * L.cout * 9;
-            const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
-            const bool to_run = bkt == 1 && tower_ok(be->kot) && !bp.dbg && rg_ntiles_ < 0;
-            // a pending run this layer does not join ends here (a launch = an ordered point: the table starts afresh)
-            if (!run_.empty() && !(to_run && run_kot_ == be->kot) && tower_flush()) return -1;
-            if (rows_use(in, L.cin_s, name) || rows_use(out, L.cout_s, name) || rows_use(res, L.cout_s, name)) return -1;
-            if (to_run) {
-                if (board_row_order_ok(L, be, bp, p.act)) { p.w = L.w_board; p.bias = L.bias_board; bp.row_order = 1; }
-                BoardSeParams sp;
-                std::memset(&sp, 0, sizeof(sp));
-                sp.b = bp;
-                return tower_append(be->kot, sp, false, flops, bytes);
-            }
-            const size_t lds = be->lds(board_plan_.npos);
-            const int grid = range_ntiles() * bkt;
-            return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, bp); });
-        }
-        if (rg_ntiles_ >= 0) return fail(std::string("chained forward: layer ") + name + " has no board kernel");
-        if (const GldsChoice* gc = choose_glds(L)) {
-            const TileTabs* tabs = nullptr;
-            if (tile_tabs(*gc->e, &tabs)) return -1;
-            GldsParams gp;
-            gp.tab_src = tabs->src;
-            gp.tab_pix = tabs->pix;
-            ConvParams& p = gp.c;
-            p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
-            p.g = dgeom();
-            p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
-            p.taps = 9; p.act = act; p.npos = 0; p.num_pix_tiles = gc->ntiles;
-            gp.zeros = d_zeros_;
-            const double px = geom_.total;
-            const double flops = 2.0 * px * L.cin * L.cout * 9;
-            const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * 9);
-            const auto fn = gc->e->fn;
-            const size_t lds = gc->e->lds;
-            const int grid = gc->ntiles * (L.ko_pad / (gc->e->wmt * 32));
-            return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, gp); });
-        }
-        const int kot = L.wmt * 32, kot_tiles = L.ko_pad / kot;
-        TileChoice tc;
-        if (choose_tile(L.wmt, kot_tiles, &tc)) return -1;
-        ConvParams p;
-        p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.out = out;
-        p.g = dgeom();
-        p.cin_s = L.cin_s; p.cout_s = L.cout_s; p.ko_pad = L.ko_pad;
-        p.taps = L.k * L.k; p.act = act; p.npos = tc.npos; p.num_pix_tiles = tc.ntiles;
-        const double px = geom_.total;
-        const double flops = 2.0 * px * L.cin * L.cout * p.taps;
-        const double bytes = sizeof(T) * (px * L.cin + px * L.cout * (res ? 2 : 1) + (double)L.cin * L.cout * p.taps);
-        const auto fn = tc.e->fn;
-        const size_t lds = tc.e->lds(tc.npos);
-        const int grid = tc.ntiles * kot_tiles;
-        return timed(name, flops, bytes, [&] { hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, stream_, p); });
-    }
-
-    int depthwise(const char* name, const ConvLayerDev& L, const T* in, T* out, const T* res, int act) {
-        const int EPP = ElemTraits<T>::kPieceElems;
-        const size_t total = (size_t)geom_.total * (L.cout_s / EPP);
-        const int grid = (int)((total + 255) / 256);
-        const double px = geom_.total;
-        const BatchGeom g = dgeom();
-        return timed(name, 2.0 * px * L.cout * L.k * L.k, sizeof(T) * px * L.cout * (res ? 3 : 2), [&] {
-            hipLaunchKernelGGL(depthwise_kernel<T>, dim3(grid), dim3(256), 0, stream_, in, res, out,
-                               (const float*)L.w, (const float*)L.bias, g, L.cout, L.cout_s, L.k, act);
-        });
-    }
-
-    // n0: the unit runs on the samples [n0, n) of the batch (conv_se's split of a mixed batch)
-    int se_unit(const FcLayerDev& sq, const FcLayerDev& ex, T* x, const T* res, int C, int cs, int act, int n0 = 0, int count = -1) {
-        const BatchGeom g = dgeom();
-        const int ns = count >= 0 ? count : geom_.n - n0;
-        const double px = geom_.off[n0 + ns] - geom_.off[n0];
-        constexpr int EPP = ElemTraits<T>::kPieceElems;
-        if (cs / EPP > 256) return fail("SE unit: more than 256*8 channels is not supported");
-        if (timed("se_pool", 2.0 * px * C, sizeof(T) * px * C, [&] {
-                hipLaunchKernelGGL(se_pool_kernel<T>, dim3(ns * kSeSplit), dim3(256), 0, stream_, (const T*)x,
-                                   d_separt_, g, cs, n0);
-            }))
-            return -1;
-        const size_t smem = sizeof(float) * (3 * C + sq.out + kSeFcThreads);
-        if (timed("se_fc", 2.0 * ns * ((double)sq.in * sq.out + (double)ex.in * ex.out),
-                  4.0 * ns * ((double)sq.in * sq.out + (double)ex.in * ex.out), [&] {
-                      hipLaunchKernelGGL(se_fc_kernel, dim3(ns), dim3(kSeFcThreads), smem, stream_,
-                                         (const float*)d_separt_, d_gate_, g, C, cs, sq.dev(), ex.dev(), act, n0);
-                  }))
-            return -1;
-        const int ppr = cs / EPP;
-        const dim3 grid((slot_pix_ * ppr + 256 * kScaleUnroll - 1) / (256 * kScaleUnroll), ns);
-        return timed("se_scale", 3.0 * px * C, sizeof(T) * px * C * 3, [&] {
-            hipLaunchKernelGGL(se_scale_kernel<T>, grid, dim3(256), 0, stream_, (const T*)x, res, x,
-                               (const float*)d_gate_, g, C, cs, act, n0);
-        });
-    }
-
-    // small pool of activation buffers
-    static constexpr int kNumBufs = 6;
-    // -------------------------------------------------------------- who may write which bytes when (the buffer table)
-    // Launches on one stream are ordered grid-wide; the layers INSIDE a persistent tower run are not (a workgroup walks the
-    // whole run on its own clock), and neither are the chains of a chained forward (streams of their own).  In such an
-    // UNORDERED SCOPE the only order is "this workgroup's / this chain's earlier layers", so a buffer may be written while
-    // other workgroups still have to read it -- sound exactly when the bytes a tile touches in a buffer are the same in every
-    // layer of the scope, i.e. when the buffer has ONE ROW STRIDE throughout it (a tile is whole samples, a sample's rows
-    // start at sample * slot_pix * stride):
-    //
-    //   buffer                    written by                     row stride              may be recycled
-    //   ------------------------  -----------------------------  ----------------------  ------------------------------------------
-    //   `in` (packed input)       pack_bits / pack_input         input conv's cin_s (64) never inside the forward (kept to its end)
-    //   pool buffers x, y, t0...  the convolution they are `out` the tower's cout_s      as soon as the layer that reads them is
-    //                             of (epilogue, own tile's rows)  (256 / 384 / 128)        appended: give() -> take(), SAME stride only
-    //   d_separt_, d_gate_        se_pool / se_fc, per sample     per-sample records      per sample, inside its chain
-    //   se_xchg (384-ch SE)       the sibling channel tiles       per (tile, channel tile) next SE layer (tagged with the layer's epoch)
-    //   d_prob_ ... d_own_        the heads kernel                per sample              by the ticket's next submit
-    //
-    // rounds 3-4 broke the first line (the input's buffer went back to the pool and came out again as a block's output with
-    // stride 256: a late workgroup's input lay under an early workgroup's third layer).  The table below is that rule as a
-    // run-time check: every use of a pool buffer inside an unordered scope names its stride, and a second stride is refused.
-    int rows_stride_[kNumBufs] = {};          // 0: not used yet in the current scope
-    const char* rows_first_[kNumBufs] = {};   // the layer that fixed it
-    void rows_reset() {
-        for (int i = 0; i < kNumBufs; ++i) rows_stride_[i] = 0;
-    }
-    int rows_use(const T* p, int stride, const char* layer) {
-        if (!p || flags_.dbg_recycle_input >= 2) return 0;
-        for (int i = 0; i < kNumBufs; ++i) {
-            if (bufs_[i] != p) continue;
-            if (rows_stride_[i] && rows_stride_[i] != stride)
-                return fail(std::string("activation buffer ") + std::to_string(i) + " is used with row stride " + std::to_string(stride) + " by " +
-                            layer + " and with " + std::to_string(rows_stride_[i]) + " by " + (rows_first_[i] ? rows_first_[i] : "?") +
-                            " inside one persistent run / chained forward: the rows of different tiles would overlap");
-            rows_stride_[i] = stride;
-            rows_first_[i] = layer;
-        }
-        return 0;
-    }
-    int take() {
-        for (int i = 0; i < kNumBufs; ++i)
-            if (!busy_[i]) { busy_[i] = true; return i; }
-        return -1;
-    }
-    void give(int i) { busy_[i] = false; }
-
-    const ConvLayerDev& cv(int id) const { return convs_.at(id); }
-    const FcLayerDev& fc(int id) const { return fcs_.at(id); }
-
-    // -------------------------------------------------------------- the graph
-    // One forward of the current batch: as ONE chain of launches on stream_, or -- chains_for_batch() -- as G chains over G
-    // ranges of tiles on G streams, forked from and joined to stream_ by events (the activations, tables and outputs of the
-    // ranges are disjoint: a tile is whole samples).
-    int forward() {
-        const int G = chains_for_batch();
-        last_chains_ = G;
-        rows_reset();
-        if (sx_kts_) {
-            IoSlot& io = io_[cur_slot_];
-            int nse = 0;
-            for (const auto& b : blocks_) nse += b.apply_se ? 1 : 0;
-            if (io.sx_epoch > 0xfff00000u) {  // tags about to wrap: start over on a clean buffer (stream order: behind the last readers)
-                HIP_OK(hipMemsetAsync(io.sx_xchg, 0, sizeof(unsigned long long) * (size_t)max_batch_ * sx_kts_ * kSxMaxSub * kSxSlots, stream_));
-                io.sx_epoch = 0;
-            }
-            sx_epoch0_ = io.sx_epoch;
-            io.sx_epoch += (unsigned)nse;
-        }
-        if (G <= 1) return forward_graph();
-        if (chain_setup(G)) return -1;
-        const BoardTabs* tabs = nullptr;
-        if (board_tabs(&tabs)) return -1;  // built on stream_, in front of the fork
-        hipStream_t main = stream_;
-        HIP_OK(hipEventRecord(chain_fork_, main));
-        int rc = 0;
-        const int nt = board_plan_.ntiles;
-        for (int g = 0; g < G && rc == 0; ++g) {
-            rg_tile0_ = (int)((long)nt * g / G);
-            rg_ntiles_ = (int)((long)nt * (g + 1) / G) - rg_tile0_;
-            rg_n0_ = board_plan_.tile_first[rg_tile0_];
-            rg_ns_ = board_plan_.tile_first[rg_tile0_ + rg_ntiles_] - rg_n0_;
-            stream_ = chain_stream_[g];
-            hipError_t e = hipStreamWaitEvent(stream_, chain_fork_, 0);
-            static const bool serial = std::getenv("SAYURI_CHAINS_SERIAL") != nullptr;  // debugging aid: the chains one after another
-            if (serial && g > 0 && e == hipSuccess) e = hipStreamWaitEvent(stream_, chain_join_[g - 1], 0);
-            if (e == hipSuccess) rc = forward_graph();
-            if (e == hipSuccess && rc == 0) e = hipEventRecord(chain_join_[g], stream_);
-            if (e != hipSuccess) rc = fail(std::string("chained forward: ") + hipGetErrorString(e));
-        }
-        stream_ = main;
-        rg_tile0_ = 0; rg_ntiles_ = -1; rg_n0_ = 0; rg_ns_ = -1;
-        if (rc) return rc;
-        for (int g = 0; g < G; ++g) HIP_OK(hipStreamWaitEvent(main, chain_join_[g], 0));
-        return 0;
-    }
-
-    int forward_graph() {
-        const auto& d = desc_;
-        const int C = d.residual_channels, csC = round_up(C, 32), act = d.default_act;
-        const BatchGeom g = dgeom();
-        for (int i = 0; i < kNumBufs; ++i) busy_[i] = false;
-        dbg_call_ = 0;
-        dbg_se_call_ = 0;
-        sx_idx_ = 0;
-        run_.clear();
-        table_used_ = 0;
-
-        int x = take();
-        {
-            const ConvLayerDev& L = cv(SAYURI_L_INPUT_CONV);
-            const int in = take();
-            const int n0 = rg_n0_, ns = range_ns();
-            const int grid = ns * kPackSplit;  // kPackSplit workgroups per sample
-            const double px = range_px();
-            T* dst = bufs_[in];
-            const int cin = d.input_channels, cs = L.cin_s, board = board_;
-            const IoSlot& io = io_[cur_slot_];
-            if (io.packed_binary > 0) {
-                // (records read across PCIe: one workgroup per sample, so that a record crosses once)
-                const unsigned* rec = io.packed_src ? io.packed_src : io.packed;
-                const int split = io.packed_src ? 1 : kPackSplit;
-                const int nbin = io.packed_binary, words = nbin * 12 + 8;
-                if (timed("pack_input", 0, (double)ns * words * 4 + px * cs * sizeof(T), [&] {
-                        hipLaunchKernelGGL(pack_bits_kernel<T>, dim3(ns * split), dim3(256), 0, stream_, rec, words, nbin, dst, g, cin, cs,
-                                           (const int*)d_perm_, n0, split);
-                    }))
-                    return -1;
-            } else {
-                const int chunk = pack_input_chunk(slot_pix_, cs, (int)sizeof(T));
-                const size_t lds = (size_t)chunk * (cs * sizeof(T) + 16);
-                const size_t flat_lds = pack_input_flat_lds(slot_pix_, cs, (int)sizeof(T));
-                // a sample that fits 64 KiB of LDS whole and whose planes are below 2^16 floats: one workgroup per sample
-                const bool flat = flat_lds <= 64 * 1024 && (size_t)cin * board * board < 65536;
-                if (timed("pack_input", 0, px * cin * 4 + px * cs * sizeof(T), [&] {
-                        if (flat)
-                            hipLaunchKernelGGL(pack_input_flat_kernel<T>, dim3(ns), dim3(kPackFlatThreads), flat_lds, stream_,
-                                               (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_, n0);
-                        else
-                            hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid), dim3(kPackThreads), lds, stream_,
-                                               (const float*)d_planes_, dst, g, cin, cs, board, (const int*)d_perm_, chunk, n0);
-                    }))
-                    return -1;
-            }
-            if (conv("conv3x3_input", L, bufs_[in], bufs_[x], nullptr, act)) return -1;
-            if (flags_.dbg_recycle_input) give(in);  // SAYURI_DEBUG_RECYCLE_INPUT: rounds 3-4's hand-back, to show what catches it
-            // `in` is NOT handed back: it stays the packed input's buffer for the whole forward.  Its rows have the input
-            // convolution's channel stride (64), every later buffer the tower's (256 / 384): recycled as a block's output, sample
-            // m's rows would lie on top of sample n's packed input.  With a kernel boundary between every two layers and one
-            // stream that is harmless.  Inside the persistent launch it is not -- a workgroup's layers follow one another with no
-            // grid-wide order, and a workgroup that STARTS LATE (more tiles than CUs, or the chip shared with another ticket's
-            // kernels) found its packed input overwritten by an early workgroup's third layer -- and across the chains of one
-            // forward neither.  Rounds 3-4 recycled it: every full-chip launch won that race by a wide margin (all 256 workgroups
-            // start together, the input is read within the first ~80 us and overwritten after ~170), which is why it took round
-            // 5's bit-level harness to see it (tools/gpu/concurrent_ctx_dbg.py, chains_layers_dbg.py).
-        }
-
-        for (int b = 0; b < d.residual_blocks; ++b) {
-            const auto& bd = blocks_[b];
-            const bool se = bd.apply_se != 0;
-            const int last_act = se ? (int)kIdentity : act;
-            const int y = take();
-            int skip = x;  // buffer added back at the end of the block
-            bool se_done = false;  // the SE unit already ran inside the block's last convolution
-            if (bd.type == SAYURI_BLOCK_RESIDUAL) {
-                const int t0 = take();
-                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[x], bufs_[t0], nullptr, act)) return -1;
-                int fused = 1;
-                if (se) {
-                    fused = conv_se(cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)),
-                                    fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[t0], bufs_[y], bufs_[x], C, act);
-                    if (fused == 1)
-                        fused = conv_sx(cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)),
-                                        fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[t0], bufs_[y], bufs_[x], C, act);
-                    if (fused < 0) return -1;
-                    se_done = fused == 0;
-                }
-                if (fused == 1 &&
-                    conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t0], bufs_[y], se ? nullptr : bufs_[x], last_act))
-                    return -1;
-                give(t0);
-            } else if (bd.type == SAYURI_BLOCK_BOTTLENECK) {
-                const int t0 = take(), t1 = take();
-                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_PRE_BTL)), bufs_[x], bufs_[t0], nullptr, act)) return -1;
-                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[t0], bufs_[t1], nullptr, act)) return -1;
-                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t1], bufs_[t0], nullptr, act)) return -1;
-                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_POST_BTL)), bufs_[t0], bufs_[y], se ? nullptr : bufs_[x], last_act)) return -1;
-                give(t0); give(t1);
-            } else if (bd.type == SAYURI_BLOCK_NESTED_BOTTLENECK) {
-                const int r1 = take(), t0 = take(), t1 = take();
-                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_PRE_BTL)), bufs_[x], bufs_[r1], nullptr, act)) return -1;
-                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[r1], bufs_[t0], nullptr, act)) return -1;
-                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t0], bufs_[t1], bufs_[r1], act)) return -1;
-                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV3)), bufs_[t1], bufs_[t0], nullptr, act)) return -1;
-                if (conv("conv3x3_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV4)), bufs_[t0], bufs_[r1], bufs_[t1], act)) return -1;
-                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_POST_BTL)), bufs_[r1], bufs_[y], se ? nullptr : bufs_[x], last_act)) return -1;
-                give(r1); give(t0); give(t1);
-            } else {  // mixer: x' = act(dw(x)+b) + x is the new skip
-                const int s2 = take(), t1 = take();
-                if (depthwise("depthwise", cv(SAYURI_L_BLOCK(b, SAYURI_S_DW_CONV)), bufs_[x], bufs_[s2], bufs_[x], act)) return -1;
-                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV1)), bufs_[s2], bufs_[t1], nullptr, act)) return -1;
-                if (conv("conv1x1_tower", cv(SAYURI_L_BLOCK(b, SAYURI_S_CONV2)), bufs_[t1], bufs_[y], se ? nullptr : bufs_[s2], last_act)) return -1;
-                give(t1);
-                give(x);
-                x = s2;
-                skip = s2;
-            }
-            if (se && !se_done) {
-                if (se_unit(fc(SAYURI_L_BLOCK(b, SAYURI_S_SQUEEZE)), fc(SAYURI_L_BLOCK(b, SAYURI_S_EXCITE)), bufs_[y],
-                            bufs_[skip], C, csC, act, rg_n0_, range_ns()))
-                    return -1;
-            }
-            give(x);
-            x = y;
-        }
-
-        // heads
-        const int Cp = d.policy_head_channels, Cv = d.value_head_channels;
-        HeadParams h;
-        h.p_inter = fc(SAYURI_L_P_INTER_FC).dev();
-        h.pass_fc = fc(SAYURI_L_PASS_FC).dev();
-        h.v_inter = fc(SAYURI_L_V_INTER_FC).dev();
-        h.v_misc = fc(SAYURI_L_V_MISC).dev();
-        h.prob_w = cv(SAYURI_L_PROB_CONV).w32;
-        h.prob_b = cv(SAYURI_L_PROB_CONV).bias;
-        h.own_w = cv(SAYURI_L_V_OWNERSHIP).w32;
-        h.own_b = cv(SAYURI_L_V_OWNERSHIP).bias;
-        h.Cp = Cp; h.cs_p = round_up(Cp, 32); h.Cv = Cv; h.cs_v = round_up(Cv, 32);
-        h.prob_ch = d.probabilities_channels; h.act = act; h.board = board_;
-        h.prob = d_prob_; h.pass = zc_pass_ ? zc_pass_ : d_pass_; h.misc = zc_misc_ ? zc_misc_ : d_misc_; h.own = d_own_; h.perm = d_perm_;
-        if (head_img_ && heads_fused_enabled()) {
-            // both heads of a sample in one workgroup: trunk -> LDS -> stacked 1x1 convolution on the matrix cores -> pooling,
-            // FCs and the per-pixel planes (head_board.h)
-            HeadBoardParams hp;
-            hp.dbg = nullptr;
-#ifdef SAYURI_EXPERIMENTS
-            if (flags_.heads_dbg) {
-                if (!d_hdbg_ && dev_alloc(&d_hdbg_, 4 * 8)) return -1;
-                hp.dbg = d_hdbg_;
-            }
-#endif
-            hp.trunk = bufs_[x]; hp.w = head_img_; hp.w2 = head_img2_; hp.bias = head_bias_; hp.g = g; hp.cs = csC; hp.PT = head_pt_; hp.VT = head_vt_; hp.h = h;
-            hp.n0 = rg_n0_;
-            const auto fn = head_fn_;
-            {
-                const int ns = range_ns();
-                const double flops = 2.0 * range_px() * C * (Cp + Cv);
-                return timed("heads_fused", flops, range_px() * csC * 2, [&] {
-                    hipLaunchKernelGGL(fn, dim3(ns), dim3(512), kMaxLds, stream_, hp);
-                });
-            }
-        }
-        if (rg_ns_ >= 0) return fail("chained forward reached the separate head kernels");
-        int pb = take();
-        const int vb = take();
-        if (conv("conv1x1_head", cv(SAYURI_L_P_HD_CONV), bufs_[x], bufs_[pb], nullptr, act)) return -1;
-        if (d.policy_head_type == 1) {
-            const int p2 = take();
-            if (depthwise("depthwise", cv(SAYURI_L_P_DW_CONV), bufs_[pb], bufs_[p2], nullptr, act)) return -1;
-            if (conv("conv1x1_head", cv(SAYURI_L_P_PT_CONV), bufs_[p2], bufs_[pb], nullptr, act)) return -1;
-            give(p2);
-        }
-        if (conv("conv1x1_head", cv(SAYURI_L_V_HD_CONV), bufs_[x], bufs_[vb], nullptr, act)) return -1;
-        const int maxc = std::max(Cp, Cv);
-        const size_t smem = sizeof(float) * (7 * maxc + 512);
-        const T* pc = bufs_[pb];
-        const T* vc = bufs_[vb];
-        return timed("head_tail", 0, 0, [&] {
-            hipLaunchKernelGGL(head_tail_kernel<T>, dim3(2 * geom_.n), dim3(256), smem, stream_, pc, vc, g, h);
-        });
-    }
-
-    // -------------------------------------------------------------- the persistent tower launch (conv_tower.h)
-    // Consecutive board convolutions whose channel tile covers the layer are not launched one by one: conv() / conv_se()
-    // append them to run_, and the first launch of anything else (timed()) -- in practice the heads -- sends the whole run
-    // as ONE launch that walks a table of TowerLayer in device memory.  The table of a slot is re-uploaded only when its
-    // contents change (another batch geometry; the buffers and weights of a slot never move).
-    static constexpr int kTowerCap = 512;  // table elements per slot
-    struct TowerSlot {
-        TowerLayer* dev = nullptr;
-        TowerLayer* stage[2] = {nullptr, nullptr};  // pinned staging, alternating
-        hipEvent_t staged[2] = {nullptr, nullptr};   // the last copy out of stage[i]
-        int next_stage = 0;
-        std::vector<TowerLayer> cache;               // what dev holds
-    };
-    int tower_load() { return load_tower_module(&tower_mod_, tower_fn_); }
-    bool tower_ok(int kot) const { return tower_mod_ && !profiling_ && (kot == 256 || kot == 128); }
-    int tower_append(int kot, const BoardSeParams& sp, bool has_se, double flops, double bytes) {
-        if (!run_.empty() && (run_kot_ != kot || (int)run_.size() + table_used_ >= kTowerCap) && tower_flush()) return -1;
-        if (run_.empty()) { run_kot_ = kot; run_flops_ = run_bytes_ = 0; }
-        TowerLayer t;
-        std::memset(&t, 0, sizeof(t));
-        t.sp = sp;
-        t.has_se = has_se ? 1 : 0;
-        if (flags_.io_v2) {
-            // what the bodies never read (tile = workgroup id, the launch's grid is the batch): left out of the table, so that
-            // a batch of 250 positions finds the table of a batch of 256 in place and nothing is uploaded
-            ConvParams& c = t.sp.b.c;
-            c.num_pix_tiles = 0;
-            c.g.n_samples = 0;
-            c.g.total_pix = 0;
-        }
-        run_.push_back(t);
-        run_flops_ += flops;
-        run_bytes_ += bytes;
-        return 0;
-    }
-    int tower_flush() {
-        std::vector<TowerLayer> run;
-        run.swap(run_);  // timed() below must not see a pending run
-        TowerSlot& ts = tower_[cur_slot_];
-        if (!ts.dev) {
-            if (dev_alloc(&ts.dev, kTowerCap)) return -1;
-            for (int i = 0; i < 2; ++i) {
-                HIP_OK(hipHostMalloc((void**)&ts.stage[i], sizeof(TowerLayer) * kTowerCap, hipHostMallocDefault));
-                HIP_OK(hipEventCreateWithFlags(&ts.staged[i], hipEventDisableTiming));
-            }
-            ts.cache.assign(kTowerCap, TowerLayer{});
-        }
-        const int n = (int)run.size(), first = table_used_;
-        if (first + n > kTowerCap) return fail("tower table overflow");
-        if (flags_.tower_noepi_after >= 0 && tower_launches_++ >= flags_.tower_noepi_after)
-            for (auto& t : run)
-                if (t.sp.b.row_order == 1 && !t.has_se) t.sp.b.row_order = 3;  // MEASURING: no epilogue (tower_seam.py epi_hook)
-        for (int i = 0; i < n; ++i) {
-            run[i].self = ts.dev + first + i;
-            run[i].last = i + 1 == n ? 1 : 0;
-        }
-        // weight hand-over (conv_board.h, CHAIN main loop): a plain layer without residual leaves the LDS alone after its K
-        // loop, so its last K group can bring in the next layer's first weight group.  Needs the same weight geometry on
-        // both sides (the piece addresses are computed with this layer's strides) and an even number of 32-channel chunks
-        // (the last group then sits in ring slot 1 and slot 0 is free).
-        for (int i = 0; i + 1 < n && flags_.tower_chain; ++i) {
-            const ConvParams &a = run[i].sp.b.c, &b = run[i + 1].sp.b.c;
-            if (run[i].has_se || a.res || a.cin_s != b.cin_s || a.ko_pad != b.ko_pad || (a.cin_s / kChunk) % 2) continue;
-            run[i].sp.b.w_next = b.w;
-            run[i + 1].sp.b.w_ready = 1;
-        }
-        if (std::memcmp(run.data(), ts.cache.data() + first, sizeof(TowerLayer) * n) != 0) {
-            const int st = ts.next_stage;
-            ts.next_stage ^= 1;
-            HIP_OK(hipEventSynchronize(ts.staged[st]));  // the copy that last read this staging area (never recorded: returns at once)
-            std::memcpy(ts.stage[st], run.data(), sizeof(TowerLayer) * n);
-            HIP_OK(hipMemcpyAsync(ts.dev + first, ts.stage[st], sizeof(TowerLayer) * n, hipMemcpyHostToDevice, stream_));
-            ++table_uploads_;
-            HIP_OK(hipEventRecord(ts.staged[st], stream_));
-            std::memcpy(ts.cache.data() + first, run.data(), sizeof(TowerLayer) * n);
-        }
-        table_used_ += n;
-        const hipFunction_t fn = tower_fn_[run_kot_ == 256 ? 0 : 1];
-        const TowerLayer* arg = ts.dev + first;
-        const int grid = board_plan_.ntiles;
-        hipError_t lrc = hipSuccess;
-        static const bool sync_dbg = std::getenv("SAYURI_TOWER_SYNC") != nullptr;  // debugging aid: nothing overlaps the tower launch
-        if (sync_dbg) HIP_OK(hipStreamSynchronize(stream_));
-        const int rc = timed("tower_run", run_flops_, run_bytes_, [&] {
-            void* params[] = {(void*)&arg};
-            lrc = hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, 0, stream_, params, nullptr);
-        });
-        if (sync_dbg && lrc == hipSuccess) HIP_OK(hipStreamSynchronize(stream_));
-        if (lrc != hipSuccess) return fail(std::string("hipModuleLaunchKernel(conv_tower_kernel): ") + hipGetErrorString(lrc));
-        return rc;
-    }
-    // conv_board_sx.h (SE units of layers split over channel tiles)
-    int sx_kts_ = 0;                      // channel tiles per layer (0: the network has no such unit)
-    unsigned* sx_err_host_ = nullptr;     // host-visible word a workgroup sets when its wait for the siblings ran out
-    unsigned* sx_err_dev_ = nullptr;
-    unsigned sx_epoch0_ = 0;              // tags of the current forward: sx_epoch0_ + 1 + index of the SE layer
-    int sx_idx_ = 0;
-    int sx_check() {
-        if (sx_err_host_ && *(volatile unsigned*)sx_err_host_) {
-            const unsigned e = *(volatile unsigned*)sx_err_host_;
-            *(volatile unsigned*)sx_err_host_ = 0;
-            return fail("SE exchange between the channel tiles of a board tile timed out (epoch " + std::to_string(e) +
-                        "): the results of this forward are invalid; SAYURI_SE_SPLIT=0 runs the unit as separate kernels");
-        }
-        return 0;
-    }
-    EngineFlags flags_;
-    hipModule_t tower_mod_ = nullptr;
-    hipFunction_t tower_fn_[2] = {nullptr, nullptr};
-    TowerSlot tower_[2];
-    std::vector<TowerLayer> run_;
-    int run_kot_ = 0, table_used_ = 0;
-    long tower_launches_ = 0;
-    int table_uploads_ = 0;
-    // SAYURI_HIP_FWDSTAT: device time of the forwards sent through submit(), by batch-size class
-    bool fwdstat_ = std::getenv("SAYURI_HIP_FWDSTAT") != nullptr;
-    hipEvent_t fs_ev_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    double fs_d2h_ms_ = 0, fs_d2h_max_ = 0;
-    long fs_d2h_slow_ = 0;
-    float *zc_pass_ = nullptr, *zc_misc_ = nullptr;  // this submit's pass / misc go straight to these (pinned host) buffers
-    bool fs_pending_[2] = {false, false};
-    int fs_n_[2] = {0, 0};
-    double fs_ms_[3] = {0, 0, 0};
-    long fs_cnt_[3] = {0, 0, 0}, fs_uploads_ = 0;
-    double run_flops_ = 0, run_bytes_ = 0;
-
-    int device_;
-    sayuri_hip_netdesc desc_;
-    std::vector<sayuri_hip_blockdesc> blocks_;
-    int max_batch_, board_;
-    int cs_max_ = 32, slot_pix_ = 0;
-    std::map<int, ConvLayerDev> convs_;
-    std::map<int, FcLayerDev> fcs_;
-    bool finalized_ = false, have_batch_ = false, profiling_ = false;
-    hipStream_t stream_ = nullptr, h2d_stream_ = nullptr, d2h_stream_ = nullptr;
-    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
-    hipEvent_t h2d_done_[2] = {nullptr, nullptr}, fwd_done_[2] = {nullptr, nullptr};
-    // device-side batch i/o, one set per ticket; the d_* members below alias the slot the current forward uses
-    struct IoSlot {
-        float *planes = nullptr, *prob = nullptr, *pass = nullptr, *misc = nullptr, *own = nullptr;
-        unsigned* packed = nullptr;  // packed records of the batch (allocated on first use)
-        const unsigned* packed_src = nullptr;  // non-null: the batch's records are read where the caller has them (pinned host memory)
-        int packed_binary = 0;       // > 0: the slot's current batch came as packed records with this many bit planes
-        int *off = nullptr, *bsz = nullptr, *perm = nullptr;
-        T* bufs[kNumBufs] = {};
-        float *gate = nullptr, *separt = nullptr;
-        unsigned long long* sx_xchg = nullptr;
-        unsigned sx_epoch = 0;  // the last tag used in sx_xchg
-        std::map<int, TileTabs> tabs;   // index tables of the geometry this slot last ran (keyed by tile variant)
-        BoardTabs board;
-        std::vector<int> tabs_bsz;
-        bool tabs_single = false;  // tabs_bsz is one board size with one sample per tile
-        int tabs_n = -1;           // batch size the across-sample tables (tabs) were last built for
-    };
-    IoSlot io_[2];
-    hipStream_t compute_[2] = {nullptr, nullptr};
-    bool inorder_ = false;  // a ticket's copies on the ticket's compute stream (init(), submit())
-    int cur_slot_ = 0;
-    void select_slot(int t) {
-        IoSlot& io = io_[t];
-        cur_slot_ = t;
-        d_planes_ = io.planes; d_off_ = io.off; d_bsz_ = io.bsz; d_perm_ = io.perm;
-        d_prob_ = io.prob; d_pass_ = io.pass; d_misc_ = io.misc; d_own_ = io.own;
-        for (int i = 0; i < kNumBufs; ++i) bufs_[i] = io.bufs[i];
-        d_gate_ = io.gate; d_separt_ = io.separt;
-        if (compute_[t]) stream_ = compute_[t];
-    }
-    std::vector<void*> allocs_;
-    size_t dev_bytes_ = 0;
-    T* bufs_[kNumBufs] = {};
-    bool busy_[kNumBufs] = {};
-    float *d_planes_ = nullptr, *d_gate_ = nullptr, *d_separt_ = nullptr, *d_prob_ = nullptr, *d_pass_ = nullptr, *d_misc_ = nullptr,
-          *d_own_ = nullptr;
-    int *d_off_ = nullptr, *d_bsz_ = nullptr, *d_perm_ = nullptr;
-    std::vector<int> perm_;  // device sample -> caller's slot (enqueue_inputs)
-    float* d_zeros_ = nullptr;
-    int* h_geom_ = nullptr;  // pinned 2-slot ring: [slot][off(max_batch+1) | bsz(max_batch) | perm(max_batch)]
-    int geom_slot_ = 0, next_ticket_ = 0;
-    hipEvent_t tick_ev_[2] = {nullptr, nullptr};
-    HostGeom geom_;
-    std::vector<int> prev_bsz_;
-    std::map<int, GldsChoice> glds_cache_;
-    BoardPlan board_plan_;
-    HeadFn head_fn_ = nullptr;
-    void* head_img2_ = nullptr;  // per-pixel weights (policy planes, ownership) as an MFMA image
-    void* head_img_ = nullptr;   // stacked head-convolution image (head_board.h); null = separate head kernels
-    float* head_bias_ = nullptr;
-    int head_pt_ = 0, head_vt_ = 0;
-    unsigned long long* d_hdbg_ = nullptr;  // SAYURI_HEADS_DBG timeline of head_board_kernel
-    unsigned long long* d_dbg_ = nullptr;  // SAYURI_BOARD_DBG timeline of one tower convolution
-    unsigned long long* d_sxdbg_ = nullptr;  // SAYURI_SX_DBG timeline of one split SE convolution
-    int dbg_call_ = 0, dbg_se_call_ = 0;
-    bool dbg_is_se_ = false;
-    bool board_plan_valid_ = false;
-    std::map<int, TileChoice> tile_cache_;
-    std::map<std::string, Stat> stats_;
-    // light per-launch timing of one kernel class inside time_runs()
-    bool light_ = false;
-    std::string light_name_;
-    int light_group_ = 1;            // launches of the marked class bracketed by one event pair
-    std::vector<int> group_counts_;  // launches inside each pair of the last time_runs
-    bool group_open_ = false;
-    std::vector<hipEvent_t> pool_;
-    size_t pool_used_ = 0;
-    double light_flops_ = 0, light_bytes_ = 0;
-    Stat timed_stat_;
-
-};
-
-}  // namespace sayuri
+#include "engine_plan.h"
+#include "engine_graph.h"
 
 // ====================================================================== C ABI
 using namespace sayuri;
@@ -2461,583 +162,4 @@ void sayuri_hip_destroy(sayuri_hip_ctx* ctx) { delete ctx; }
 
 }
 
-// ---------------------------------------------------------------------- layer-level test tap
-// Drives ONE convolution kernel directly (host-side layout conversion in, out) so the parity
-// tests can localise a defect to a layer kind.
-
-namespace sayuri {
-
-template <typename T>
-static int test_conv_impl(int device, int n, const int* board_sizes, int max_board, int cin, int cout, int k,
-                          int depthwise, int act, int post_residual, const float* x, const float* w, const float* bias,
-                          const float* res, float* y) {
-    HIP_OK(hipSetDevice(device));
-    enable_big_lds<T>();
-    HostGeom hg;
-    hg.n = n;
-    hg.bsz.assign(board_sizes, board_sizes + n);
-    hg.off.resize(n + 1);
-    hg.off[0] = 0;
-    for (int i = 0; i < n; ++i) {
-        if (hg.bsz[i] < 2 || hg.bsz[i] > max_board) return fail("test_conv: bad board size");
-        hg.off[i + 1] = hg.off[i] + hg.bsz[i] * hg.bsz[i];
-    }
-    hg.total = hg.off[n];
-    const int slot = max_board * max_board;
-    const int cin_s = round_up(depthwise ? cout : cin, 32), cout_s = round_up(cout, 32);
-    std::vector<void*> allocs;
-    auto cleanup = [&] { for (void* p : allocs) (void)hipFree(p); };
-    auto dalloc = [&](size_t bytes) -> void* {
-        void* p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) return nullptr;
-        (void)hipMemset(p, 0, std::max<size_t>(bytes, 256));
-        allocs.push_back(p);
-        return p;
-    };
-    // host NCHW (compact per sample) -> compact NHWC
-    auto to_nhwc = [&](const float* src, int C, int cs) {
-        std::vector<T> h((size_t)n * slot * cs, (T)0.f);
-        size_t so = 0;
-        for (int i = 0; i < n; ++i) {
-            const int S = hg.bsz[i] * hg.bsz[i];
-            for (int c = 0; c < C; ++c)
-                for (int p = 0; p < S; ++p) h[((size_t)i * slot + p) * cs + c] = (T)src[so + (size_t)c * S + p];
-            so += (size_t)C * S;
-        }
-        return h;
-    };
-    const int xin_c = depthwise ? cout : cin;
-    std::vector<T> hx = to_nhwc(x, xin_c, cin_s);
-    T* dx = (T*)dalloc(hx.size() * sizeof(T) + kZeroPrefix);
-    if (dx) dx += kZeroPrefix / sizeof(T);  // conv_board.h reads its halo cells from a zero prefix in front of the activations
-    T* dy = (T*)dalloc((size_t)n * slot * cout_s * sizeof(T));
-    T* dres = nullptr;
-    if (!dx || !dy) { cleanup(); return fail("test_conv: hipMalloc failed"); }
-    HIP_OK(hipMemcpy(dx, hx.data(), hx.size() * sizeof(T), hipMemcpyHostToDevice));
-    if (res) {
-        std::vector<T> hr = to_nhwc(res, cout, cout_s);
-        dres = (T*)dalloc(hr.size() * sizeof(T));
-        if (!dres) { cleanup(); return fail("test_conv: hipMalloc failed"); }
-        HIP_OK(hipMemcpy(dres, hr.data(), hr.size() * sizeof(T), hipMemcpyHostToDevice));
-    }
-    int* d_off = (int*)dalloc(sizeof(int) * (n + 1));
-    int* d_bsz = (int*)dalloc(sizeof(int) * n);
-    HIP_OK(hipMemcpy(d_off, hg.off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_bsz, hg.bsz.data(), sizeof(int) * n, hipMemcpyHostToDevice));
-    const BatchGeom g{d_off, d_bsz, n, hg.total, slot};
-
-    if (depthwise) {
-        g_test_conv_kind = 3;
-        const int kk = k * k;
-        std::vector<float> wt((size_t)kk * cout_s, 0.f), b(cout_s, 0.f);
-        for (int c = 0; c < cout; ++c) {
-            for (int t = 0; t < kk; ++t) wt[(size_t)t * cout_s + c] = w[(size_t)c * kk + t];
-            b[c] = bias ? bias[c] : 0.f;
-        }
-        float* dw = (float*)dalloc(wt.size() * 4);
-        float* db = (float*)dalloc(b.size() * 4);
-        HIP_OK(hipMemcpy(dw, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
-        const int EPP = ElemTraits<T>::kPieceElems;
-        const size_t total = (size_t)hg.total * (cout_s / EPP);
-        hipLaunchKernelGGL(depthwise_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, (const T*)dx,
-                           post_residual ? (const T*)dres : (const T*)nullptr, dy, (const float*)dw, (const float*)db, g,
-                           cout, cout_s, k, act);
-    } else {
-        const int wmt = pick_wmt(cout_s, sizeof(T) == 2);
-        const int kot = wmt * 32, ko_pad = round_up(cout_s, kot), taps = k * k, nch = cin_s / 32;
-        std::vector<T> img((size_t)taps * nch * 4 * ko_pad * 8, (T)0.f);
-        for (int t = 0; t < taps; ++t)
-            for (int ch = 0; ch < nch; ++ch)
-                for (int kg = 0; kg < 4; ++kg)
-                    for (int ko = 0; ko < cout; ++ko)
-                        for (int e = 0; e < 8; ++e) {
-                            const int c = ch * 32 + kg * 8 + e;
-                            if (c >= cin) continue;
-                            img[((((size_t)t * nch + ch) * 4 + kg) * ko_pad + ko) * 8 + e] =
-                                (T)w[((size_t)ko * cin + c) * taps + t];
-                        }
-        std::vector<float> b(ko_pad, 0.f);
-        if (bias) std::copy(bias, bias + cout, b.begin());
-        T* dw = (T*)dalloc(img.size() * sizeof(T));
-        float* db = (float*)dalloc(b.size() * 4);
-        HIP_OK(hipMemcpy(dw, img.data(), img.size() * sizeof(T), hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
-        int g_ntiles = 0;
-        const GldsEntry* ge = nullptr;
-        bool board_done = false;
-        if (sizeof(T) == 2 && k == 3) {
-            enable_big_lds_glds();
-            const ConvOverride cov = EngineFlags::from_env().conv;
-            const BoardPlan plan = board_plan(hg, cov);
-            int kot_tiles = 0;
-            const BoardEntry* be = plan.fill >= cov.board_min_fill ? pick_board(plan, ko_pad, &kot_tiles) : nullptr;
-            if (be) {
-                int* tsrc = (int*)dalloc(sizeof(int) * (size_t)plan.ntiles * plan.npos);
-                int2* tpix = (int2*)dalloc(sizeof(int2) * (size_t)plan.ntiles * kBoardPT);
-                int* tcols = (int*)dalloc(sizeof(int) * (size_t)plan.ntiles);
-                if (!tsrc || !tpix || !tcols) { cleanup(); return fail("test_conv: hipMalloc failed"); }
-                hipLaunchKernelGGL(board_setup_kernel, dim3(plan.ntiles), dim3(256), 0, 0, g, plan.npos, tsrc, tpix, tcols);
-                BoardParams bp;
-                std::memset(&bp, 0, sizeof(bp));
-                bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos; bp.dbg = nullptr;
-                bp.uniform_info = plan.uniform_info;
-                bp.arith = (plan.single && plan.uniform_info >= 0) ? 1 : 0;
-                ConvParams& p = bp.c;
-                p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
-                p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;
-                p.num_pix_tiles = plan.ntiles;
-                hipLaunchKernelGGL(be->fn, dim3(plan.ntiles * kot_tiles), dim3(512), be->lds(plan.npos), 0, bp);
-                HIP_OK(hipGetLastError());
-                HIP_OK(hipDeviceSynchronize());
-                board_done = true;
-                g_test_conv_kind = 2;
-            }
-        }
-        if (sizeof(T) == 2 && k == 3 && !board_done) {
-            enable_big_lds_glds();
-            ge = pick_glds(hg, ko_pad, &g_ntiles, EngineFlags::from_env().conv);
-        }
-        if (ge) {
-            float* dz = (float*)dalloc(256);
-            int* tsrc = (int*)dalloc(sizeof(int) * (size_t)g_ntiles * ge->npos);
-            int2* tpix = (int2*)dalloc(sizeof(int2) * (size_t)g_ntiles * ge->pt);
-            if (!dz || !tsrc || !tpix) { cleanup(); return fail("test_conv: hipMalloc failed"); }
-            hipLaunchKernelGGL(ge->setup, dim3(g_ntiles), dim3(256), 0, 0, g, tsrc, tpix);
-            GldsParams gp;
-            gp.tab_src = tsrc;
-            gp.tab_pix = tpix;
-            ConvParams& p = gp.c;
-            p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
-            p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.npos = 0;
-            p.num_pix_tiles = g_ntiles;
-            gp.zeros = dz;
-            hipLaunchKernelGGL(ge->fn, dim3(g_ntiles * (ko_pad / (ge->wmt * 32))), dim3(512), ge->lds, 0, gp);
-            g_test_conv_kind = 1;
-            HIP_OK(hipGetLastError());
-            HIP_OK(hipDeviceSynchronize());
-        }
-        const typename ConvKernelTable<T>::Entry* best = nullptr;
-        int best_npos = 0;
-        for (const auto& e : ConvKernelTable<T>::entries()) {
-            if (ge || board_done) break;
-            if (e.wmt != wmt) continue;
-            int npos, nsub;
-            hg.tile_bounds(64 * e.wnt, &npos, &nsub);
-            if (npos > e.npos_cap || nsub > kMaxSub || e.lds(npos) > kMaxLds) continue;
-            if (!best || e.wnt > best->wnt) { best = &e; best_npos = npos; }
-        }
-        if (!best && !ge && !board_done) { cleanup(); return fail("test_conv: no tile configuration fits"); }
-        if (best) {
-        g_test_conv_kind = 0;
-        ConvParams p;
-        p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = g;
-        p.cin_s = cin_s; p.cout_s = cout_s; p.ko_pad = ko_pad; p.taps = taps; p.act = act;
-        p.npos = best_npos;
-        const int PT = 64 * best->wnt;
-        p.num_pix_tiles = (hg.total + PT - 1) / PT;
-        hipLaunchKernelGGL(best->fn, dim3(p.num_pix_tiles * (ko_pad / kot)), dim3(512), best->lds(best_npos), 0, p);
-        }
-    }
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipDeviceSynchronize());
-    std::vector<T> hy((size_t)n * slot * cout_s);
-    HIP_OK(hipMemcpy(hy.data(), dy, hy.size() * sizeof(T), hipMemcpyDeviceToHost));
-    size_t so = 0;
-    for (int i = 0; i < n; ++i) {
-        const int S = hg.bsz[i] * hg.bsz[i];
-        for (int c = 0; c < cout; ++c)
-            for (int pp = 0; pp < S; ++pp) y[so + (size_t)c * S + pp] = (float)hy[((size_t)i * slot + pp) * cout_s + c];
-        so += (size_t)cout * S;
-    }
-    cleanup();
-    return 0;
-}
-
-}  // namespace sayuri
-
-// ---------------------------------------------------------------------- small-op test taps
-namespace sayuri {
-
-struct TestGeom {
-    HostGeom hg;
-    int slot = 0;
-    int* d_off = nullptr;
-    int* d_bsz = nullptr;
-    BatchGeom g{};
-};
-
-class TestArena {  // device allocations of one tap call, freed at scope exit
-public:
-    ~TestArena() { for (void* p : ptrs_) (void)hipFree(p); }
-    void* alloc(size_t bytes) {
-        void* p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) return nullptr;
-        (void)hipMemset(p, 0, std::max<size_t>(bytes, 256));
-        ptrs_.push_back(p);
-        return p;
-    }
-    template <typename U> U* upload(const std::vector<U>& h) {
-        U* d = (U*)alloc(h.size() * sizeof(U));
-        if (d && hipMemcpy(d, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        return d;
-    }
-private:
-    std::vector<void*> ptrs_;
-};
-
-static int make_test_geom(TestArena& A, int n, const int* board_sizes, int max_board, TestGeom* tg) {
-    tg->hg.n = n;
-    tg->hg.bsz.assign(board_sizes, board_sizes + n);
-    tg->hg.off.assign(n + 1, 0);
-    for (int i = 0; i < n; ++i) {
-        if (tg->hg.bsz[i] < 2 || tg->hg.bsz[i] > max_board) return fail("test tap: bad board size");
-        tg->hg.off[i + 1] = tg->hg.off[i] + tg->hg.bsz[i] * tg->hg.bsz[i];
-    }
-    tg->hg.total = tg->hg.off[n];
-    tg->slot = max_board * max_board;
-    tg->d_off = A.upload(tg->hg.off);
-    tg->d_bsz = A.upload(tg->hg.bsz);
-    if (!tg->d_off || !tg->d_bsz) return fail("test tap: hipMalloc failed");
-    tg->g = BatchGeom{tg->d_off, tg->d_bsz, n, tg->hg.total, tg->slot};
-    return 0;
-}
-// host NCHW (compact per sample) <-> compact NHWC
-template <typename T> static std::vector<T> nchw_to_nhwc(const TestGeom& tg, const float* src, int C, int cs) {
-    std::vector<T> h((size_t)tg.hg.n * tg.slot * cs, (T)0.f);
-    size_t so = 0;
-    for (int i = 0; i < tg.hg.n; ++i) {
-        const int S = tg.hg.bsz[i] * tg.hg.bsz[i];
-        for (int c = 0; c < C; ++c)
-            for (int p = 0; p < S; ++p) h[((size_t)i * tg.slot + p) * cs + c] = (T)src[so + (size_t)c * S + p];
-        so += (size_t)C * S;
-    }
-    return h;
-}
-static std::vector<float> fc_transposed(const float* w, int in, int out) {  // [out][in] -> [in][out]
-    std::vector<float> t((size_t)in * out);
-    for (int o = 0; o < out; ++o)
-        for (int i = 0; i < in; ++i) t[(size_t)i * out + o] = w[(size_t)o * in + i];
-    return t;
-}
-
-template <typename T>
-static int test_se_unit_impl(int device, int n, const int* board_sizes, int max_board, int C, int se, int act, const float* x,
-                             const float* res, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
-                             float* gate_out) {
-    HIP_OK(hipSetDevice(device));
-    TestArena A;
-    TestGeom tg;
-    if (make_test_geom(A, n, board_sizes, max_board, &tg)) return -1;
-    const int cs = round_up(C, 32);
-    constexpr int EPP = ElemTraits<T>::kPieceElems;
-    if (cs / EPP > 256) return fail("test_se_unit: too many channels");
-    T* dx = A.upload(nchw_to_nhwc<T>(tg, x, C, cs));
-    T* dres = res ? A.upload(nchw_to_nhwc<T>(tg, res, C, cs)) : nullptr;
-    float* dw1 = A.upload(fc_transposed(w1, 3 * C, se));
-    float* dw2 = A.upload(fc_transposed(w2, se, 2 * C));
-    float* db1 = A.upload(std::vector<float>(b1, b1 + se));
-    float* db2 = A.upload(std::vector<float>(b2, b2 + 2 * C));
-    float* separt = (float*)A.alloc(sizeof(float) * (size_t)n * kSeSplit * 2 * cs);
-    float* gate = (float*)A.alloc(sizeof(float) * (size_t)n * 2 * cs);
-    if (!dx || (res && !dres) || !dw1 || !dw2 || !db1 || !db2 || !separt || !gate) return fail("test_se_unit: hipMalloc failed");
-    const FcDev sq{dw1, db1, 3 * C, se}, ex{dw2, db2, se, 2 * C};
-    hipLaunchKernelGGL(se_pool_kernel<T>, dim3(n * kSeSplit), dim3(256), 0, 0, (const T*)dx, separt, tg.g, cs);
-    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(kSeFcThreads), sizeof(float) * (3 * C + se + kSeFcThreads), 0, (const float*)separt, gate, tg.g, C, cs, sq,
-                       ex, act);
-    const int ppr = cs / EPP;
-    const dim3 grid((tg.slot * ppr + 256 * kScaleUnroll - 1) / (256 * kScaleUnroll), n);
-    hipLaunchKernelGGL(se_scale_kernel<T>, grid, dim3(256), 0, 0, (const T*)dx, (const T*)dres, dx, (const float*)gate, tg.g, C, cs, act);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipDeviceSynchronize());
-    std::vector<T> hy((size_t)n * tg.slot * cs);
-    HIP_OK(hipMemcpy(hy.data(), dx, hy.size() * sizeof(T), hipMemcpyDeviceToHost));
-    size_t so = 0;
-    for (int i = 0; i < n; ++i) {
-        const int S = tg.hg.bsz[i] * tg.hg.bsz[i];
-        for (int c = 0; c < C; ++c)
-            for (int pp = 0; pp < S; ++pp) y[so + (size_t)c * S + pp] = (float)hy[((size_t)i * tg.slot + pp) * cs + c];
-        so += (size_t)C * S;
-    }
-    if (gate_out) {
-        std::vector<float> hg((size_t)n * 2 * cs);
-        HIP_OK(hipMemcpy(hg.data(), gate, hg.size() * 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i)
-            for (int c = 0; c < C; ++c) {
-                gate_out[(size_t)i * 2 * C + c] = hg[(size_t)i * 2 * cs + c];
-                gate_out[(size_t)i * 2 * C + C + c] = hg[(size_t)i * 2 * cs + cs + c];
-            }
-    }
-    return 0;
-}
-
-template <typename T>
-static int test_head_tail_impl(int device, int n, const int* board_sizes, int max_board, int Cp, int Cv, int prob_ch, int pass_outs,
-                               int misc_outs, int act, const float* pconv, const float* vconv, const float* const* w, float* prob,
-                               float* pass, float* misc, float* own) {
-    // w: p_inter_w, p_inter_b, pass_w, pass_b, v_inter_w, v_inter_b, v_misc_w, v_misc_b, prob_w, prob_b, own_w, own_b
-    HIP_OK(hipSetDevice(device));
-    TestArena A;
-    TestGeom tg;
-    if (make_test_geom(A, n, board_sizes, max_board, &tg)) return -1;
-    if (prob_ch > 8) return fail("test_head_tail: too many policy planes");
-    const int cs_p = round_up(Cp, 32), cs_v = round_up(Cv, 32), B2 = max_board * max_board;
-    T* dp = A.upload(nchw_to_nhwc<T>(tg, pconv, Cp, cs_p));
-    T* dv = A.upload(nchw_to_nhwc<T>(tg, vconv, Cv, cs_v));
-    HeadParams h;
-    float* d_pi = A.upload(fc_transposed(w[0], 3 * Cp, Cp));
-    float* d_pib = A.upload(std::vector<float>(w[1], w[1] + Cp));
-    float* d_pw = A.upload(fc_transposed(w[2], Cp, pass_outs));
-    float* d_pwb = A.upload(std::vector<float>(w[3], w[3] + pass_outs));
-    float* d_vi = A.upload(fc_transposed(w[4], 3 * Cv, 3 * Cv));
-    float* d_vib = A.upload(std::vector<float>(w[5], w[5] + 3 * Cv));
-    float* d_vm = A.upload(fc_transposed(w[6], 3 * Cv, misc_outs));
-    float* d_vmb = A.upload(std::vector<float>(w[7], w[7] + misc_outs));
-    float* d_prw = A.upload(std::vector<float>(w[8], w[8] + (size_t)prob_ch * Cp));
-    float* d_prb = A.upload(std::vector<float>(w[9], w[9] + prob_ch));
-    float* d_ow = A.upload(std::vector<float>(w[10], w[10] + Cv));
-    float* d_ob = A.upload(std::vector<float>(w[11], w[11] + 1));
-    float* d_prob = (float*)A.alloc(sizeof(float) * (size_t)n * prob_ch * B2);
-    float* d_pass = (float*)A.alloc(sizeof(float) * (size_t)n * pass_outs);
-    float* d_misc = (float*)A.alloc(sizeof(float) * (size_t)n * misc_outs);
-    float* d_own = (float*)A.alloc(sizeof(float) * (size_t)n * B2);
-    if (!dp || !dv || !d_pi || !d_pib || !d_pw || !d_pwb || !d_vi || !d_vib || !d_vm || !d_vmb || !d_prw || !d_prb || !d_ow || !d_ob ||
-        !d_prob || !d_pass || !d_misc || !d_own)
-        return fail("test_head_tail: hipMalloc failed");
-    h.p_inter = FcDev{d_pi, d_pib, 3 * Cp, Cp};
-    h.pass_fc = FcDev{d_pw, d_pwb, Cp, pass_outs};
-    h.v_inter = FcDev{d_vi, d_vib, 3 * Cv, 3 * Cv};
-    h.v_misc = FcDev{d_vm, d_vmb, 3 * Cv, misc_outs};
-    h.prob_w = d_prw; h.prob_b = d_prb; h.own_w = d_ow; h.own_b = d_ob;
-    h.Cp = Cp; h.cs_p = cs_p; h.Cv = Cv; h.cs_v = cs_v; h.prob_ch = prob_ch; h.act = act; h.board = max_board;
-    h.prob = d_prob; h.pass = d_pass; h.misc = d_misc; h.own = d_own; h.perm = nullptr;
-    const int maxc = std::max(Cp, Cv);
-    hipLaunchKernelGGL(head_tail_kernel<T>, dim3(2 * n), dim3(256), sizeof(float) * (7 * maxc + 512), 0, (const T*)dp, (const T*)dv, tg.g, h);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpy(prob, d_prob, sizeof(float) * (size_t)n * prob_ch * B2, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(pass, d_pass, sizeof(float) * (size_t)n * pass_outs, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(misc, d_misc, sizeof(float) * (size_t)n * misc_outs, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(own, d_own, sizeof(float) * (size_t)n * B2, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-// The convolution with the SE unit inside it (conv_board_se_kernel, or the same stage inside the persistent tower kernel
-// when via_tower != 0): C -> C 3x3 convolution + bias, then the unit's pool -> FC -> FC -> act(sigmoid(g) x + b + res).
-// Returns 1 when the fused kernel does not apply to this batch (several samples per tile, channel tile not 128 / 256).
-static int test_conv_se_impl(int device, int n, const int* board_sizes, int max_board, int C, int se, int act, int via_tower,
-                             const float* x, const float* w, const float* bias, const float* res, const float* w1, const float* b1,
-                             const float* w2, const float* b2, float* y) {
-    typedef f16 T;
-    HIP_OK(hipSetDevice(device));
-    enable_big_lds_glds();
-    TestArena A;
-    TestGeom tg;
-    if (make_test_geom(A, n, board_sizes, max_board, &tg)) return -1;
-    const int cs = round_up(C, 32), wmt = pick_wmt(cs, true), ko_pad = round_up(cs, wmt * 32);
-    const BoardPlan plan = board_plan(tg.hg, ConvOverride{});
-    const BoardEntry* be = nullptr;
-    if (plan.ok)
-        for (const auto& e : kBoardEntries)
-            if (e.fn_se && e.kot == ko_pad && e.lds(plan.npos) <= kMaxLds) be = &e;
-    if (!be || !plan.single || C > be->kot) return 1;
-    std::vector<f16> img1;
-    std::vector<unsigned char> img2;
-    int w1_bytes = 0, w2_bytes = 0;
-    const bool staged = make_se_images(C, se, max_board, w1, b1, w2, b2, &img1, &img2, &w1_bytes, &w2_bytes);
-    if (!staged && (se % 4 || se > 512 || (2 * C) % 4 || 512 % (se / 4) || 512 % (2 * C / 4))) return 1;
-    // activations (with the zero prefix the board kernels read their halo cells from), weights image, tables
-    std::vector<T> hx = nchw_to_nhwc<T>(tg, x, C, cs);
-    T* dx = (T*)A.alloc(hx.size() * sizeof(T) + kZeroPrefix);
-    if (!dx) return fail("test_conv_se: hipMalloc failed");
-    dx += kZeroPrefix / sizeof(T);
-    HIP_OK(hipMemcpy(dx, hx.data(), hx.size() * sizeof(T), hipMemcpyHostToDevice));
-    T* dres = res ? A.upload(nchw_to_nhwc<T>(tg, res, C, cs)) : nullptr;
-    T* dy = (T*)A.alloc((size_t)n * tg.slot * cs * sizeof(T));
-    const int nch = cs / 32;
-    std::vector<T> img((size_t)9 * nch * 4 * ko_pad * 8, (T)0.f);
-    for (int t = 0; t < 9; ++t)
-        for (int ko = 0; ko < C; ++ko)
-            for (int c = 0; c < C; ++c)
-                img[((((size_t)t * nch + c / 32) * 4 + (c % 32) / 8) * ko_pad + ko) * 8 + c % 8] = (T)w[((size_t)ko * C + c) * 9 + t];
-    std::vector<float> hb(ko_pad, 0.f);
-    if (bias) std::copy(bias, bias + C, hb.begin());
-    // through the tower a Mish layer with computed table entries takes the generated epilogue: weights and bias in
-    // board_row_channel order (Engine::board_row_order_ok)
-    const bool row_order = via_tower && board_uses_row_order(be->kot) && (act == kMish || act == kReLU || act == kIdentity) && plan.single && plan.uniform_info >= 0 && cs == be->kot &&
-                           !EngineFlags::off("SAYURI_TOWER_GEN_EPI");
-    if (row_order) {
-        std::vector<float> hbb(ko_pad);
-        for (int r = 0; r < ko_pad; ++r) hbb[r] = hb[board_row_channel(r)];
-        hb.swap(hbb);
-    }
-    T* dw = A.upload(row_order ? board_row_order(img, ko_pad) : img);
-    float* db = A.upload(hb);
-    float* dw1 = A.upload(fc_transposed(w1, 3 * C, se));
-    float* dw2 = A.upload(fc_transposed(w2, se, 2 * C));
-    float* db1 = A.upload(std::vector<float>(b1, b1 + se));
-    float* db2 = A.upload(std::vector<float>(b2, b2 + 2 * C));
-    f16* d1 = staged ? A.upload(img1) : nullptr;
-    unsigned char* d2 = staged ? A.upload(img2) : nullptr;
-    int* tsrc = (int*)A.alloc(sizeof(int) * (size_t)plan.ntiles * plan.npos);
-    int2* tpix = (int2*)A.alloc(sizeof(int2) * (size_t)plan.ntiles * kBoardPT);
-    int* tcols = (int*)A.alloc(sizeof(int) * (size_t)plan.ntiles);
-    if ((res && !dres) || !dy || !dw || !db || !dw1 || !dw2 || !db1 || !db2 || (staged && (!d1 || !d2)) || !tsrc || !tpix || !tcols)
-        return fail("test_conv_se: hipMalloc failed");
-    hipLaunchKernelGGL(board_setup_kernel, dim3(plan.ntiles), dim3(256), 0, 0, tg.g, plan.npos, tsrc, tpix, tcols);
-    BoardSeParams sp;
-    std::memset(&sp, 0, sizeof(sp));
-    BoardParams& bp = sp.b;
-    bp.tab_src = tsrc; bp.tab_pix = tpix; bp.tab_cols = tcols; bp.npos = plan.npos;
-    bp.uniform_info = plan.uniform_info;
-    bp.arith = (plan.single && plan.uniform_info >= 0) ? 1 : 0;
-    bp.row_order = row_order ? 1 : 0;
-    ConvParams& p = bp.c;
-    p.in = dx; p.w = dw; p.bias = db; p.res = dres; p.out = dy; p.g = tg.g;
-    p.cin_s = cs; p.cout_s = cs; p.ko_pad = ko_pad; p.taps = 9; p.act = act; p.num_pix_tiles = plan.ntiles;
-    sp.squeeze = FcDev{dw1, db1, 3 * C, se};
-    sp.excite = FcDev{dw2, db2, se, 2 * C};
-    sp.C = C;
-    sp.w1h = d1; sp.w2h = d2; sp.w1_bytes = w1_bytes; sp.w2_bytes = w2_bytes;
-    hipModule_t mod = nullptr;
-    if (via_tower) {
-        hipFunction_t fn[2] = {nullptr, nullptr};
-        if (load_tower_module(&mod, fn)) return -1;
-        TowerLayer t;
-        std::memset(&t, 0, sizeof(t));
-        TowerLayer* dt = (TowerLayer*)A.alloc(sizeof(TowerLayer));
-        if (!dt) return fail("test_conv_se: hipMalloc failed");
-        t.self = dt; t.last = 1; t.has_se = 1; t.sp = sp;
-        HIP_OK(hipMemcpy(dt, &t, sizeof(t), hipMemcpyHostToDevice));
-        const TowerLayer* arg = dt;
-        void* params[] = {(void*)&arg};
-        HIP_OK(hipModuleLaunchKernel(fn[be->kot == 256 ? 0 : 1], plan.ntiles, 1, 1, 512, 1, 1, 0, nullptr, params, nullptr));
-    } else {
-        hipLaunchKernelGGL(be->fn_se, dim3(plan.ntiles), dim3(512), be->lds(plan.npos), 0, sp);
-    }
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipDeviceSynchronize());
-    if (mod) (void)hipModuleUnload(mod);
-    std::vector<T> hy((size_t)n * tg.slot * cs);
-    HIP_OK(hipMemcpy(hy.data(), dy, hy.size() * sizeof(T), hipMemcpyDeviceToHost));
-    size_t so = 0;
-    for (int i = 0; i < n; ++i) {
-        const int S = tg.hg.bsz[i] * tg.hg.bsz[i];
-        for (int c = 0; c < C; ++c)
-            for (int pp = 0; pp < S; ++pp) y[so + (size_t)c * S + pp] = (float)hy[((size_t)i * tg.slot + pp) * cs + c];
-        so += (size_t)C * S;
-    }
-    return 0;
-}
-
-// Both heads of a sample in one workgroup (head_board_kernel): trunk [n][C][bs*bs] -> the four output tensors.
-// Returns 1 when no head_board_kernel variant fits these channel counts (the engine then runs conv1x1 x2 + head_tail).
-static int test_head_board_impl(int device, int n, const int* board_sizes, int max_board, int C, int Cp, int Cv, int prob_ch,
-                                int pass_outs, int misc_outs, int act, const float* trunk, const float* p_w, const float* p_b,
-                                const float* v_w, const float* v_b, const float* const* w, float* prob, float* pass, float* misc,
-                                float* own) {
-    typedef f16 T;
-    HIP_OK(hipSetDevice(device));
-    enable_big_lds_glds();
-    TestArena A;
-    TestGeom tg;
-    if (make_test_geom(A, n, board_sizes, max_board, &tg)) return -1;
-    HeadImages hi;
-    const HeadFn fn = make_head_images(C, Cp, Cv, prob_ch, max_board, p_w, p_b, v_w, v_b, w[8], w[10], &hi);
-    if (!fn) return 1;
-    const int cs = round_up(C, 32), B2 = max_board * max_board;
-    T* dt = A.upload(nchw_to_nhwc<T>(tg, trunk, C, cs));
-    HeadBoardParams hp;
-    std::memset(&hp, 0, sizeof(hp));
-    HeadParams& h = hp.h;
-    float* d_pi = A.upload(fc_transposed(w[0], 3 * Cp, Cp));
-    float* d_pib = A.upload(std::vector<float>(w[1], w[1] + Cp));
-    float* d_pw = A.upload(fc_transposed(w[2], Cp, pass_outs));
-    float* d_pwb = A.upload(std::vector<float>(w[3], w[3] + pass_outs));
-    float* d_vi = A.upload(fc_transposed(w[4], 3 * Cv, 3 * Cv));
-    float* d_vib = A.upload(std::vector<float>(w[5], w[5] + 3 * Cv));
-    float* d_vm = A.upload(fc_transposed(w[6], 3 * Cv, misc_outs));
-    float* d_vmb = A.upload(std::vector<float>(w[7], w[7] + misc_outs));
-    float* d_prw = A.upload(std::vector<float>(w[8], w[8] + (size_t)prob_ch * Cp));
-    float* d_prb = A.upload(std::vector<float>(w[9], w[9] + prob_ch));
-    float* d_ow = A.upload(std::vector<float>(w[10], w[10] + Cv));
-    float* d_ob = A.upload(std::vector<float>(w[11], w[11] + 1));
-    f16* d_img = A.upload(hi.img);
-    f16* d_img2 = A.upload(hi.img2);
-    float* d_bias = A.upload(hi.bias);
-    float* d_prob = (float*)A.alloc(sizeof(float) * (size_t)n * prob_ch * B2);
-    float* d_pass = (float*)A.alloc(sizeof(float) * (size_t)n * pass_outs);
-    float* d_misc = (float*)A.alloc(sizeof(float) * (size_t)n * misc_outs);
-    float* d_own = (float*)A.alloc(sizeof(float) * (size_t)n * B2);
-    if (!dt || !d_pi || !d_pib || !d_pw || !d_pwb || !d_vi || !d_vib || !d_vm || !d_vmb || !d_prw || !d_prb || !d_ow || !d_ob || !d_img ||
-        !d_img2 || !d_bias || !d_prob || !d_pass || !d_misc || !d_own)
-        return fail("test_head_board: hipMalloc failed");
-    h.p_inter = FcDev{d_pi, d_pib, 3 * Cp, Cp};
-    h.pass_fc = FcDev{d_pw, d_pwb, Cp, pass_outs};
-    h.v_inter = FcDev{d_vi, d_vib, 3 * Cv, 3 * Cv};
-    h.v_misc = FcDev{d_vm, d_vmb, 3 * Cv, misc_outs};
-    h.prob_w = d_prw; h.prob_b = d_prb; h.own_w = d_ow; h.own_b = d_ob;
-    h.Cp = Cp; h.cs_p = round_up(Cp, 32); h.Cv = Cv; h.cs_v = round_up(Cv, 32); h.prob_ch = prob_ch; h.act = act; h.board = max_board;
-    h.prob = d_prob; h.pass = d_pass; h.misc = d_misc; h.own = d_own; h.perm = nullptr;
-    hp.trunk = dt; hp.w = d_img; hp.w2 = d_img2; hp.bias = d_bias; hp.g = tg.g; hp.cs = cs; hp.PT = hi.PT; hp.VT = hi.VT; hp.dbg = nullptr;
-    hipLaunchKernelGGL(fn, dim3(n), dim3(512), kMaxLds, 0, hp);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpy(prob, d_prob, sizeof(float) * (size_t)n * prob_ch * B2, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(pass, d_pass, sizeof(float) * (size_t)n * pass_outs, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(misc, d_misc, sizeof(float) * (size_t)n * misc_outs, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(own, d_own, sizeof(float) * (size_t)n * B2, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-}  // namespace sayuri
-
-extern "C" int sayuri_hip_test_conv_se(int device, int n, const int* board_sizes, int max_board, int channels, int se_size, int act,
-                                       int via_tower, const float* x, const float* w, const float* bias, const float* res,
-                                       const float* w1, const float* b1, const float* w2, const float* b2, float* y) {
-    if (!board_sizes || !x || !w || !w1 || !b1 || !w2 || !b2 || !y || n <= 0) return fail("test_conv_se: bad argument");
-    return test_conv_se_impl(device, n, board_sizes, max_board, channels, se_size, act, via_tower, x, w, bias, res, w1, b1, w2, b2, y);
-}
-
-extern "C" int sayuri_hip_test_head_board(int device, int n, const int* board_sizes, int max_board, int channels, int policy_channels,
-                                          int value_channels, int prob_channels, int pass_outs, int misc_outs, int act, const float* trunk,
-                                          const float* p_w, const float* p_b, const float* v_w, const float* v_b,
-                                          const float* const* weights12, float* prob, float* pass, float* misc, float* own) {
-    if (!board_sizes || !trunk || !p_w || !p_b || !v_w || !v_b || !weights12 || !prob || !pass || !misc || !own || n <= 0)
-        return fail("test_head_board: bad argument");
-    return test_head_board_impl(device, n, board_sizes, max_board, channels, policy_channels, value_channels, prob_channels, pass_outs,
-                                misc_outs, act, trunk, p_w, p_b, v_w, v_b, weights12, prob, pass, misc, own);
-}
-
-extern "C" int sayuri_hip_test_se_unit(int device, int use_fp16, int n, const int* board_sizes, int max_board, int channels, int se_size,
-                                       int act, const float* x, const float* res, const float* w1, const float* b1, const float* w2,
-                                       const float* b2, float* y, float* gate) {
-    if (!board_sizes || !x || !w1 || !b1 || !w2 || !b2 || !y || n <= 0) return fail("test_se_unit: bad argument");
-    if (use_fp16) return test_se_unit_impl<f16>(device, n, board_sizes, max_board, channels, se_size, act, x, res, w1, b1, w2, b2, y, gate);
-    return test_se_unit_impl<float>(device, n, board_sizes, max_board, channels, se_size, act, x, res, w1, b1, w2, b2, y, gate);
-}
-
-extern "C" int sayuri_hip_test_head_tail(int device, int use_fp16, int n, const int* board_sizes, int max_board, int policy_channels,
-                                         int value_channels, int prob_channels, int pass_outs, int misc_outs, int act, const float* pconv,
-                                         const float* vconv, const float* const* weights12, float* prob, float* pass, float* misc,
-                                         float* own) {
-    if (!board_sizes || !pconv || !vconv || !weights12 || !prob || !pass || !misc || !own || n <= 0) return fail("test_head_tail: bad argument");
-    if (use_fp16)
-        return test_head_tail_impl<f16>(device, n, board_sizes, max_board, policy_channels, value_channels, prob_channels, pass_outs,
-                                        misc_outs, act, pconv, vconv, weights12, prob, pass, misc, own);
-    return test_head_tail_impl<float>(device, n, board_sizes, max_board, policy_channels, value_channels, prob_channels, pass_outs,
-                                      misc_outs, act, pconv, vconv, weights12, prob, pass, misc, own);
-}
-
-extern "C" int sayuri_hip_test_last_conv_kind(void) { return sayuri::g_test_conv_kind; }
-
-extern "C" int sayuri_hip_test_conv(int device, int use_fp16, int n, const int* board_sizes, int max_board, int cin,
-                                    int cout, int k, int depthwise, int act, int post_residual, const float* x,
-                                    const float* w, const float* bias, const float* res, float* y) {
-    if (!board_sizes || !x || !w || !y || n <= 0) return fail("test_conv: bad argument");
-    if (use_fp16)
-        return test_conv_impl<f16>(device, n, board_sizes, max_board, cin, cout, k, depthwise, act, post_residual, x, w,
-                                   bias, res, y);
-    return test_conv_impl<float>(device, n, board_sizes, max_board, cin, cout, k, depthwise, act, post_residual, x, w,
-                                 bias, res, y);
-}
+#include "engine_taps.h"

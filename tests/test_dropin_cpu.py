@@ -177,7 +177,7 @@ def test_bench_two_ranks_on_the_fake_device(tmp_path):
     """bench.py's own multi-rank path (the command line the driver uses for N > 1: torch.distributed.run, one rank per
     device, barrier + max-over-ranks timing, the stats all-gather, the periodic exchange of the self-play segment), executed
     on two gloo ranks over the serial fake device -- so that the first run on an 8-GPU node is not this code's first run."""
-    d = _bench_on_the_fake_device(tmp_path, 2, 29541)
+    d = _bench_on_the_fake_device(tmp_path, 2, 29541, extra=["--no-config5"])  # (configs[4] on two ranks: the plain-command test below)
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"] and d["config"]["parallelism"] == "dp2"
     # value = the units ALL ranks processed / the max-over-ranks time: two serial devices at 3.8 ms per 256-batch
@@ -198,11 +198,14 @@ def test_plain_bench_command_starts_its_own_ranks(tmp_path):
     assert sp["exchange_rounds"] > 0 and sp["exchange"]["world"] == 2 and sp["exchange"]["rounds"] == sp["exchange_rounds"]
     assert sp["nn_evals_per_sec"] > 0 and sp["games_per_hour_empty_board_27min"] is not None
     assert d["tower"] == "per-layer fallback" and "hipcc" in d  # the fake device has no persistent kernel, and the line says so
+    # configs[4] runs on every rank of a multi-rank launch (it is an 8-GPU configuration): the sum over the ranks on the line
+    c5 = d["config5"]
+    assert c5["n_gpus"] == 2 and len(c5["per_rank_evals_per_sec"]) == 2 and c5["evals_per_sec"] > max(c5["per_rank_evals_per_sec"])
 
 
 def test_plain_bench_command_with_eight_ranks(tmp_path):
     """The same for the configuration the scaling run uses: `python bench.py --gpus 8` on eight fake devices."""
-    d = _bench_on_the_fake_device(tmp_path, 8, 29553, launcher=False, seconds=6, extra=["--no-pump"])
+    d = _bench_on_the_fake_device(tmp_path, 8, 29553, launcher=False, seconds=6, extra=["--no-pump", "--no-config5"])
     assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 8 * 256
     assert d["selfplay"]["exchange"]["world"] == 8 and d["selfplay"]["exchange_rounds"] > 0
     assert "cpu_baseline" not in d and "config5" not in d
