@@ -49,6 +49,7 @@ struct BoardSxParams {
     unsigned long long* xchg;  // granules [tile][kt][kSxMaxSub][kSxSlots]
     unsigned epoch;       // tag of this launch's granules (never 0)
     unsigned* err;        // host-visible: set to epoch when a wait for the siblings ran out
+    int dbg_stall;        // SAYURI_DEBUG_SX_STALL=1 (tests): channel tile 1 publishes under a wrong tag -- its siblings' wait must run out
 };
 
 // LDS map of the stage (the K loop's rings are dead): [0, kStage) the accumulators of 64 channels as [slot][68] fp32 -- later
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(512, 2) void conv_board_sx_kernel(const BoardSxPara
         float t = 0.f;
         for (int pt = 0; pt < parts; ++pt) t += red[(s * parts + pt) * se + o];
         part[(kt * kSxMaxSub + s) * 128 + o] = t;
-        __hip_atomic_store(xg + ((size_t)kt * kSxMaxSub + s) * kSxSlots + o, ((unsigned long long)sp.epoch << 32) | (unsigned long long)__float_as_uint(t),
+        const unsigned tag = (sp.dbg_stall && kt == 1) ? (sp.epoch ^ 0x80000000u) : sp.epoch;
+        __hip_atomic_store(xg + ((size_t)kt * kSxMaxSub + s) * kSxSlots + o, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(t),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (dbg) dbg[3] = __builtin_amdgcn_s_memtime();

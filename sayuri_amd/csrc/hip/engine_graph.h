@@ -1177,6 +1177,7 @@ private:
             sp.w1t = sq.sx_img; sp.w2t = ex.sx_img; sp.w1_bytes = sq.sx_bytes; sp.w2_bytes = ex.sx_bytes;
             sp.nsizes = board_ - 1; sp.se = sq.out; sp.kts = kts;
             sp.xchg = io_[cur_slot_].sx_xchg; sp.epoch = epoch; sp.err = sx_err_dev_;
+            sp.dbg_stall = flags_.dbg_sx_stall ? 1 : 0;
             if (flags_.sx_dbg > 0 && profiling_ && sx_idx_ == flags_.sx_dbg) {
                 if (!d_sxdbg_ && dev_alloc(&d_sxdbg_, 4 * 64)) return -1;
                 sp.b.dbg = d_sxdbg_;

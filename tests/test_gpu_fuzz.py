@@ -225,7 +225,12 @@ def run_fuzz(nets, scenarios, seed, env_extra=None, stop_at_first=False, tmp_wei
             ctx = pipe.ctx(0)
             ham = None
             if sc["hammer"]:
-                other = [x for x in nets if x != name][0] if len(nets) > 1 else name
+                # another network's context -- or, one time in three, a second context of the SAME network (two engines whose
+                # launches of one kind run side by side: the split SE convolutions of 40b x 384 wait for siblings inside a launch)
+                other = [x for x in nets if x != name][int(rng.integers(0, max(len(nets) - 1, 1)))] if len(nets) > 1 else name
+                if rng.integers(0, 3) == 0:
+                    other = name
+                sc["hammer_net"] = other
                 if other not in hammers:
                     hammers[other] = Hammer(make_pipe(paths[other], dict(env_extra)), pool)
                 ham = hammers[other]

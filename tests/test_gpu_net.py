@@ -526,6 +526,35 @@ def test_split_se_unit_inside_the_convolution_40b384(tmp_weights_dir, monkeypatc
             assert np.array_equal(a[idx[0]], b[0]), ("alone", idx[0], bsz[idx[0]])
 
 
+def test_split_se_exchange_that_never_completes_fails_loudly(tmp_weights_dir, monkeypatch):
+    """conv_board_sx.h: a workgroup waits for its siblings' partial sums inside the launch.  The wait is bounded: when a sibling never
+    publishes (SAYURI_DEBUG_SX_STALL=1: channel tile 1 writes its granules under a wrong tag) every waiting workgroup gives up after
+    ~0.3 s, sets a host-visible word, and the forward comes back as an ERROR -- not as a hang, and not as silently wrong numbers.  The
+    next forward of a healthy engine on the same device is unaffected."""
+    import time
+    from sayuri_amd.pipe import hip_forward_raw
+    g = Golden("net_40b384", tmp_weights_dir)
+    B, n = 19, 6
+    planes = W.synthetic_planes(n, B, seed=6700)
+    grid = np.ascontiguousarray(np.stack(planes), np.float32)
+    monkeypatch.setenv("SAYURI_DEBUG_SX_STALL", "1")
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=8, fp16=True)
+    monkeypatch.delenv("SAYURI_DEBUG_SX_STALL")
+    try:
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match="SE exchange"):
+            hip_forward_raw(pipe.ctx(0), grid, [B] * n, B)
+        assert time.time() - t0 < 120.0
+    finally:
+        pipe.Destroy()
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=8, fp16=True)
+    try:
+        out = hip_forward_raw(pipe.ctx(0), grid, [B] * n, B)
+        assert all(np.isfinite(o).all() for o in out) and np.abs(out[0]).max() > 0
+    finally:
+        pipe.Destroy()
+
+
 def test_chained_forward(tmp_weights_dir, monkeypatch):
     """configs[4]: a batch whose layers are more than one round of workgroups (40b x 384: 150 board tiles x 3 channel tiles on
     256 CUs) is run as chains of per-layer launches over groups of tiles, each on a stream of its own (Engine::forward; +6...10 %
