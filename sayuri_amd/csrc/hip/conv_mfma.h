@@ -26,8 +26,8 @@
 namespace sayuri {
 
 constexpr int kChunk = 32;     // channels per K chunk
-constexpr int kMaxSub = 24;    // max samples a pixel tile may touch
-constexpr int kHdrBytes = 1024;
+constexpr int kMaxSub = 34;    // max samples a pixel tile may touch (a 128-pixel tile over 2x2 boards: 33)
+constexpr int kHdrBytes = 1280;  // 8 + 8 * kMaxSub ints
 
 struct ConvParams {
     const void* in;     // [slot][pix][cin_s]
@@ -52,7 +52,10 @@ template <typename T, int WMT_, int WNT_> struct ConvCfg {
     static constexpr int NT = 64 * WAVM * WAVN;
     // halo positions a pixel tile may need: a tile over several small boards pays a one-cell frame per board
     // (worst mixes of 9/13/19 boards measured: 304 @ PT 128, 400 @ 192, 480 @ 256)
-    static constexpr int NPOS_CAP = PT + PT / 2 + 160;
+    // The 128-pixel tiles (WNT = 2) are the fallback for ANY geometry the reference accepts (boards from 2x2, types.h:23): a tile
+    // over 2x2 boards touches 33 samples with a 4x4 halo each -- 4 positions per pixel (round 6: the fuzz drew a batch with two
+    // dozen 2x2 / 3x3 boards in a row on the 96-channel network and the engine refused it).
+    static constexpr int NPOS_CAP = WNT_ == 2 ? 4 * PT + 32 : PT + PT / 2 + 160;
     static size_t lds_bytes(int npos) {
         return kHdrBytes + ((npos * 4 + 15) & ~15) + 2 * (size_t)KO_T * kChunk * sizeof(T) +
                2 * (size_t)npos * kChunk * sizeof(T);

@@ -555,6 +555,28 @@ def test_split_se_exchange_that_never_completes_fails_loudly(tmp_weights_dir, mo
         pipe.Destroy()
 
 
+@pytest.mark.parametrize("fp16", [False, True], ids=["fp32", "fp16"])
+def test_a_batch_of_many_tiny_boards_on_the_generic_kernel(fp16, tmp_weights_dir):
+    """The reference accepts boards from 2x2 (types.h:23).  On a network whose channel count has no board kernel (6b x 96) the
+    convolutions tile the batch's pixels across samples (conv_mfma.h); a 128-pixel tile over 2x2 boards touches 33 samples with a
+    4x4 halo each.  Until round 6 the tile limits (24 samples, 352 halo positions) made the engine REFUSE a batch with two dozen
+    2x2 / 3x3 boards in a row ("no conv tile configuration fits this batch geometry" -- found by the fuzz, seed 11); now such a
+    batch is evaluated, and matches the oracle."""
+    g = Golden("net_6b96", tmp_weights_dir)
+    net = PortNet(g.weights_path)
+    bsz = [2] * 40 + [3] * 30 + [9, 19, 2, 3, 5, 2]
+    planes = W.synthetic_planes(len(bsz), bsz, seed=6800)
+    pipe = HipForwardPipe(g.weights_path, board_size=19, batch_size=128, fp16=fp16)
+    try:
+        outs = pipe.BatchForward(planes, bsz)
+    finally:
+        pipe.Destroy()
+    for i in (0, 17, 39, 40, 55, 69, 70, 71, 72, 73, 74, 75):
+        exp = net.forward(planes[i], bsz[i])
+        assert np.isfinite(outs[i]).all()
+        assert np.abs(outs[i] - exp).max() <= (fp16_tol(exp) if fp16 else FP32_ATOL), (i, bsz[i])
+
+
 def test_chained_forward(tmp_weights_dir, monkeypatch):
     """configs[4]: a batch whose layers are more than one round of workgroups (40b x 384: 150 board tiles x 3 channel tiles on
     256 CUs) is run as chains of per-layer launches over groups of tiles, each on a stream of its own (Engine::forward; +6...10 %
