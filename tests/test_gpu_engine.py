@@ -158,7 +158,7 @@ def test_selfplay_configs2_workload_keeps_full_batches(tmp_weights_dir, tmp_path
 
 
 def test_bench_two_ranks_share_the_gpu():
-    """bench.py's multi-rank path against the real runtime: the driver's command line for N = 2 (torch.distributed.run, one
+    """bench.py's multi-rank path against the real runtime: `python bench.py --gpus 2` (the script starts its two ranks, one
     process per rank), on gloo, the two ranks sharing this box's one GPU (SAYURI_BENCH_SHARE_DEVICE).  What is checked is
     that the path runs -- barrier, max-over-ranks timing, the stats gather, the exchange rounds of the self-play window, ONE
     JSON line from rank 0 -- not the throughput of two processes on one device (tests/test_dropin_cpu.py runs the same on the
@@ -168,8 +168,11 @@ def test_bench_two_ranks_share_the_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SAYURI_BENCH_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    # round 6: the PLAIN command -- no launcher around it; bench.py starts its two ranks itself (launch_ranks), and configs[4]
+    # runs on both of them
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--master-port", "29547", "--gpus", "2", "--steps", "5", "--warmup", "2",
            "--dist-backend", "gloo", "--selfplay-seconds", "10", "--selfplay-games", "64", "--selfplay-visits", "16"]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -181,6 +184,7 @@ def test_bench_two_ranks_share_the_gpu():
     sp = d["selfplay"]
     assert sp["exchange_rounds"] > 0 and sp["nn_evals_per_sec"] > 0 and not sp["halt_seen"]
     assert "cpu_baseline" not in d
+    assert d["config5"]["n_gpus"] == 2 and len(d["config5"]["per_rank_evals_per_sec"]) == 2 and d["tower"] == "persistent"
 
 
 def test_bench_exchange_over_rccl_beside_the_persistent_launch():
