@@ -1133,7 +1133,7 @@ private:
     // kernels, exactly as conv_se splits a mixed batch.  Honours the tile range of a chained forward.
     int conv_sx(const ConvLayerDev& L, const FcLayerDev& sq, const FcLayerDev& ex, const T* in, T* out, const T* res, int C, int act) {
         if constexpr (sizeof(T) != 2) return 1;
-        if (!flags_.se_split || !sq.sx_img || !ex.sx_img || !sx_kts_ || L.ko_pad != sx_kts_ * 128 || L.cout_s != L.ko_pad) return 1;
+        if (!flags_.se_split || sx_disabled_ || !sq.sx_img || !ex.sx_img || !sx_kts_ || L.ko_pad != sx_kts_ * 128 || L.cout_s != L.ko_pad) return 1;
         int bkt = 0;
         if (!choose_board(L, &bkt)) return 1;
         const BoardEntry* be = nullptr;
@@ -1702,12 +1702,14 @@ private:
     unsigned* sx_err_dev_ = nullptr;
     unsigned sx_epoch0_ = 0;              // tags of the current forward: sx_epoch0_ + 1 + index of the SE layer
     int sx_idx_ = 0;
+    bool sx_disabled_ = false;            // set by sx_check(): the exchange timed out once on this ctx
     int sx_check() {
         if (sx_err_host_ && *(volatile unsigned*)sx_err_host_) {
             const unsigned e = *(volatile unsigned*)sx_err_host_;
             *(volatile unsigned*)sx_err_host_ = 0;
+            sx_disabled_ = true;  // this ctx goes on with the separate kernels: a wait that ran out once is not tried again
             return fail("SE exchange between the channel tiles of a board tile timed out (epoch " + std::to_string(e) +
-                        "): the results of this forward are invalid; SAYURI_SE_SPLIT=0 runs the unit as separate kernels");
+                        "): the results of this forward are invalid; from here on this context runs the unit as separate kernels (SAYURI_SE_SPLIT=0)");
         }
         return 0;
     }

@@ -530,7 +530,7 @@ def test_split_se_exchange_that_never_completes_fails_loudly(tmp_weights_dir, mo
     """conv_board_sx.h: a workgroup waits for its siblings' partial sums inside the launch.  The wait is bounded: when a sibling never
     publishes (SAYURI_DEBUG_SX_STALL=1: channel tile 1 writes its granules under a wrong tag) every waiting workgroup gives up after
     ~0.3 s, sets a host-visible word, and the forward comes back as an ERROR -- not as a hang, and not as silently wrong numbers.  The
-    next forward of a healthy engine on the same device is unaffected."""
+    context then goes on with the separate SE kernels; a healthy engine on the same device is unaffected."""
     import time
     from sayuri_amd.pipe import hip_forward_raw
     g = Golden("net_40b384", tmp_weights_dir)
@@ -545,8 +545,19 @@ def test_split_se_exchange_that_never_completes_fails_loudly(tmp_weights_dir, mo
         with pytest.raises(RuntimeError, match="SE exchange"):
             hip_forward_raw(pipe.ctx(0), grid, [B] * n, B)
         assert time.time() - t0 < 120.0
+        # the context goes on with the separate kernels (a wait that ran out once is not tried again): the next forward succeeds
+        again = hip_forward_raw(pipe.ctx(0), grid, [B] * n, B)
     finally:
         pipe.Destroy()
+    monkeypatch.setenv("SAYURI_SE_SPLIT", "0")
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=8, fp16=True)
+    monkeypatch.delenv("SAYURI_SE_SPLIT")
+    try:
+        sep = hip_forward_raw(pipe.ctx(0), grid, [B] * n, B)
+    finally:
+        pipe.Destroy()
+    for a, b in zip(again, sep):
+        assert np.isfinite(a).all() and np.array_equal(a, b)  # ... with the bits of the separate kernels
     pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=8, fp16=True)
     try:
         out = hip_forward_raw(pipe.ctx(0), grid, [B] * n, B)
