@@ -565,7 +565,10 @@ SelfplayStats SelfplayPipe::Run(double seconds) {
     const int cores = UsableCores(static_cast<int>(cpus.size()));
     int fiber_threads = 0;
     if (opt_.selfplay.game_threads > 0) fiber_threads = std::min(opt_.selfplay.game_threads, games);
-    else if (opt_.selfplay.game_threads == 0 && games >= 256) fiber_threads = std::min(games, std::max(8, 4 * cores));
+    // ... and never more than 64: measured on the 16-CPU quota 64 threads 73.2 k evals/s at 4.7 cores, 96: 72.8 k at 5.0, 128: 72.0 k at
+    // 5.8 (round 5) -- more scheduler threads only add wake-ups.  A box that grants more CPUs (an 8-GPU pod running ONE rank sees the
+    // whole node's quota) must not get 512 threads for 512 games.
+    else if (opt_.selfplay.game_threads == 0 && games >= 256) fiber_threads = std::min(games, std::min(64, std::max(8, 4 * cores)));
     // One process per GPU on a node: every rank would otherwise pin its threads to the same first CPUs of the (shared)
     // affinity mask.  Each local rank takes its own contiguous slice of the mask.
     size_t cpu_lo = 0, cpu_n = cpus.size();
