@@ -799,6 +799,7 @@ private:
             if (dev_alloc(&io.separt, (size_t)max_batch_ * kSeSplit * 2 * round_up(desc_.residual_channels, 32))) return -1;
             // conv_board_sx.h: the granules the sibling channel tiles of a board tile exchange, [tile][kt][sample][slot]
             if (sx_kts_ && dev_alloc(&io.sx_xchg, (size_t)max_batch_ * sx_kts_ * kSxMaxSub * kSxSlots)) return -1;
+            io.sx_epoch = flags_.dbg_sx_epoch0;
         }
         if (sx_kts_) {
             HIP_OK(hipHostMalloc((void**)&sx_err_host_, 64, hipHostMallocMapped));

@@ -148,6 +148,7 @@ struct EngineFlags {
                                        // se_pool / se_fc / se_scale again instead of inside the convolution (conv_board_sx.h)
     int tower_noepi_after = -1;        // SAYURI_TOWER_NOEPI_AFTER=n (measuring): from the n-th persistent launch on, the layers with the
                                        // generated epilogue skip it (row_order = 3): timing only, the outputs are stale
+    unsigned dbg_sx_epoch0 = 0;        // SAYURI_DEBUG_SX_EPOCH0=n (tests): the exchange tags of a new context start at n (the wrap of the tags)
     bool dbg_sx_stall = false;         // SAYURI_DEBUG_SX_STALL=1 (tests): one sibling of every tile never publishes under the right tag
     int sx_dbg = 0;                    // SAYURI_SX_DBG=n: s_memtime timeline of the n-th split SE convolution of a profiled forward
     int dbg_recycle_input = 0;         // SAYURI_DEBUG_RECYCLE_INPUT=1: hand the packed input's buffer back to the pool after the input
@@ -174,6 +175,7 @@ struct EngineFlags {
         f.se_split = !off("SAYURI_SE_SPLIT");
         if (const char* e = getenv("SAYURI_SX_DBG")) f.sx_dbg = atoi(e);
         f.dbg_sx_stall = getenv("SAYURI_DEBUG_SX_STALL") != nullptr;
+        if (const char* e = getenv("SAYURI_DEBUG_SX_EPOCH0")) f.dbg_sx_epoch0 = (unsigned)strtoul(e, nullptr, 0);
         if (const char* e = getenv("SAYURI_TOWER_NOEPI_AFTER")) f.tower_noepi_after = atoi(e);
         f.io_v2 = !off("SAYURI_IO_V2");
         f.io_zc = f.io_v2 && !off("SAYURI_IO_ZC");

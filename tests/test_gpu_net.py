@@ -588,6 +588,36 @@ def test_a_batch_of_many_tiny_boards_on_the_generic_kernel(fp16, tmp_weights_dir
         assert np.abs(outs[i] - exp).max() <= (fp16_tol(exp) if fp16 else FP32_ATOL), (i, bsz[i])
 
 
+def test_split_se_exchange_tags_wrap(tmp_weights_dir, monkeypatch):
+    """conv_board_sx.h tags every exchanged value with the launch's epoch, which grows by one per SE layer launch; a slot's old tag
+    must never equal a later epoch, so shortly before the 32-bit tags wrap the engine clears the buffer and starts over
+    (Engine::forward).  A context whose tags start just below that point (SAYURI_DEBUG_SX_EPOCH0) crosses it within a few forwards:
+    every forward, before and after, must carry the bits of an ordinary context."""
+    from sayuri_amd.pipe import hip_forward_raw
+    g = Golden("net_40b384", tmp_weights_dir)
+    B = 19
+    bsz = [19, 13, 9, 13, 19, 9, 9, 9, 13, 19]
+    planes = W.synthetic_planes(len(bsz), bsz, seed=6900)
+    grid = np.zeros((len(bsz), 43, B * B), np.float32)
+    for i, (p, bs) in enumerate(zip(planes, bsz)):
+        grid[i].reshape(43, B, B)[:, :bs, :bs] = p.reshape(43, bs, bs)
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=16, fp16=True)
+    try:
+        ref = hip_forward_raw(pipe.ctx(0), grid, bsz, B)
+    finally:
+        pipe.Destroy()
+    monkeypatch.setenv("SAYURI_DEBUG_SX_EPOCH0", str(0xfff00000 - 30))  # 13 tags per forward: the third forward crosses the line
+    pipe = HipForwardPipe(g.weights_path, board_size=B, batch_size=16, fp16=True)
+    monkeypatch.delenv("SAYURI_DEBUG_SX_EPOCH0")
+    try:
+        for k in range(8):
+            out = hip_forward_raw(pipe.ctx(0), grid, bsz, B)
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b), k
+    finally:
+        pipe.Destroy()
+
+
 def test_chained_forward(tmp_weights_dir, monkeypatch):
     """configs[4]: a batch whose layers are more than one round of workgroups (40b x 384: 150 board tiles x 3 channel tiles on
     256 CUs) is run as chains of per-layer launches over groups of tiles, each on a stream of its own (Engine::forward; +6...10 %
