@@ -277,7 +277,7 @@ def parity_sample(net, kind: str, pipe, planes, fp16: bool, k: int = 4) -> dict:
             "max_abs_err": round(err, 6), "output_scale": round(scale, 3), "gate": round(gate, 6),
             "gate_rule": "4e-3 x max(1, output scale) and SelfCheck L2 <= 0.2 (fp16 engine)" if fp16 else "1e-4 abs (SURVEY 8c)",
             "selfcheck_l2_max": round(l2max, 6), "within_gate": bool(err <= gate and l2max <= 0.2),
-            "strict_engine": "python bench.py --fp32: fp32 storage and MFMA, gated at 1e-4 abs, 5.7 k evals/s (profiles/r05_bench_fp32.json)"}
+            "strict_engine": "python bench.py --fp32: fp32 storage and MFMA, gated at 1e-4 abs, 5.7 k evals/s (profiles/r06_bench_fp32.json)"}
 
 
 def cpu_baseline(weights_path: str, planes, seconds: float = 15.0, pipe=None, fp16: bool = True):
