@@ -63,13 +63,13 @@ class Pool:
         return rng.integers(0, len(self.bsz), size=n)  # "wild": anything from 2x2 to 19x19
 
 
-def make_pipe(path, env):
+def make_pipe(path, env, fp16=True):
     keep = {k: os.environ.get(k) for k in SWITCHES}
     for k in SWITCHES:
         os.environ.pop(k, None)
     os.environ.update(env)
     try:
-        return HipForwardPipe(path, board_size=B, batch_size=MAXB, fp16=True)  # the switches are read at creation
+        return HipForwardPipe(path, board_size=B, batch_size=MAXB, fp16=fp16)  # the switches are read at creation
     finally:
         for k, v in keep.items():
             os.environ.pop(k, None)
@@ -77,9 +77,9 @@ def make_pipe(path, env):
                 os.environ[k] = v
 
 
-def reference_bits(path, pool):
+def reference_bits(path, pool, fp16=True):
     """prob / pass / misc / own of every pool position from the per-layer, one-chain, one-stream engine."""
-    pipe = make_pipe(path, {"SAYURI_TOWER": "0", "SAYURI_CHAINS": "1"})
+    pipe = make_pipe(path, {"SAYURI_TOWER": "0", "SAYURI_CHAINS": "1"}, fp16)
     try:
         ctx = pipe.ctx(0)
         assert _lib.hip().sayuri_hip_tower_state(ctx) == 0
@@ -195,13 +195,13 @@ def draw_n(rng):
     return int(rng.integers(262, 601))          # more tiles than CUs: workgroups of a second round start late
 
 
-def run_fuzz(nets, scenarios, seed, env_extra=None, stop_at_first=False, tmp_weights_dir=None, only=None):
+def run_fuzz(nets, scenarios, seed, env_extra=None, stop_at_first=False, tmp_weights_dir=None, only=None, fp16=True):
     """-> list of (scenario description, wrong samples, batch size) for every batch that came back with wrong bits."""
     lib = _lib.hip()
     pool = Pool()
     rng = np.random.default_rng(seed)
     paths = {name: Golden(name, tmp_weights_dir).weights_path for name in nets}
-    refs = {name: reference_bits(paths[name], pool) for name in nets}
+    refs = {name: reference_bits(paths[name], pool, fp16) for name in nets}
     pipes, pinned, failures, ran = {}, Pinned(lib), [], []
     env_extra = env_extra or {}
 
@@ -211,13 +211,13 @@ def run_fuzz(nets, scenarios, seed, env_extra=None, stop_at_first=False, tmp_wei
             env = dict(env_extra)
             if chains == "1":
                 env["SAYURI_CHAINS"] = "1"
-            pipes[key] = make_pipe(paths[name], env)
+            pipes[key] = make_pipe(paths[name], env, fp16)
         return pipes[key]
 
     hammers = {}
     try:
         for k in range(scenarios):
-            name = only or str(rng.choice(nets, p=[0.45, 0.35, 0.2][:len(nets)] if len(nets) == 3 else None))
+            name = only or str(rng.choice(nets, p=[0.45, 0.35, 0.2] if len(nets) == 3 else None))
             sc = dict(k=k, net=name, n=draw_n(rng), mix=str(rng.choice(["uniform19", "mixed", "mixed", "wild"])),
                       tickets=int(rng.integers(1, 3)), chains=str(rng.choice(["auto", "1"])), packed=bool(rng.integers(0, 2)),
                       hammer=bool(rng.integers(0, 2)))
@@ -232,7 +232,7 @@ def run_fuzz(nets, scenarios, seed, env_extra=None, stop_at_first=False, tmp_wei
                     other = name
                 sc["hammer_net"] = other
                 if other not in hammers:
-                    hammers[other] = Hammer(make_pipe(paths[other], dict(env_extra)), pool)
+                    hammers[other] = Hammer(make_pipe(paths[other], dict(env_extra), fp16), pool)
                 ham = hammers[other]
                 ham.start()
             try:
@@ -293,6 +293,17 @@ def test_bit_identity_fuzz(tmp_weights_dir, capsys):
     # the draw must have reached the corners this test exists for
     assert any(s["net"] == "net_20b256" and s["n"] > 256 for s in ran) and any(s["tickets"] == 2 and s["mix"] != "uniform19" for s in ran)
     assert any(s["chains_ran"] > 1 for s in ran) and any(s["hammer"] and s["tickets"] == 2 for s in ran)
+
+
+def test_bit_identity_fuzz_fp32_engine(tmp_weights_dir, capsys):
+    """The strict-parity engine (fp32 storage and MFMA: generic kernels, uploads / forwards / downloads on three streams with events
+    between them) under the same fuzz: 30 scenarios on the two small networks."""
+    failures, ran = run_fuzz(["net_6b96", "tiny_all"], 30, 20261001, tmp_weights_dir=tmp_weights_dir, fp16=False)
+    with capsys.disabled():
+        print(f"\n[fuzz, fp32 engine] {len(ran)} scenarios, two tickets in {sum(1 for s in ran if s['tickets'] == 2)}, "
+              f"hammered {sum(1 for s in ran if s['hammer'])}; wrong batches: {len(failures)}")
+    assert not failures, failures[:5]
+    assert any(s["tickets"] == 2 for s in ran)
 
 
 def test_fuzz_sees_the_recycled_input_buffer(tmp_weights_dir, capsys):
