@@ -41,7 +41,7 @@ typedef __attribute__((address_space(1))) unsigned long long sx_gu64;
 
 struct BoardSxParams {
     BoardParams b;        // c.res / c.act are the UNIT's residual and activation; c.npos = first tile, c.num_pix_tiles = tiles of the launch
-    const void* w1t;      // squeeze images: [kt][board size 2..][2 x 128 rows][se] fp16, mean rows (scaled mean folded in) then max rows (read from L2 into registers)
+    const void* w1t;      // squeeze images: [kt][board size 2..][2 x 128 rows][se] fp16, mean rows (scaled mean folded in) then max rows 
     const void* w2t;      // excite images:  [kt][se / 4][2 x 128][4] fp16, then excite bias of the own 2 x 128 outputs, then squeeze bias [se] (fp32)
     int w1_bytes, w2_bytes;  // bytes of one image (multiples of 1 KiB)
     int nsizes;           // board sizes per channel tile in w1t (board - 1)
@@ -53,7 +53,7 @@ struct BoardSxParams {
 };
 
 // LDS map of the stage (the K loop's rings are dead): [0, kStage) the accumulators of 64 channels as [slot][68] fp32 -- later
-// the excite image -- then the small arrays.
+// the two weight images -- then the small arrays.
 struct SxLds {
     static constexpr int kPitch = 68;                                  // floats per pixel slot (64 + 4: the 16 pixel lanes of a store hit different banks)
     static constexpr int stage = 0, stage_bytes = kBoardPT * kPitch * 4;   // 104 448
@@ -122,19 +122,8 @@ __global__ __launch_bounds__(512, 2) void conv_board_sx_kernel(const BoardSxPara
     const int q = lane >> 4, px = lane & 15;
     const int se = sp.se;
 
-    // the squeeze weights of this thread -- (4 consecutive outputs, every parts-th of the 256 own rows) -- straight from L2 into
-    // registers, requested NOW: they arrive while the accumulators are being pooled
-    const int quads = se >> 2, parts = min(32, 512 / quads);  // parts * se <= 2048; rows per thread <= 16 (se >= 32)
+    const int quads = se >> 2, parts = min(32, 512 / quads);  // squeeze FC: thread = (4 consecutive outputs, every parts-th own row); parts * se <= 2048
     const int oq = tid % quads, pt = tid / quads;
-    f16x4 w1r[16];
-    {
-        const unsigned char* g1 = (const unsigned char*)sp.w1t + ((size_t)kt * sp.nsizes + (bs - 2)) * sp.w1_bytes + oq * 8;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int r = pt + k * parts;
-            w1r[k] = (pt < parts && r < 256) ? *(const f16x4*)(g1 + (size_t)r * se * 2) : f16x4{0, 0, 0, 0};
-        }
-    }
 
     // ---- 1. pooling, 64 channels at a time through LDS
     sx_barrier();  // every wave is done with the rings
@@ -183,13 +172,14 @@ __global__ __launch_bounds__(512, 2) void conv_board_sx_kernel(const BoardSxPara
         sx_barrier();
     }
 
-    // ---- 2. the excite image of this channel tile into the (now free) stage area: it is needed behind the exchange.  The
-    // eighths folded in order meanwhile.
+    // ---- 2. the two images of this channel tile into the (now free) stage area; the eighths folded in order meanwhile
     {
-        const int n2 = sp.w2_bytes >> 10;
+        const int n1 = sp.w1_bytes >> 10, n2 = sp.w2_bytes >> 10;
+        const unsigned char* g1 = (const unsigned char*)sp.w1t + ((size_t)kt * sp.nsizes + (bs - 2)) * sp.w1_bytes;
         const unsigned char* g2 = (const unsigned char*)sp.w2t + (size_t)kt * sp.w2_bytes;
         const uint32_t l0 = (uint32_t)(uintptr_t)smem;
-        for (int k = wave; k < n2; k += 8) glds16_s(lane * 16, g2 + k * 1024, l0 + k * 1024);
+        for (int k = wave; k < n1; k += 8) glds16_s(lane * 16, g1 + k * 1024, l0 + k * 1024);
+        for (int k = wave; k < n2; k += 8) glds16_s(lane * 16, g2 + k * 1024, l0 + sp.w1_bytes + k * 1024);
     }
     {
         const float inv = 1.0f / (float)npix;
@@ -204,24 +194,24 @@ __global__ __launch_bounds__(512, 2) void conv_board_sx_kernel(const BoardSxPara
             pool[s * 256 + 128 + c] = x;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the two images have landed
     sx_barrier();
 
     if (dbg) dbg[2] = __builtin_amdgcn_s_memtime();
     // ---- 3. squeeze FC over the own 2 x 128 rows: thread = (4 consecutive outputs, every parts-th row), all samples at once
     {
         if (pt < parts) {
+            const unsigned char* w1 = smem + oq * 8;
             f32x4 a[kSxMaxSub];
 #pragma unroll
             for (int s = 0; s < kSxMaxSub; ++s) a[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int r = pt; r < 256; r += parts) {
+                const f16x4 w = *(const f16x4*)(w1 + (size_t)r * se * 2);
+                const f32x4 wf = {(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int r = pt + k * parts;
-                if (r < 256) {
-                    const f32x4 wf = {(float)w1r[k][0], (float)w1r[k][1], (float)w1r[k][2], (float)w1r[k][3]};
-#pragma unroll
-                    for (int s = 0; s < kSxMaxSub; ++s)
-                        if (s < nsub) a[s] += pool[s * 256 + r] * wf;
-                }
+                for (int s = 0; s < kSxMaxSub; ++s)
+                    if (s < nsub) a[s] += pool[s * 256 + r] * wf;
             }
 #pragma unroll
             for (int s = 0; s < kSxMaxSub; ++s)
@@ -261,11 +251,10 @@ __global__ __launch_bounds__(512, 2) void conv_board_sx_kernel(const BoardSxPara
         }
         if (gave_up) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)sp.err, sp.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the excite image have landed
     sx_barrier();
     if (dbg) dbg[4] = __builtin_amdgcn_s_memtime();
     // mid = act(b1 + p_0 + p_1 + ...): the same order in every sibling
-    const unsigned char* w2 = smem;
+    const unsigned char* w2 = smem + sp.w1_bytes;
     const float* b2 = (const float*)(w2 + (size_t)se * 256 * 2);  // excite bias of the own outputs
     const float* b1 = b2 + 256;                                    // squeeze bias
     for (int k = tid; k < nsub * se; k += 512) {
