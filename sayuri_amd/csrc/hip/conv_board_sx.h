@@ -10,7 +10,7 @@
 //   excite FC   gamma / beta of a workgroup's own channels need all of mid and only the own rows of W2: local again
 //   gate        x <- sigmoid(gamma) x + beta on the accumulators, then the ordinary epilogue (residual, activation, store)
 // so x never makes the round trip through HBM and the unit's three launches (se_pool / se_fc / se_scale: 58 us per unit on
-// configs[4]'s batch, 7 % of the forward) are gone.
+// configs[4]'s batch, 7 % of the forward) are gone.  What the stage costs instead: ~12 us per workgroup (profiles/r06_split_se_ab.txt).
 //
 // The exchange follows cdna_hip_programming.md section 6 Guideline 16, form R2 ("the data is the flag"): every partial is ONE
 // 8-byte granule {tag = the launch's epoch, value} written by one relaxed agent-scope store (sc1, write-through) and polled by
@@ -21,7 +21,7 @@
 // A tile may hold several samples of one size (two 13x13, four 9x9): the pooling is per SAMPLE and must not depend on where in
 // the tile the sample sits (a request's result is a function of the request, batch_forward_pipe.cc:15-33).  So it is not done on
 // the accumulator layout: the tile's accumulators go through LDS as [pixel slot][channel] fp32 (64 channels at a time), and
-// thread (sample, channel, quarter) adds the sample's pixels of its quarter IN PIXEL ORDER; the four quarters are folded in
+// wave e adds the e-th eighth of every sample's pixels IN PIXEL ORDER (lane = channel); the eight eighths are folded in
 // order.  The order of every sum is a function of the sample's own size alone.
 //
 // Progress: a workgroup waits for its siblings inside the launch, so the siblings must get to run.  Block index =
